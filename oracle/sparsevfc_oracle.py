@@ -1,0 +1,270 @@
+"""CPU ORACLE (test infrastructure, NOT product code) for the SparseVFC kernel-regression hot path.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module.
+The product (``spateo-release_amd/``) never imports it and has no CPU fallback.
+
+What it restates
+----------------
+Spateo's ``morphofield_sparsevfc`` calls ``dynamo.vectorfield.scVectorField.SparseVFC``
+(reference call sites: ``spateo/tdr/morphometrics/morphofield/sparsevfc.py:167,189-198,234`` and
+``spateo/tdr/interpolations/interpolation_sparseVFC.py:63``).  ``dynamo-release`` (pinned only as ``>=1.4.1`` in
+``requirements.txt:7``) is a third-party dependency that is NOT vendored in ``/root/reference`` and is not installed
+here, so this file restates its published algorithm (Ma et al., "Regularized vector field learning with sparse
+approximation for mismatch removal", Pattern Recognition 2013; dynamo 1.4.x ``SparseVFC``/``get_P``/``lstsq_solver``/
+``bandwidth_selector``/``sample_by_velocity``/``con_K``/``vector_field_function``) op-for-op in float64 NumPy/SciPy,
+including its inefficiencies (``cdist``+``exp``; the ``U.T * repmat(P.T, M, 1)`` M x N temporary;
+``scipy.linalg.lstsq``), following SURVEY.md Appendix A.
+
+PARITY STATUS
+-------------
+* ``con_K`` (both code paths) is pinned against the real in-tree twin
+  ``spateo/tdr/morphometrics/morphofield/gaussian_process.py:16-36`` executed in the build container
+  (``tests/golden/make_golden.py`` -> ``tests/golden/ref_twins.npz``).
+* The EM loop itself (``SparseVFC``, ``get_P``, ``lstsq_solver``, ``bandwidth_selector``, ``sample_by_velocity``) is
+  **parity unpinned**: the reference holds no test, golden vector or source for it.  It is
+  pinned only by analytic known-answer tests and cross-formulation checks in ``tests/test_oracle.py``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg
+from scipy.spatial.distance import cdist
+
+__all__ = [
+    "con_K",
+    "get_P",
+    "lstsq_solver",
+    "linear_least_squares",
+    "bandwidth_selector",
+    "sample_by_velocity",
+    "vector_field_function",
+    "SparseVFC",
+    "sparsevfc_setup",
+    "em_step",
+]
+
+
+def con_K(x, y, beta: float = 0.1, method: str = "cdist", return_d: bool = False):
+    """Gaussian RBF kernel ``K[i, j] = exp(-beta * ||x_i - y_j||^2)``.
+
+    Follows the in-tree twin ``gaussian_process.py:16-36`` (identical to dynamo's ``con_K``):
+    ``cdist(..., "sqeuclidean")`` path (``:21-24``, a single-row result is flattened to 1-D) and the explicit
+    difference path (``:25-29``) that also returns ``D[n, :, m] = x_n - y_m`` (n x d x m).
+    """
+    x = np.asarray(x)
+    y = np.asarray(y)
+    if x.ndim == 1:
+        x = x[None, :]
+    if method == "cdist" and not return_d:
+        K = cdist(x, y, "sqeuclidean")
+        if len(K) == 1:
+            K = K.flatten()
+        D = None
+    else:
+        # D[n, :, m] = x[n, :] - y[m, :]   (gaussian_process.py:26-28 builds it with tile/transpose)
+        D = x[:, :, None] - np.transpose(y[:, :, None], (2, 1, 0))
+        K = np.squeeze(np.sum(D**2, 1))
+    K = -beta * K
+    K = np.exp(K)
+    if return_d:
+        return K, D
+    return K
+
+
+def get_P(Y, V, sigma2, gamma, a):
+    """E-step (dynamo ``get_P``).  Returns (P as N x 1, energy E)."""
+    D = Y.shape[1]
+    r = np.sum((Y - V) ** 2, 1)
+    temp1 = np.exp(-r / (2 * sigma2))
+    temp2 = (2 * np.pi * sigma2) ** (D / 2) * (1 - gamma) / (gamma * a)
+    zero = temp1 == 0
+    if zero.any():
+        # dynamo: temp1[temp1 == 0] = np.min(temp1[temp1 != 0])
+        temp1[zero] = np.min(temp1[~zero])
+    P = temp1 / (temp1 + temp2)
+    E = P.T.dot(r) / (2 * sigma2) + np.sum(P) * np.log(sigma2) * D / 2
+    return P[:, None], float(E)
+
+
+def linear_least_squares(a, b):
+    """dynamo ``linear_least_squares`` (the ``"drouin"`` solver): normal equations through BLAS dgemm."""
+    a = np.asarray(a, order="c")
+    i = a.T.dot(a)
+    return np.linalg.solve(i, a.T.dot(b))
+
+
+def lstsq_solver(lhs, rhs, method: str = "drouin"):
+    """dynamo ``lstsq_solver``.  Spateo always passes ``"scipy"`` (``sparsevfc.py:110,194,250``):
+    ``scipy.linalg.lstsq`` = LAPACK gelsd, minimum-norm solution, singular values below eps*s_max dropped."""
+    if method == "scipy":
+        return scipy.linalg.lstsq(lhs, rhs)[0]
+    # "drouin" and (with a warning in dynamo) anything else
+    return linear_least_squares(lhs, rhs)
+
+
+def bandwidth_selector(X):
+    """dynamo ``bandwidth_selector``: exact kNN with k = max(2, int(0.2 n)) neighbours (self included);
+    ``d = mean(dist[:, 1:]) / 1.5``; ``h = sqrt(2) d``.  (dynamo uses sklearn kd-tree/ball-tree; exact either way.)"""
+    from sklearn.neighbors import NearestNeighbors
+
+    n, m = X.shape
+    k = max(2, int(0.2 * n))
+    alg = "ball_tree" if m > 10 else "kd_tree"
+    nbrs = NearestNeighbors(n_neighbors=k, algorithm=alg).fit(X)
+    distances, _ = nbrs.kneighbors(X)
+    d = np.mean(distances[:, 1:]) / 1.5
+    return np.sqrt(2) * d
+
+
+def sample_by_velocity(V, n, seed=19491001):
+    """dynamo ``tools.sampling.sample_by_velocity``: velocity-magnitude weighted sampling without replacement.
+
+    [VERIFY, SURVEY.md Appendix A step 2] dynamo's function carries its own ``seed=19491001`` default and re-seeds the
+    global RNG, which makes the result independent of ``SparseVFC(seed=...)``; restated as recalled."""
+    np.random.seed(seed)
+    tmp_V = np.linalg.norm(V, axis=1)
+    p = tmp_V / np.sum(tmp_V)
+    return np.random.choice(np.arange(len(V)), size=n, p=p, replace=False)
+
+
+def vector_field_function(x, vf_dict, dim=None):
+    """dynamo ``vector_field_function``: ``v(x) = con_K(x, X_ctrl, beta) @ C`` (call site
+    ``differential_geometry.py:67-68``; GP twin ``gaussian_process.py:102-127``)."""
+    x = np.array(x)
+    if x.ndim == 1:
+        x = x[None, :]
+    K = con_K(x, vf_dict["X_ctrl"], vf_dict["beta"])
+    K = K.dot(vf_dict["C"])
+    if dim is not None:
+        K = K[:, :dim] if np.isscalar(dim) else K[:, dim]
+    return K
+
+
+def sparsevfc_setup(X, Y, M=100, beta=None, velocity_based_sampling=True, seed=0):
+    """Preprocessing of ``SparseVFC`` (Appendix A steps 1-3): finite-row filter, unique rows, control points, beta."""
+    valid_ind = np.where(np.isfinite(Y.sum(1)))[0]
+    Xv, Yv = X[valid_ind], Y[valid_ind]
+    tmp_X, uid = np.unique(Xv, axis=0, return_index=True)
+    M = min(M, tmp_X.shape[0])
+    if velocity_based_sampling:
+        np.random.seed(seed)
+        idx = sample_by_velocity(Yv[uid], M)
+    else:
+        idx = np.random.RandomState(seed=seed).permutation(tmp_X.shape[0])
+        idx = idx[range(M)]
+    ctrl_pts = tmp_X[idx, :]
+    if beta is None:
+        h = bandwidth_selector(ctrl_pts)
+        beta = 1 / h**2
+    return valid_ind, Xv, Yv, idx, ctrl_pts, beta
+
+
+def em_step(U, K, Y, V, C, sigma2, gamma, E, *, a, lambda_, minP, theta, lstsq_method):
+    """One EM iteration exactly as the body of dynamo's ``while`` loop (Appendix A step 5 a-e).
+
+    Returns ``(P, E, tecr, C, V, sigma2, gamma)``.  This is also the unit timed as the reference CPU baseline."""
+    N, D = Y.shape
+    M = U.shape[1]
+    E_old = E
+    P, E = get_P(Y, V, sigma2, gamma, a)
+    E = E + lambda_ / 2 * np.trace(C.T.dot(K).dot(C))
+    tecr = abs((E - E_old) / E)
+
+    P = np.maximum(P, minP)
+    UP = U.T * np.tile(P.T, (M, 1))  # numpy.matlib.repmat(P.T, M, 1): the M x N temporary
+    lhs = UP.dot(U) + lambda_ * sigma2 * K
+    rhs = UP.dot(Y)
+    C = lstsq_solver(lhs, rhs, method=lstsq_method)
+
+    V = U.dot(C)
+    Sp = np.sum(P)
+    sigma2 = float(P[:, 0].dot(np.sum((Y - V) ** 2, 1)) / (Sp * D))
+
+    numcorr = len(np.where(P > theta)[0])
+    gamma = numcorr / N
+    gamma = 0.95 if gamma > 0.95 else (0.05 if gamma < 0.05 else gamma)
+    return P, E, tecr, C, V, sigma2, gamma
+
+
+def SparseVFC(
+    X,
+    Y,
+    Grid,
+    M=100,
+    a=5,
+    beta=None,
+    ecr=1e-5,
+    gamma=0.9,
+    lambda_=3,
+    minP=1e-5,
+    MaxIter=500,
+    theta=0.75,
+    div_cur_free_kernels=False,
+    velocity_based_sampling=True,
+    sigma=0.8,
+    eta=0.5,
+    seed=0,
+    lstsq_method="drouin",
+    verbose=1,
+):
+    """Restatement of ``dynamo.vectorfield.scVectorField.SparseVFC`` (defaults as dynamo's).
+
+    Spateo overrides ``M=100, lambda_=0.02, lstsq_method="scipy"`` and passes ``seed=restart_seed[k]``
+    (``sparsevfc.py:108-113,189-198``).  ``div_cur_free_kernels=True`` is out of scope."""
+    if div_cur_free_kernels:
+        raise NotImplementedError("div_cur_free_kernels=True is out of scope (SURVEY.md Appendix A)")
+    X = np.asarray(X, dtype=float)
+    Y = np.asarray(Y, dtype=float)
+    X_ori, Y_ori = X.copy(), Y.copy()
+    valid_ind, X, Y, idx, ctrl_pts, beta = sparsevfc_setup(
+        X, Y, M=M, beta=beta, velocity_based_sampling=velocity_based_sampling, seed=seed
+    )
+    N, D = Y.shape
+    grid_U = None
+
+    K = con_K(ctrl_pts, ctrl_pts, beta)
+    U = con_K(X, ctrl_pts, beta)
+    if U.ndim == 1:
+        U = U[None, :]
+    if Grid is not None:
+        grid_U = con_K(Grid, ctrl_pts, beta)
+    M = ctrl_pts.shape[0]
+
+    V = np.zeros((N, D))
+    C = np.zeros((M, D))
+    i, tecr, E = 0, 1, 1
+    sigma2 = np.sum((Y - V) ** 2) / (N * D)
+    sigma2 = 1e-7 if sigma2 < 1e-8 else sigma2
+    tecr_vec = np.ones(MaxIter) * np.nan
+    E_vec = np.ones(MaxIter) * np.nan
+    P = None
+    while i < MaxIter and tecr > ecr and sigma2 > 1e-8:
+        P, E, tecr, C, V, sigma2, gamma = em_step(
+            U, K, Y, V, C, sigma2, gamma, E, a=a, lambda_=lambda_, minP=minP, theta=theta, lstsq_method=lstsq_method
+        )
+        E_vec[i] = E
+        tecr_vec[i] = tecr
+        i += 1
+
+    grid_V = None
+    if Grid is not None:
+        grid_V = np.dot(grid_U, C)
+
+    return {
+        "X": X_ori,
+        "valid_ind": valid_ind,
+        "X_ctrl": ctrl_pts,
+        "ctrl_idx": idx,
+        "Y": Y_ori,
+        "beta": beta,
+        "V": V,
+        "C": C,
+        "P": P,
+        "VFCIndex": np.where(P > theta)[0],
+        "sigma2": sigma2,
+        "grid": Grid,
+        "grid_V": grid_V,
+        "iteration": i - 1,
+        "tecr_traj": tecr_vec[:i],
+        "E_traj": E_vec[:i],
+    }

@@ -1,0 +1,215 @@
+"""CPU tests that pin the oracle: (1) against the real reference twins' golden vectors, (2) analytic known answers,
+(3) cross-formulation checks for the part the reference does not hold (the dynamo EM loop)."""
+import numpy as np
+import pytest
+
+from oracle import dg_oracle as dgo
+from oracle import sparsevfc_oracle as svo
+
+RT = dict(rtol=1e-12, atol=1e-13)
+
+
+# ---------------------------------------------------------------- golden: con_K twins (gaussian_process.py:16-36)
+def test_con_k_matches_reference_twin(golden):
+    g = golden
+    x, y, beta = g["conk_x"], g["conk_y"], float(g["conk_beta"])
+    np.testing.assert_allclose(svo.con_K(x, y, beta), g["conk_K_cdist"], **RT)
+    K, D = svo.con_K(x, y, beta, return_d=True)
+    np.testing.assert_allclose(K, g["conk_K_diff"], **RT)
+    np.testing.assert_array_equal(D, g["conk_D"])  # plain differences: bit-exact
+    Krow = svo.con_K(x[2], y, beta)
+    assert Krow.shape == g["conk_K_row"].shape == (len(y),)  # 1-row input is flattened
+    np.testing.assert_allclose(Krow, g["conk_K_row"], **RT)
+    np.testing.assert_allclose(svo.con_K(g["conk_x2"], g["conk_y2"], 0.5), g["conk_K_2d"], **RT)
+
+
+def test_con_k_paths_agree_and_gram_properties():
+    rng = np.random.default_rng(1)
+    c = rng.standard_normal((20, 3)) * 3
+    K1 = svo.con_K(c, c, 0.1)
+    K2, _ = svo.con_K(c, c, 0.1, return_d=True)
+    np.testing.assert_allclose(K1, K2, rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(K1, K1.T, atol=1e-15)
+    np.testing.assert_allclose(np.diag(K1), 1.0)
+
+
+# ---------------------------------------------------------------- golden: Jacobian + evaluators (GPVectorField.py)
+def _vfd(g):
+    return {"X_ctrl": g["dg_Xc"], "C": g["dg_C"], "beta": float(g["dg_beta"])}
+
+
+def test_jacobian_matches_reference_twin(golden):
+    g, vfd = golden, _vfd(golden)
+    Xq = g["dg_Xq"]
+    np.testing.assert_allclose(dgo.Jacobian_rkhs_gaussian(Xq, vfd), g["dg_J_loop"], **RT)
+    np.testing.assert_allclose(dgo.Jacobian_rkhs_gaussian(Xq, vfd, vectorize=True), g["dg_J_vec"], **RT)
+    J1 = dgo.Jacobian_rkhs_gaussian(Xq[3], vfd)
+    assert J1.shape == (3, 3)
+    np.testing.assert_allclose(J1, g["dg_J_1d"], **RT)
+
+
+def test_evaluators_match_reference_twin(golden):
+    g, vfd = golden, _vfd(golden)
+    Xq = g["dg_Xq"]
+    vf = lambda x: svo.vector_field_function(x, vfd)  # noqa: E731
+    fj = lambda x: dgo.Jacobian_rkhs_gaussian(x, vfd)  # noqa: E731
+    np.testing.assert_allclose(vf(Xq), g["dg_v"], **RT)
+    acc, acc_mat = dgo.compute_acceleration(vf, fj, Xq)
+    np.testing.assert_allclose(acc, g["dg_acc"], **RT)
+    np.testing.assert_allclose(acc_mat, g["dg_acc_mat"], **RT)
+    c2, c2m = dgo.compute_curvature(vf, fj, Xq, formula=2)
+    np.testing.assert_allclose(c2, g["dg_curv2"], **RT)
+    np.testing.assert_allclose(c2m, g["dg_curv2_mat"], **RT)
+    c1, c1m = dgo.compute_curvature(vf, fj, Xq, formula=1)
+    assert c1m is None
+    np.testing.assert_allclose(c1, g["dg_curv1"], **RT)
+    curl = dgo.compute_curl(fj, Xq)
+    assert curl.shape == (len(Xq), 3, 3)  # reference quirk: 3-vector broadcast over 3 rows
+    np.testing.assert_allclose(curl, g["dg_curl"], **RT)
+    tor = dgo.compute_torsion(vf, fj, Xq)
+    assert tor.shape == (len(Xq), 3, 3)
+    np.testing.assert_allclose(tor, g["dg_tor"], **RT)
+    np.testing.assert_allclose(dgo.compute_divergence(fj, Xq, vectorize_size=4), g["dg_div"], **RT)
+    vfd2 = {"X_ctrl": g["dg_Xc"][:, :2], "C": g["dg_C"][:, :2], "beta": vfd["beta"]}
+    curl2 = dgo.compute_curl(lambda x: dgo.Jacobian_rkhs_gaussian(x, vfd2), Xq[:, :2])
+    np.testing.assert_allclose(curl2, g["dg_curl2d"], **RT)
+
+
+def test_torsion_rejects_non_3d():
+    with pytest.raises(Exception, match="torsion is only defined in 3 dimension"):
+        dgo.compute_torsion(None, None, np.zeros((4, 2)))
+    with pytest.raises(ValueError):
+        dgo.compute_curl(lambda x: np.zeros((4, 4)), np.zeros((3, 4)))
+
+
+# ---------------------------------------------------------------- analytic known answers
+def test_jacobian_vs_central_differences():
+    rng = np.random.default_rng(3)
+    vfd = {"X_ctrl": rng.standard_normal((25, 3)) * 4, "C": rng.standard_normal((25, 3)), "beta": 0.05}
+    x = rng.standard_normal((6, 3)) * 3
+    J = dgo.Jacobian_rkhs_gaussian(x, vfd)
+    h = 1e-5
+    for j in range(3):
+        e = np.zeros(3)
+        e[j] = h
+        fd = (svo.vector_field_function(x + e, vfd) - svo.vector_field_function(x - e, vfd)) / (2 * h)  # n x f
+        np.testing.assert_allclose(J[:, j, :].T, fd, rtol=1e-6, atol=1e-9)
+
+
+def _fit_linear_field(A, n=1500, M=200, seed=0, noise=0.005):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1, 1, (n, 3)) * 10
+    Y = X @ A.T + noise * rng.standard_normal((n, 3))
+    vf = svo.SparseVFC(X, Y, None, M=M, lambda_=0.02, lstsq_method="scipy", MaxIter=60)
+    return X, Y, vf
+
+
+def test_rotation_field_curl_and_divergence():
+    w = 0.03
+    A = np.array([[0, -w, 0], [w, 0, 0], [0, 0, 0.0]])  # rigid rotation about z: curl = (0,0,2w), div = 0
+    X, Y, vf = _fit_linear_field(A)
+    sel = np.linalg.norm(X, axis=1) < 6
+    np.testing.assert_allclose(vf["V"][sel], Y[sel], atol=0.1 * np.abs(Y).max())
+    inner = X[sel][:40]
+    fj = lambda x: dgo.Jacobian_rkhs_gaussian(x, vf)  # noqa: E731
+    curl = dgo.compute_curl(fj, inner)
+    np.testing.assert_allclose(curl[:, 0, :], np.tile([0, 0, 2 * w], (len(inner), 1)), atol=0.3 * w)
+    np.testing.assert_allclose(curl[:, 1, :], curl[:, 0, :])  # broadcast rows
+    np.testing.assert_allclose(dgo.compute_divergence(fj, inner), 0, atol=0.3 * w)
+
+
+def test_radial_field_divergence_and_recovered_jacobian():
+    g = 0.02
+    A = g * np.eye(3) + np.array([[0, 0.004, 0], [0, 0, -0.003], [0.002, 0, 0]])
+    X, Y, vf = _fit_linear_field(A, seed=4)
+    inner = X[np.linalg.norm(X, axis=1) < 6][:40]
+    J = dgo.Jacobian_rkhs_gaussian(inner, vf)
+    np.testing.assert_allclose(J, np.repeat(A[:, :, None], len(inner), axis=2), atol=0.2 * g)
+    div = dgo.compute_divergence(lambda x: dgo.Jacobian_rkhs_gaussian(x, vf), inner)
+    np.testing.assert_allclose(div, 3 * g, atol=0.4 * g)
+
+
+# ---------------------------------------------------------------- EM loop invariants + cross-formulations
+def _c1(seed=1, n=1000, M=100):
+    """BASELINE config 1: 2-D synthetic 1k-cell displacement field, M = 100 (noise 0.1 instead of the
+    survey's 0.5, at which the EM collapses onto ~20 % of the cells under dynamo's default ``a = 5``)."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0, 1, (n, 2)) * 100
+    th = np.deg2rad(30)
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    V = 0.05 * (X - 50) @ (R - np.eye(2)).T + 0.1 * rng.standard_normal((n, 2))
+    out = rng.choice(n, n // 10, replace=False)
+    V[out] = 5 * rng.standard_normal((len(out), 2))
+    gx, gy = np.meshgrid(np.linspace(0, 100, 20), np.linspace(0, 100, 20))
+    NX = np.column_stack([gx.ravel(), gy.ravel()])
+    return X, V, NX, out
+
+
+def test_config1_2d_em_invariants():
+    X, V, NX, out = _c1()
+    vf = svo.SparseVFC(X, V, NX, M=100, lambda_=0.02, lstsq_method="scipy")
+    N = len(X)
+    assert vf["P"].shape == (N, 1) and vf["V"].shape == (N, 2) and vf["C"].shape == (100, 2)
+    assert vf["grid_V"].shape == (400, 2)
+    assert np.all(vf["P"] >= 1e-5) and np.all(vf["P"] <= 1.0)
+    assert np.isfinite(vf["E_traj"]).all() and len(vf["E_traj"]) == vf["iteration"] + 1 == len(vf["tecr_traj"])
+    assert vf["sigma2"] > 0
+    U = svo.con_K(X, vf["X_ctrl"], vf["beta"])
+    np.testing.assert_allclose(vf["V"], U @ vf["C"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(vf["grid_V"], svo.vector_field_function(NX, vf), rtol=1e-10, atol=1e-12)
+    # the gross outliers are rejected, most inliers kept
+    inl = np.ones(N, bool)
+    inl[out] = False
+    assert (vf["P"][out, 0] < 0.75).mean() > 0.8
+    assert (vf["P"][inl, 0] > 0.75).mean() > 0.9
+    assert set(vf["VFCIndex"]) == set(np.where(vf["P"][:, 0] > 0.75)[0])
+
+
+def test_em_step_lhs_symmetric_and_solver_cross_check():
+    X, V, _, _ = _c1(seed=2, n=400, M=30)
+    valid, Xv, Yv, idx, ctrl, beta = svo.sparsevfc_setup(X, V, M=30, seed=0)
+    K = svo.con_K(ctrl, ctrl, beta)
+    U = svo.con_K(Xv, ctrl, beta)
+    P, _ = svo.get_P(Yv, np.zeros_like(Yv), 1.3, 0.9, 5)
+    P = np.maximum(P, 1e-5)
+    lhs = (U.T * P.T) @ U + 0.5 * 1.3 * K  # well-regularised: all three solvers must agree
+    rhs = (U.T * P.T) @ Yv
+    np.testing.assert_allclose(lhs, lhs.T, rtol=1e-12, atol=1e-12)
+    c_scipy = svo.lstsq_solver(lhs, rhs, "scipy")
+    c_chol = np.linalg.solve(lhs, rhs)
+    np.testing.assert_allclose(U @ c_scipy, U @ c_chol, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(U @ c_scipy, U @ (np.linalg.pinv(lhs) @ rhs), rtol=1e-7, atol=1e-9)
+
+
+def test_get_P_zero_replacement_and_bounds():
+    Y = np.array([[0.0, 0.0], [100.0, 0.0], [0.1, 0.1]])
+    V = np.zeros_like(Y)
+    P, E = svo.get_P(Y, V, 1e-3, 0.9, 5)  # exp(-1e4/2e-3) underflows to 0 -> replaced by the min non-zero
+    assert P.shape == (3, 1) and np.isfinite(E)
+    assert P[1, 0] == P[2, 0] > 0 and P[0, 0] > 0.99  # the underflowed row inherits the smallest non-zero t1
+
+
+def test_non_finite_rows_are_dropped():
+    X, V, _, _ = _c1(seed=5, n=300, M=20)
+    V[[3, 17]] = np.nan
+    vf = svo.SparseVFC(X, V, None, M=20, lambda_=0.02, lstsq_method="scipy", MaxIter=5)
+    assert len(vf["valid_ind"]) == 298 and vf["V"].shape == (298, 2) and vf["X"].shape == (300, 2)
+    assert vf["grid_V"] is None
+
+
+def test_control_points_are_unique_rows_and_M_clipped():
+    X = np.repeat(np.arange(12.0).reshape(4, 3), 5, axis=0)
+    Y = np.ones_like(X)
+    vf = svo.SparseVFC(X, Y, None, M=10, lstsq_method="scipy", MaxIter=2, beta=0.1)
+    assert vf["X_ctrl"].shape == (4, 3)
+    assert len(np.unique(vf["X_ctrl"], axis=0)) == 4
+
+
+def test_bandwidth_selector_matches_bruteforce():
+    rng = np.random.default_rng(7)
+    c = rng.standard_normal((50, 3))
+    from scipy.spatial.distance import cdist
+
+    d = np.sort(cdist(c, c), axis=1)[:, : max(2, int(0.2 * 50))]
+    h = np.sqrt(2) * np.mean(d[:, 1:]) / 1.5
+    np.testing.assert_allclose(svo.bandwidth_selector(c), h, rtol=1e-12)
