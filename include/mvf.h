@@ -1,0 +1,129 @@
+/*
+ * mvf.h -- C ABI of libmvf.so, the MI355X (gfx950) morphometric vector-field engine.
+ *
+ * This is the drop-in boundary for ONE hot path of aristoteleo/spateo-release: the SparseVFC kernel regression
+ * under spateo.tdr (con_K -> EM loop -> coefficient solve -> differential-geometry evaluators).  The reference has
+ * no native code and no FFI for this path (SURVEY.md "Three facts", section 8b): its arithmetic lives in Python
+ * (third-party `dynamo` + in-tree twins).  Each entry point below therefore cites the reference *Python* interface
+ * it replaces (file:line under /root/reference); INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.  All data pointers are DEVICE pointers
+ *     (hipMalloc'd by the caller, e.g. torch tensors' data_ptr()); the library never allocates or frees memory
+ *     and never takes ownership.  Workspaces are caller-provided and sized by the *_workspace_bytes queries.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Every call is asynchronous on it.
+ *   - `dtype` selects the arithmetic of the cell-sized arrays: MVF_F32 or MVF_F64.  Reductions, the Gram matrix,
+ *     the coefficient solve and the coefficients C are always float64.
+ *   - Row-major, dense, no strides.  Cell coordinates / displacements use the padded layout "x4": n rows of
+ *     4 elements (x, y, z, 0) so that one lane loads one cell with a single 16/32-byte access; 2-D data sets z = 0.
+ *   - Return value: 0 = ok; non-zero = error, message in mvf_last_error() (thread-local).  No exceptions cross
+ *     the boundary.  The Python host raises RuntimeError on a non-zero status.
+ */
+#ifndef MVF_H
+#define MVF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { MVF_F32 = 0, MVF_F64 = 1 } mvf_dtype;
+
+/* evaluator output selection flags for mvf_eval */
+enum {
+    MVF_EVAL_V = 1,        /* v(x)                      n x 3            */
+    MVF_EVAL_JAC = 2,      /* Jacobian                  (3, 3, n) layout */
+    MVF_EVAL_DIV = 4,      /* divergence = trace J      n                */
+    MVF_EVAL_CURL = 8,     /* curl 3-vector             n x 3            */
+    MVF_EVAL_ACC = 16,     /* acceleration a = J v      n x 3            */
+    MVF_EVAL_CURV = 32,    /* curvature vector (f. 2)   n x 3            */
+    MVF_EVAL_TORS = 64,    /* torsion 3-vector          n x 3            */
+    MVF_EVAL_JDET = 128    /* det J                     n                */
+};
+
+/* ---- library ------------------------------------------------------------------------------------------------ */
+const char* mvf_last_error(void);
+int mvf_version(void);                 /* ABI version, currently 1 */
+int mvf_device_count(int* count);      /* number of visible HIP devices (0 without a GPU) */
+
+/* ---- con_K ----------------------------------------------------------------------------------------------------
+ * K[i, j] = exp(-beta * ||x_i - y_j||^2), materialised n x m row-major.
+ * Replaces: dynamo `con_K` / in-tree twin `_con_K` spateo/tdr/morphometrics/morphofield/gaussian_process.py:16-36
+ * (cdist path :21-24).  x: n x d, y: m x d, plain row-major (NOT x4), 1 <= d <= 8.  HBM-write-bound. */
+int mvf_con_k(const void* x, int64_t n, const void* y, int64_t m, int d, double beta, void* K, mvf_dtype dtype,
+              void* stream);
+/* return_d=True variant (gaussian_process.py:25-29): also D[n, :, m] = x_n - y_m as n x d x m. */
+int mvf_con_k_d(const void* x, int64_t n, const void* y, int64_t m, int d, double beta, void* K, void* D,
+                mvf_dtype dtype, void* stream);
+
+/* ---- field evaluation:  V = con_K(x, ctrl, beta) @ C  ---------------------------------------------------------
+ * Replaces: dynamo `vector_field_function` (call site differential_geometry.py:67-68; twin `_gp_velocity`
+ * gaussian_process.py:102-127), `V = U.dot(C)` and `grid_V = grid_U.dot(C)` of SparseVFC.
+ * U is never materialised: kernel values are recomputed from x and ctrl.  x4: n x 4, ctrl4: m x 4 (dtype),
+ * C: m x 3 float64 (unused columns zero), V4 out: n x 4 (dtype, 4th = 0).
+ * If y4 != NULL also writes r[i] = ||y_i - V_i||^2 (dtype) and, if P != NULL (dtype, n), accumulates
+ * stats[0] += sum_i P_i r_i  (float64; caller zeroes stats). */
+int mvf_apply(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, const double* C, void* V4,
+              const void* y4, const void* P, void* r, double* stats, mvf_dtype dtype, void* stream);
+
+/* ---- E-step ---------------------------------------------------------------------------------------------------
+ * Replaces: dynamo `get_P` + the `P = max(P, minP)` / numcorr lines of SparseVFC.
+ * Input r (dtype, n) = ||Y - V||^2.  Two phases so that the min-non-zero rule `temp1[temp1 == 0] =
+ * min(temp1[temp1 != 0])` can be made global across ranks between them:
+ *   mvf_estep_min : mins[0] = min non-zero exp(-r/(2 sigma2)) (float64, +inf if none), mins[1] = #zeros;
+ *                   `mins` must hold MVF_ESTEP_MIN_DOUBLES float64 (the tail is block-partial scratch)
+ *   mvf_estep_p   : P_out (dtype, n) = max(P, minP) with P = t1/(t1+t2);  stats (float64[4], caller zeroes):
+ *                   [0] += sum P_unfloored * r, [1] += sum P_unfloored, [2] += sum P_floored, [3] += #(P_floored > theta)
+ * All arithmetic in float64 regardless of dtype. */
+#define MVF_ESTEP_MIN_DOUBLES 4098
+int mvf_estep_min(const void* r, int64_t n, double sigma2, double* mins, mvf_dtype dtype, void* stream);
+int mvf_estep_p(const void* r, int64_t n, double sigma2, double gamma, double a, int dy, double minP, double theta,
+                double t1_zero_fill, void* P_out, double* stats, mvf_dtype dtype, void* stream);
+
+/* ---- M-step assembly:  G = U^T diag(P) U (m x m),  R = U^T diag(P) Y (m x 3)  --------------------------------
+ * Replaces: `UP = U.T * repmat(P.T, M, 1); lhs = UP.dot(U) ...; rhs = UP.dot(Y)` of SparseVFC (App. A 5c; same
+ * shape in-tree at spateo/alignment/methods/morpho_class.py:1266-1293).  MFMA kernel; U tiles are regenerated from
+ * x4/ctrl4 in registers, accumulated in short float32 MFMA chains folded into float64, reduced deterministically.
+ * Outputs are float64: G (m x m, full symmetric), R (m x 3).  They hold THIS rank's partial sums; the caller
+ * all-reduces [G | R | scalars] across ranks (one RCCL all-reduce per EM step). */
+size_t mvf_gram_workspace_bytes(int64_t n, int64_t m, mvf_dtype dtype);
+int mvf_gram(const void* x4, const void* P, const void* y4, int64_t n, const void* ctrl4, int64_t m, double beta,
+             double* G, double* R, void* workspace, size_t workspace_bytes, mvf_dtype dtype, void* stream);
+/* Same, one stage at a time (mask of MVF_GRAM_STAGE_*): TILES = the MFMA kernel writing per-slice partial tiles into
+ * the workspace, RHS = the U^T P Y kernel, REDUCE = fixed-order sums of the partials into G and R.  mvf_gram ==
+ * all three.  Lets a caller bracket the dominant kernel with HIP events on `stream` (bench.py's roofline). */
+enum { MVF_GRAM_STAGE_TILES = 1, MVF_GRAM_STAGE_RHS = 2, MVF_GRAM_STAGE_REDUCE = 4 };
+int mvf_gram_stages(int stages, const void* x4, const void* P, const void* y4, int64_t n, const void* ctrl4,
+                    int64_t m, double beta, double* G, double* R, void* workspace, size_t workspace_bytes,
+                    mvf_dtype dtype, void* stream);
+
+/* ---- coefficient solve:  (G + lambda_sigma2 * K + jitter * mean(diag) * I) C = R  ------------------------------
+ * Replaces: dynamo `lstsq_solver(lhs, rhs, "scipy")` as Spateo calls it (sparsevfc.py:110,194,250).  Blocked
+ * right-looking Cholesky in float64 (MFMA f64 for the trailing update) + forward/back substitution.  The system is
+ * symmetric PSD and numerically rank-deficient; see DESIGN.md for why the field (not C) is the parity quantity.
+ * G, K: m x m float64 (read-only), R: m x nrhs, C out: m x nrhs.  info[0] = 0 on success, or 1 + index of the first
+ * non-positive pivot (caller retries with a larger jitter).  workspace >= mvf_solve_workspace_bytes. */
+size_t mvf_solve_workspace_bytes(int64_t m, int nrhs);
+int mvf_solve(const double* G, const double* K, double lambda_sigma2, double jitter, const double* R, int64_t m,
+              int nrhs, double* C, int* info, void* workspace, size_t workspace_bytes, void* stream);
+
+/* trace(C^T K C) -> out[0] (float64), the regulariser of the energy (App. A 5b). K: m x m, C: m x nrhs. */
+int mvf_quadform(const double* K, const double* C, int64_t m, int nrhs, double* out, void* stream);
+
+/* ---- differential-geometry evaluators -------------------------------------------------------------------------
+ * Replaces: dynamo `Jacobian_rkhs_gaussian` and `compute_{acceleration,curvature,curl,torsion,divergence}` =
+ * in-tree twins spateo/tdr/morphometrics/morphofield_dg/GPVectorField.py:143-190 and :12-121 (wrappers
+ * differential_geometry.py:42-341).  One fused kernel: per query point, one pass over the control points
+ * accumulates v (3) and J (3x3) in float64, then derives the requested quantities in registers.
+ * x4: n x 4 (dtype), ctrl4: m x 4 (dtype), C: m x 3 float64.  Outputs are float64, NULL if not requested:
+ * v, curl, acc, curv, tors: n x 3;  jac: (3, 3, n) = J[f][i][n];  div, jdet: n.  `flags` = MVF_EVAL_* bits. */
+int mvf_eval(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, const double* C, int flags,
+             double* v, double* jac, double* div, double* curl, double* acc, double* curv, double* tors,
+             double* jdet, mvf_dtype dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVF_H */

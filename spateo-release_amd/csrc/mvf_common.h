@@ -1,0 +1,96 @@
+// Shared host/device helpers for libmvf (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/mvf.h"
+
+namespace mvf {
+
+// ---- error channel (thread-local message + int status across the C ABI) ----
+char* err_buf();
+int set_error(const char* fmt, ...);
+
+#define MVF_CHECK_HIP(expr)                                                                      \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) return ::mvf::set_error("%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+#define MVF_REQUIRE(cond, ...)                       \
+    do {                                             \
+        if (!(cond)) return ::mvf::set_error(__VA_ARGS__); \
+    } while (0)
+
+#define MVF_LAUNCH_CHECK() MVF_CHECK_HIP(hipGetLastError())
+
+constexpr int WAVE = 64;
+
+// log2(e): exp(-beta d^2) == exp2(-(beta*log2e) d^2); coordinates are pre-scaled by sqrt(beta*log2e)
+constexpr double LOG2E = 1.4426950408889634074;
+
+template <typename T>
+struct Vec4;
+template <>
+struct Vec4<float> {
+    using type = float4;
+};
+template <>
+struct Vec4<double> {
+    using type = double4;
+};
+
+// exp2 of a non-positive argument
+__device__ __forceinline__ float exp2_neg(float e) { return __builtin_amdgcn_exp2f(e); }  // v_exp_f32
+__device__ __forceinline__ double exp2_neg(double e) { return exp2(e); }
+
+// ---- wave / block reductions (wave64 shuffles, then LDS across waves) ----
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+// Sum `v` over a block of NT threads (NT multiple of 64, <= 1024); result valid in thread 0.
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double* sm /* >= NT/64 doubles */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) t += sm[i];
+    }
+    return t;
+}
+template <int NT>
+__device__ __forceinline__ double block_min(double v, double* sm) {
+    v = wave_min(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    double t = INFINITY;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) t = fmin(t, sm[i]);
+    }
+    return t;
+}
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace mvf

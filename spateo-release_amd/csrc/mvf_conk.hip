@@ -1,0 +1,142 @@
+// con_K: materialised Gaussian RBF kernel  K[i, j] = exp(-beta ||x_i - y_j||^2)   (n x m row-major)
+//
+// Reference: dynamo `con_K` / in-tree twin spateo/tdr/morphometrics/morphofield/gaussian_process.py:16-36.
+// Roofline: HBM-WRITE bound (algorithmic bytes = s*(n*m + n*d + m*d)); ~7 VALU + 1 v_exp per element.
+//
+// Mapping: a lane owns VEC consecutive columns (16 bytes: 4 floats / 2 doubles) so a wave stores 1 KiB contiguous
+// per row with one dwordx4 store; a block of 256 lanes covers 256*VEC columns and loops over ROWS rows, keeping its
+// VEC control points (pre-scaled by sqrt(beta*log2e)) in registers.  Row coordinates are wave-uniform -> scalar
+// loads.  Output is streamed with non-temporal stores (never re-read by this kernel).
+#include "mvf_common.h"
+
+namespace mvf {
+
+template <typename T, int D, int VEC>
+__global__ __launch_bounds__(256) void conk_kernel(const T* __restrict__ x, int64_t n, const T* __restrict__ y,
+                                                   int64_t m, T s /* sqrt(beta*log2e) */, T* __restrict__ K,
+                                                   int rows_per_block, int dyn_d) {
+    const int d = D > 0 ? D : dyn_d;
+    const int64_t j0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+    const int64_t i0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t i1 = min(i0 + rows_per_block, n);
+    constexpr int DMAX = D > 0 ? D : 8;
+    T c[VEC][DMAX];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) c[v][k] = (k < d && j0 + v < m) ? y[(j0 + v) * d + k] * s : T(0);
+    if (j0 >= m) return;
+    const bool full = (j0 + VEC <= m) && ((m % VEC) == 0);  // aligned vector store possible
+    for (int64_t i = i0; i < i1; ++i) {
+        T xi[DMAX];
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) xi[k] = (k < d) ? x[i * d + k] * s : T(0);  // wave-uniform
+        T out[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            T e = T(0);
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) {
+                if (k < d) {
+                    const T t = xi[k] - c[v][k];
+                    e = fma(t, t, e);
+                }
+            }
+            out[v] = exp2_neg(-e);
+        }
+        T* dst = K + i * m + j0;
+        if (full) {
+            if constexpr (sizeof(T) == 4 && VEC == 4) {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                f4 o = {out[0], out[1], out[2], out[3]};
+                __builtin_nontemporal_store(o, reinterpret_cast<f4*>(dst));
+            } else if constexpr (sizeof(T) == 8 && VEC == 2) {
+                typedef double d2 __attribute__((ext_vector_type(2)));
+                d2 o = {out[0], out[1]};
+                __builtin_nontemporal_store(o, reinterpret_cast<d2*>(dst));
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) dst[v] = out[v];
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                if (j0 + v < m) dst[v] = out[v];
+        }
+    }
+}
+
+// D[n, :, m] = x_n - y_m  (n x d x m), the return_d=True companion (gaussian_process.py:25-29).
+template <typename T>
+__global__ __launch_bounds__(256) void conk_diff_kernel(const T* __restrict__ x, int64_t n, const T* __restrict__ y,
+                                                        int64_t m, int d, T* __restrict__ Dout) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j >= m) return;
+    for (int k = 0; k < d; ++k) Dout[(i * d + k) * m + j] = x[i * d + k] - y[j * d + k];
+}
+
+template <typename T, int VEC>
+static int launch_conk(const T* x, int64_t n, const T* y, int64_t m, int d, double beta, T* K, hipStream_t st) {
+    const T s = (T)std::sqrt(beta * LOG2E);
+    const int rows = 32;
+    dim3 grid((unsigned)cdiv(m, 256 * VEC), (unsigned)cdiv(n, rows));
+    if (d == 3)
+        hipLaunchKernelGGL((conk_kernel<T, 3, VEC>), grid, dim3(256), 0, st, x, n, y, m, s, K, rows, d);
+    else if (d == 2)
+        hipLaunchKernelGGL((conk_kernel<T, 2, VEC>), grid, dim3(256), 0, st, x, n, y, m, s, K, rows, d);
+    else
+        hipLaunchKernelGGL((conk_kernel<T, 0, VEC>), grid, dim3(256), 0, st, x, n, y, m, s, K, rows, d);
+    MVF_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace mvf
+
+using namespace mvf;
+
+extern "C" int mvf_con_k(const void* x, int64_t n, const void* y, int64_t m, int d, double beta, void* K,
+                         mvf_dtype dtype, void* stream) {
+    MVF_REQUIRE(n >= 0 && m >= 0 && d >= 1 && d <= 8, "mvf_con_k: bad shape n=%lld m=%lld d=%d", (long long)n,
+                (long long)m, d);
+    MVF_REQUIRE(beta >= 0.0 && std::isfinite(beta), "mvf_con_k: beta must be finite and >= 0");
+    if (n == 0 || m == 0) return 0;
+    MVF_REQUIRE(x && y && K, "mvf_con_k: null pointer");
+    MVF_REQUIRE(cdiv(n, 32) <= 65535 * 1024LL, "mvf_con_k: n too large");
+    hipStream_t st = (hipStream_t)stream;
+    // grid.y is limited to 65535: chunk rows
+    const int64_t max_rows = 65535LL * 32;
+    for (int64_t r0 = 0; r0 < n; r0 += max_rows) {
+        const int64_t nr = (n - r0 < max_rows) ? n - r0 : max_rows;
+        int rc;
+        if (dtype == MVF_F32)
+            rc = launch_conk<float, 4>((const float*)x + r0 * d, nr, (const float*)y, m, d, beta,
+                                       (float*)K + r0 * m, st);
+        else if (dtype == MVF_F64)
+            rc = launch_conk<double, 2>((const double*)x + r0 * d, nr, (const double*)y, m, d, beta,
+                                        (double*)K + r0 * m, st);
+        else
+            return set_error("mvf_con_k: bad dtype %d", (int)dtype);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int mvf_con_k_d(const void* x, int64_t n, const void* y, int64_t m, int d, double beta, void* K, void* D,
+                           mvf_dtype dtype, void* stream) {
+    int rc = mvf_con_k(x, n, y, m, d, beta, K, dtype, stream);
+    if (rc) return rc;
+    if (n == 0 || m == 0) return 0;
+    MVF_REQUIRE(D, "mvf_con_k_d: null D");
+    MVF_REQUIRE(n <= 65535, "mvf_con_k_d: n <= 65535 rows per call (D is n x d x m)");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)cdiv(m, 256), (unsigned)n);
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(conk_diff_kernel<float>, grid, dim3(256), 0, st, (const float*)x, n, (const float*)y, m,
+                           d, (float*)D);
+    else
+        hipLaunchKernelGGL(conk_diff_kernel<double>, grid, dim3(256), 0, st, (const double*)x, n, (const double*)y,
+                           m, d, (double*)D);
+    MVF_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,275 @@
+// EM-loop kernels that are NOT the Gram matrix: field application V = U C (+ residuals), E-step, quadratic form.
+//
+// U = con_K(x, ctrl, beta) is never materialised: every kernel regenerates K(x_n, c_m) from 16-byte cell / control
+// point records.  Control points (pre-scaled by sqrt(beta*log2e)) and coefficients are staged through LDS in chunks
+// and read back with broadcast ds_read_b128; a lane owns CPT cells so that VALU work (6 flops + v_exp + 3 f64 FMA per
+// pair and cell) outweighs the LDS broadcast traffic.  Accumulation of V is float64 in every mode: the solve is
+// ill-conditioned, C can carry large cancelling coefficients, and the kernel is a ~1 % slice of an EM step anyway.
+#include "mvf_common.h"
+
+namespace mvf {
+
+// ----------------------------------------------------------------------------------------------------------------
+// apply: V = con_K(x, ctrl) @ C ; optional residual r = ||y - V||^2 and stats[0] += sum P r
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int APPLY_CHUNK = 512;  // control points per LDS stage
+
+template <typename T, int CPT>
+__global__ __launch_bounds__(256) void apply_kernel(const T* __restrict__ x4, int64_t n, const T* __restrict__ ctrl4,
+                                                    int64_t m, T s, const double* __restrict__ C /* m x 3 */,
+                                                    T* __restrict__ V4, const T* __restrict__ y4,
+                                                    const T* __restrict__ P, T* __restrict__ r,
+                                                    double* __restrict__ stats) {
+    using V4T = typename Vec4<T>::type;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[APPLY_CHUNK * (sizeof(V4T) + 4 * sizeof(double))];
+    V4T* sc = reinterpret_cast<V4T*>(smem_raw);                                         // scaled ctrl coords
+    double4* sC = reinterpret_cast<double4*>(smem_raw + APPLY_CHUNK * sizeof(V4T));     // coefficients (c0,c1,c2,0)
+
+    const int64_t base = ((int64_t)blockIdx.x * 256) * CPT + threadIdx.x;
+    T px[CPT], py[CPT], pz[CPT];
+    double v0[CPT], v1[CPT], v2[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const int64_t i = base + (int64_t)c * 256;
+        V4T xv = (i < n) ? reinterpret_cast<const V4T*>(x4)[i] : V4T{0, 0, 0, 0};
+        px[c] = xv.x * s;
+        py[c] = xv.y * s;
+        pz[c] = xv.z * s;
+        v0[c] = v1[c] = v2[c] = 0.0;
+    }
+
+    for (int64_t m0 = 0; m0 < m; m0 += APPLY_CHUNK) {
+        const int mc = (int)min((int64_t)APPLY_CHUNK, m - m0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < APPLY_CHUNK; j += 256) {
+            if (j < mc) {
+                V4T cv = reinterpret_cast<const V4T*>(ctrl4)[m0 + j];
+                sc[j] = V4T{cv.x * s, cv.y * s, cv.z * s, 0};
+                const double* cp = C + (m0 + j) * 3;
+                sC[j] = double4{cp[0], cp[1], cp[2], 0.0};
+            } else {
+                sc[j] = V4T{0, 0, 0, 0};
+                sC[j] = double4{0.0, 0.0, 0.0, 0.0};  // zero coefficients: padded control points contribute nothing
+            }
+        }
+        __syncthreads();
+        const int mc_pad = (mc + 3) & ~3;
+#pragma unroll 4
+        for (int j = 0; j < mc_pad; ++j) {
+            const V4T cv = sc[j];
+            const double4 cc = sC[j];
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                const T dx = px[c] - cv.x, dy = py[c] - cv.y, dz = pz[c] - cv.z;
+                const T e = fma(dz, dz, fma(dy, dy, dx * dx));
+                const double k = (double)exp2_neg(-e);
+                v0[c] = fma(k, cc.x, v0[c]);
+                v1[c] = fma(k, cc.y, v1[c]);
+                v2[c] = fma(k, cc.z, v2[c]);
+            }
+        }
+    }
+
+    double pr = 0.0;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const int64_t i = base + (int64_t)c * 256;
+        if (i < n) {
+            reinterpret_cast<V4T*>(V4)[i] = V4T{(T)v0[c], (T)v1[c], (T)v2[c], 0};
+            if (y4) {
+                const V4T yv = reinterpret_cast<const V4T*>(y4)[i];
+                // residual against the field as stored (rounded to T), like the reference's (Y - V) on stored V
+                const double d0 = (double)yv.x - (double)(T)v0[c], d1 = (double)yv.y - (double)(T)v1[c],
+                             d2 = (double)yv.z - (double)(T)v2[c];
+                const double rr = d0 * d0 + d1 * d1 + d2 * d2;
+                r[i] = (T)rr;
+                if (P) pr += (double)P[i] * (double)(T)rr;
+            }
+        }
+    }
+    if (y4 && P && stats) {
+        __shared__ double red[4];
+        const double t = block_sum<256>(pr, red);
+        if (threadIdx.x == 0) atomicAdd(stats, t);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// E-step (float64 arithmetic on r)
+// ----------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void estep_min_kernel(const T* __restrict__ r, int64_t n, double inv2s2,
+                                                        double* __restrict__ block_min_out,
+                                                        double* __restrict__ block_zero_out) {
+    double mn = INFINITY, zeros = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double t1 = exp(-(double)r[i] * inv2s2);
+        if (t1 == 0.0)
+            zeros += 1.0;
+        else
+            mn = fmin(mn, t1);
+    }
+    __shared__ double red[4];
+    const double bm = block_min<256>(mn, red);
+    const double bz = block_sum<256>(zeros, red);
+    if (threadIdx.x == 0) {
+        block_min_out[blockIdx.x] = bm;
+        block_zero_out[blockIdx.x] = bz;
+    }
+}
+
+__global__ __launch_bounds__(256) void estep_min_finish(const double* __restrict__ bmin, const double* __restrict__ bzero,
+                                                        int nb, double* __restrict__ mins) {
+    double mn = INFINITY, z = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        mn = fmin(mn, bmin[i]);
+        z += bzero[i];
+    }
+    __shared__ double red[4];
+    const double a = block_min<256>(mn, red);
+    const double b = block_sum<256>(z, red);
+    if (threadIdx.x == 0) {
+        mins[0] = a;
+        mins[1] = b;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void estep_p_kernel(const T* __restrict__ r, int64_t n, double inv2s2, double t2,
+                                                      double minP, double theta, double zero_fill,
+                                                      T* __restrict__ Pout, double* __restrict__ stats) {
+    double s_pr = 0.0, s_p = 0.0, s_pf = 0.0, s_cnt = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double ri = (double)r[i];
+        double t1 = exp(-ri * inv2s2);
+        if (t1 == 0.0) t1 = zero_fill;
+        const double p = t1 / (t1 + t2);
+        s_pr += p * ri;
+        s_p += p;
+        const T pf = (T)fmax(p, minP);  // the floored posterior as stored (and as the Gram / sigma2 update see it)
+        Pout[i] = pf;
+        s_pf += (double)pf;
+        s_cnt += ((double)pf > theta) ? 1.0 : 0.0;
+    }
+    __shared__ double red[4];
+    const double a = block_sum<256>(s_pr, red);
+    const double b = block_sum<256>(s_p, red);
+    const double c = block_sum<256>(s_pf, red);
+    const double d = block_sum<256>(s_cnt, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(stats + 0, a);
+        atomicAdd(stats + 1, b);
+        atomicAdd(stats + 2, c);
+        atomicAdd(stats + 3, d);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// trace(C^T K C)
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void quadform_kernel(const double* __restrict__ K, const double* __restrict__ C,
+                                                       int64_t m, int nrhs, double* __restrict__ out) {
+    // one block per row i:  sum_d C[i,d] * sum_j K[i,j] C[j,d]
+    const int64_t i = blockIdx.x;
+    double acc = 0.0;
+    for (int d = 0; d < nrhs; ++d) {
+        double t = 0.0;
+        for (int64_t j = threadIdx.x; j < m; j += 256) t += K[i * m + j] * C[j * nrhs + d];
+        acc += t * C[i * nrhs + d];
+    }
+    __shared__ double red[4];
+    const double s = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+}  // namespace mvf
+
+using namespace mvf;
+
+extern "C" int mvf_apply(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, const double* C,
+                         void* V4, const void* y4, const void* P, void* r, double* stats, mvf_dtype dtype,
+                         void* stream) {
+    MVF_REQUIRE(n >= 0 && m >= 0, "mvf_apply: bad shape");
+    MVF_REQUIRE(beta >= 0.0 && std::isfinite(beta), "mvf_apply: beta must be finite and >= 0");
+    if (n == 0) return 0;
+    MVF_REQUIRE(x4 && V4 && (m == 0 || (ctrl4 && C)), "mvf_apply: null pointer");
+    MVF_REQUIRE(!y4 || r, "mvf_apply: y4 given but r is null");
+    MVF_REQUIRE(!(P && y4) || stats, "mvf_apply: P given but stats is null");
+    hipStream_t st = (hipStream_t)stream;
+    const double s = std::sqrt(beta * LOG2E);
+    constexpr int CPT = 4;
+    dim3 grid((unsigned)cdiv(n, 256 * CPT));
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL((apply_kernel<float, CPT>), grid, dim3(256), 0, st, (const float*)x4, n,
+                           (const float*)ctrl4, m, (float)s, C, (float*)V4, (const float*)y4, (const float*)P,
+                           (float*)r, stats);
+    else if (dtype == MVF_F64)
+        hipLaunchKernelGGL((apply_kernel<double, 2>), dim3((unsigned)cdiv(n, 256 * 2)), dim3(256), 0, st,
+                           (const double*)x4, n, (const double*)ctrl4, m, s, C, (double*)V4, (const double*)y4,
+                           (const double*)P, (double*)r, stats);
+    else
+        return set_error("mvf_apply: bad dtype %d", (int)dtype);
+    MVF_LAUNCH_CHECK();
+    return 0;
+}
+
+namespace {
+constexpr int ESTEP_MAX_BLOCKS = 2048;  // == (MVF_ESTEP_MIN_DOUBLES - 2) / 2
+}  // namespace
+
+extern "C" int mvf_estep_min(const void* r, int64_t n, double sigma2, double* mins, mvf_dtype dtype, void* stream) {
+    MVF_REQUIRE(n >= 0 && sigma2 > 0.0, "mvf_estep_min: need n >= 0 and sigma2 > 0");
+    MVF_REQUIRE(mins && (n == 0 || r), "mvf_estep_min: null pointer");
+    static_assert(MVF_ESTEP_MIN_DOUBLES == 2 + 2 * ESTEP_MAX_BLOCKS, "scratch size mismatch with mvf.h");
+    hipStream_t st = (hipStream_t)stream;
+    int nb = (int)std::min<int64_t>(ESTEP_MAX_BLOCKS, std::max<int64_t>(1, cdiv(n, 256 * 4)));
+    double* bmin = mins + 2;  // block partials live behind the two results (caller-provided, see mvf.h)
+    double* bzero = mins + 2 + ESTEP_MAX_BLOCKS;
+    const double inv2s2 = 1.0 / (2.0 * sigma2);
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(estep_min_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)r, n, inv2s2, bmin, bzero);
+    else if (dtype == MVF_F64)
+        hipLaunchKernelGGL(estep_min_kernel<double>, dim3(nb), dim3(256), 0, st, (const double*)r, n, inv2s2, bmin,
+                           bzero);
+    else
+        return set_error("mvf_estep_min: bad dtype %d", (int)dtype);
+    MVF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(estep_min_finish, dim3(1), dim3(256), 0, st, bmin, bzero, nb, mins);
+    MVF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mvf_estep_p(const void* r, int64_t n, double sigma2, double gamma, double a, int dy, double minP,
+                           double theta, double t1_zero_fill, void* P_out, double* stats, mvf_dtype dtype,
+                           void* stream) {
+    MVF_REQUIRE(n >= 0 && sigma2 > 0.0 && gamma > 0.0 && gamma < 1.0 && a > 0.0 && dy >= 1,
+                "mvf_estep_p: bad parameters (sigma2=%g gamma=%g a=%g dy=%d)", sigma2, gamma, a, dy);
+    if (n == 0) return 0;
+    MVF_REQUIRE(r && P_out && stats, "mvf_estep_p: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const double inv2s2 = 1.0 / (2.0 * sigma2);
+    const double t2 = std::pow(2.0 * M_PI * sigma2, dy / 2.0) * (1.0 - gamma) / (gamma * a);
+    int nb = (int)std::min<int64_t>(ESTEP_MAX_BLOCKS, std::max<int64_t>(1, cdiv(n, 256 * 4)));
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(estep_p_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)r, n, inv2s2, t2, minP,
+                           theta, t1_zero_fill, (float*)P_out, stats);
+    else if (dtype == MVF_F64)
+        hipLaunchKernelGGL(estep_p_kernel<double>, dim3(nb), dim3(256), 0, st, (const double*)r, n, inv2s2, t2, minP,
+                           theta, t1_zero_fill, (double*)P_out, stats);
+    else
+        return set_error("mvf_estep_p: bad dtype %d", (int)dtype);
+    MVF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mvf_quadform(const double* K, const double* C, int64_t m, int nrhs, double* out, void* stream) {
+    MVF_REQUIRE(m >= 0 && nrhs >= 1, "mvf_quadform: bad shape");
+    MVF_REQUIRE(out, "mvf_quadform: null out");
+    hipStream_t st = (hipStream_t)stream;
+    MVF_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(double), st));
+    if (m == 0) return 0;
+    MVF_REQUIRE(K && C, "mvf_quadform: null pointer");
+    hipLaunchKernelGGL(quadform_kernel, dim3((unsigned)m), dim3(256), 0, st, K, C, m, nrhs, out);
+    MVF_LAUNCH_CHECK();
+    return 0;
+}

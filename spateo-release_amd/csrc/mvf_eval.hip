@@ -1,0 +1,176 @@
+// Differential-geometry evaluators of the learned field  v(x) = sum_m K(x, c_m) C[m, :]
+//
+// Reference: dynamo `Jacobian_rkhs_gaussian` + `compute_{acceleration,curvature,curl,torsion,divergence}`; in-tree
+// twins spateo/tdr/morphometrics/morphofield_dg/GPVectorField.py:143-190 (Jacobian) and :12-121 (evaluators), which
+// run one Python-level `_con_K` call per cell.  Here: ONE fused kernel; a lane owns CPT query points, control points
+// and coefficients are broadcast from LDS, v (3) and J (3x3) are accumulated in float64 in registers and every
+// requested quantity is derived in registers, so HBM traffic is 16 B in + the requested outputs per query.
+//   J[f][i] = -2 beta sum_m K_m C[m, f] (x - c_m)_i                      (GPVectorField.py:176,190 with pre_scale = 1)
+//   div = tr J;  curl = [J21 - J12, J02 - J20, J10 - J01];  a = J v
+//   curvature (formula 2) = (a (v.v) - v (v.a)) / |v|^4;  torsion = v (a . J a) / (|v|^2 |a|^2)
+#include "mvf_common.h"
+
+namespace mvf {
+
+constexpr int EVAL_CHUNK = 512;
+
+template <typename T, int CPT>
+__global__ __launch_bounds__(256) void eval_kernel(const T* __restrict__ x4, int64_t n, const T* __restrict__ ctrl4,
+                                                   int64_t m, T s, double jscale /* -2 beta / s */,
+                                                   const double* __restrict__ C, int flags, double* __restrict__ v_out,
+                                                   double* __restrict__ jac, double* __restrict__ div,
+                                                   double* __restrict__ curl, double* __restrict__ acc_out,
+                                                   double* __restrict__ curv, double* __restrict__ tors,
+                                                   double* __restrict__ jdet) {
+    using V4T = typename Vec4<T>::type;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[EVAL_CHUNK * (sizeof(V4T) + 4 * sizeof(double))];
+    V4T* sc = reinterpret_cast<V4T*>(smem_raw);
+    double4* sC = reinterpret_cast<double4*>(smem_raw + EVAL_CHUNK * sizeof(V4T));
+
+    const int64_t base = ((int64_t)blockIdx.x * 256) * CPT + threadIdx.x;
+    T px[CPT], py[CPT], pz[CPT];
+    double v[CPT][3], J[CPT][3][3];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const int64_t i = base + (int64_t)c * 256;
+        V4T xv = (i < n) ? reinterpret_cast<const V4T*>(x4)[i] : V4T{0, 0, 0, 0};
+        px[c] = xv.x * s, py[c] = xv.y * s, pz[c] = xv.z * s;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            v[c][f] = 0.0;
+#pragma unroll
+            for (int i2 = 0; i2 < 3; ++i2) J[c][f][i2] = 0.0;
+        }
+    }
+
+    for (int64_t m0 = 0; m0 < m; m0 += EVAL_CHUNK) {
+        const int mc = (int)min((int64_t)EVAL_CHUNK, m - m0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < EVAL_CHUNK; j += 256) {
+            if (j < mc) {
+                V4T cv = reinterpret_cast<const V4T*>(ctrl4)[m0 + j];
+                sc[j] = V4T{cv.x * s, cv.y * s, cv.z * s, 0};
+                const double* cp = C + (m0 + j) * 3;
+                sC[j] = double4{cp[0], cp[1], cp[2], 0.0};
+            } else {
+                sc[j] = V4T{0, 0, 0, 0};
+                sC[j] = double4{0.0, 0.0, 0.0, 0.0};
+            }
+        }
+        __syncthreads();
+        const int mc_pad = (mc + 1) & ~1;
+#pragma unroll 2
+        for (int j = 0; j < mc_pad; ++j) {
+            const V4T cv = sc[j];
+            const double4 cc = sC[j];
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                const T dx = px[c] - cv.x, dy = py[c] - cv.y, dz = pz[c] - cv.z;
+                const T e = fma(dz, dz, fma(dy, dy, dx * dx));
+                const double k = (double)exp2_neg(-e);
+                const double t0 = k * cc.x, t1 = k * cc.y, t2 = k * cc.z;
+                const double ddx = (double)dx, ddy = (double)dy, ddz = (double)dz;
+                v[c][0] += t0, v[c][1] += t1, v[c][2] += t2;
+                J[c][0][0] = fma(t0, ddx, J[c][0][0]), J[c][0][1] = fma(t0, ddy, J[c][0][1]), J[c][0][2] = fma(t0, ddz, J[c][0][2]);
+                J[c][1][0] = fma(t1, ddx, J[c][1][0]), J[c][1][1] = fma(t1, ddy, J[c][1][1]), J[c][1][2] = fma(t1, ddz, J[c][1][2]);
+                J[c][2][0] = fma(t2, ddx, J[c][2][0]), J[c][2][1] = fma(t2, ddy, J[c][2][1]), J[c][2][2] = fma(t2, ddz, J[c][2][2]);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const int64_t q = base + (int64_t)c * 256;
+        if (q >= n) continue;
+        double Jm[3][3];
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) Jm[f][i] = J[c][f][i] * jscale;
+        const double v0 = v[c][0], v1 = v[c][1], v2 = v[c][2];
+        if (flags & MVF_EVAL_V) {
+            v_out[q * 3 + 0] = v0, v_out[q * 3 + 1] = v1, v_out[q * 3 + 2] = v2;
+        }
+        if (flags & MVF_EVAL_JAC) {
+#pragma unroll
+            for (int f = 0; f < 3; ++f)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) jac[(int64_t)(f * 3 + i) * n + q] = Jm[f][i];
+        }
+        if (flags & MVF_EVAL_DIV) div[q] = Jm[0][0] + Jm[1][1] + Jm[2][2];
+        if (flags & MVF_EVAL_JDET)
+            jdet[q] = Jm[0][0] * (Jm[1][1] * Jm[2][2] - Jm[1][2] * Jm[2][1]) -
+                      Jm[0][1] * (Jm[1][0] * Jm[2][2] - Jm[1][2] * Jm[2][0]) +
+                      Jm[0][2] * (Jm[1][0] * Jm[2][1] - Jm[1][1] * Jm[2][0]);
+        if (flags & MVF_EVAL_CURL) {
+            curl[q * 3 + 0] = Jm[2][1] - Jm[1][2];
+            curl[q * 3 + 1] = Jm[0][2] - Jm[2][0];
+            curl[q * 3 + 2] = Jm[1][0] - Jm[0][1];
+        }
+        if (flags & (MVF_EVAL_ACC | MVF_EVAL_CURV | MVF_EVAL_TORS)) {
+            const double a0 = Jm[0][0] * v0 + Jm[0][1] * v1 + Jm[0][2] * v2;
+            const double a1 = Jm[1][0] * v0 + Jm[1][1] * v1 + Jm[1][2] * v2;
+            const double a2 = Jm[2][0] * v0 + Jm[2][1] * v1 + Jm[2][2] * v2;
+            if (flags & MVF_EVAL_ACC) {
+                acc_out[q * 3 + 0] = a0, acc_out[q * 3 + 1] = a1, acc_out[q * 3 + 2] = a2;
+            }
+            const double vv = v0 * v0 + v1 * v1 + v2 * v2;
+            if (flags & MVF_EVAL_CURV) {
+                const double va = v0 * a0 + v1 * a1 + v2 * a2;
+                const double nv = sqrt(vv);
+                const double den = (nv * nv) * (nv * nv);  // ||v||^4 as norm(v)**4
+                curv[q * 3 + 0] = (a0 * vv - v0 * va) / den;
+                curv[q * 3 + 1] = (a1 * vv - v1 * va) / den;
+                curv[q * 3 + 2] = (a2 * vv - v2 * va) / den;
+            }
+            if (flags & MVF_EVAL_TORS) {
+                const double Ja0 = Jm[0][0] * a0 + Jm[0][1] * a1 + Jm[0][2] * a2;
+                const double Ja1 = Jm[1][0] * a0 + Jm[1][1] * a1 + Jm[1][2] * a2;
+                const double Ja2 = Jm[2][0] * a0 + Jm[2][1] * a1 + Jm[2][2] * a2;
+                const double aJa = a0 * Ja0 + a1 * Ja1 + a2 * Ja2;
+                const double aa = a0 * a0 + a1 * a1 + a2 * a2;
+                const double den = vv * aa;  // ||v a^T||_F^2
+                tors[q * 3 + 0] = v0 * aJa / den;
+                tors[q * 3 + 1] = v1 * aJa / den;
+                tors[q * 3 + 2] = v2 * aJa / den;
+            }
+        }
+    }
+}
+
+}  // namespace mvf
+
+using namespace mvf;
+
+extern "C" int mvf_eval(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, const double* C,
+                        int flags, double* v, double* jac, double* div, double* curl, double* acc, double* curv,
+                        double* tors, double* jdet, mvf_dtype dtype, void* stream) {
+    MVF_REQUIRE(n >= 0 && m >= 0, "mvf_eval: bad shape");
+    MVF_REQUIRE(beta > 0.0 && std::isfinite(beta), "mvf_eval: beta must be finite and > 0");
+    if (n == 0) return 0;
+    MVF_REQUIRE(x4 && (m == 0 || (ctrl4 && C)), "mvf_eval: null input");
+    MVF_REQUIRE(!(flags & MVF_EVAL_V) || v, "mvf_eval: v requested but null");
+    MVF_REQUIRE(!(flags & MVF_EVAL_JAC) || jac, "mvf_eval: jac requested but null");
+    MVF_REQUIRE(!(flags & MVF_EVAL_DIV) || div, "mvf_eval: div requested but null");
+    MVF_REQUIRE(!(flags & MVF_EVAL_CURL) || curl, "mvf_eval: curl requested but null");
+    MVF_REQUIRE(!(flags & MVF_EVAL_ACC) || acc, "mvf_eval: acc requested but null");
+    MVF_REQUIRE(!(flags & MVF_EVAL_CURV) || curv, "mvf_eval: curv requested but null");
+    MVF_REQUIRE(!(flags & MVF_EVAL_TORS) || tors, "mvf_eval: tors requested but null");
+    MVF_REQUIRE(!(flags & MVF_EVAL_JDET) || jdet, "mvf_eval: jdet requested but null");
+    hipStream_t st = (hipStream_t)stream;
+    const double s = std::sqrt(beta * LOG2E);
+    // (x - c) = (scaled difference) / s, with s as the kernel rounds it
+    const double jscale = -2.0 * beta / ((dtype == MVF_F32) ? (double)(float)s : s);
+    constexpr int CPT = 2;
+    dim3 grid((unsigned)cdiv(n, 256 * CPT));
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL((eval_kernel<float, CPT>), grid, dim3(256), 0, st, (const float*)x4, n, (const float*)ctrl4,
+                           m, (float)s, jscale, C, flags, v, jac, div, curl, acc, curv, tors, jdet);
+    else if (dtype == MVF_F64)
+        hipLaunchKernelGGL((eval_kernel<double, CPT>), grid, dim3(256), 0, st, (const double*)x4, n,
+                           (const double*)ctrl4, m, s, jscale, C, flags, v, jac, div, curl, acc, curv, tors, jdet);
+    else
+        return set_error("mvf_eval: bad dtype %d", (int)dtype);
+    MVF_LAUNCH_CHECK();
+    return 0;
+}

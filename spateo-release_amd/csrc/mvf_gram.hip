@@ -1,0 +1,462 @@
+// M-step assembly:  G = U^T diag(P) U  (m x m)  and  R = U^T diag(P) Y  (m x 3),  U = con_K(x, ctrl, beta) (n x m)
+//
+// Reference: `UP = U.T * repmat(P.T, M, 1); lhs = UP.dot(U) + ...; rhs = UP.dot(Y)` of dynamo SparseVFC
+// (call sites spateo/tdr/morphometrics/morphofield/sparsevfc.py:189-198).
+//
+// Design (MI355X first, not a GEMM on a materialised U):
+//   * G is an n-long reduction SYRK; at m >= 500 it is MFMA-bound (2 n m^2 flops vs 16 n bytes of input).  U is never
+//     read from HBM: each lane REGENERATES its own MFMA operand element.  For v_mfma_f32_32x32x2_f32 lane l holds
+//     A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; with A[i][k] = P_n K(x_n, c_i), B[k][j] = K(x_n, c_j) and n the
+//     cell k of the step, a lane needs only ITS control point (registers, loaded once) and the step's two cells
+//     (one broadcast ds_read_b128 from a 4 KiB LDS stage).  6 VALU + 1 v_exp per operand, 4 operands per 4 MFMAs.
+//   * Only tile pairs ti <= tj of the symmetric G are computed (algorithmic flops n m (m+1)).
+//   * Precision: float32 MFMA chains are kept short (GCHUNK = 256 cells), then folded into float64 accumulators in
+//     registers; per-slice float64 partial tiles go to a workspace and are summed in a fixed order -> deterministic,
+//     and the rounding noise of G is ~1e-9 relative instead of ~1e-5 for one long float32 chain.
+//   * The float64 mode uses v_mfma_f64_16x16x4_f64 with float64 operand generation.
+//   * Work decomposition: job = (tile pair, cell slice); blockIdx = slice * npairs + pair so that concurrently
+//     resident workgroups stream the same cell slice (L2 / MALL hits on the only global input).
+#include "mvf_common.h"
+
+namespace mvf {
+
+constexpr int GT = 128;      // Gram tile edge per workgroup (4 waves, 64 x 64 per wave)
+constexpr int GCHUNK = 256;  // cells per LDS stage == length of a float32 MFMA accumulation chain
+constexpr float PAD_COORD = 1.0e18f;  // padded control points sit "at infinity": K == exp2(-3e36) == 0 exactly
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+struct GramPlan {
+    int nt = 0, npairs = 0;
+    int64_t slice_len = 0, nslices = 0;    // Gram jobs
+    int64_t rslice_len = 0, rslices = 0;   // rhs jobs
+    int rcolblocks = 0;
+    size_t gram_bytes = 0, rhs_bytes = 0;
+};
+
+constexpr int RHS_CPT = 2;                  // control points per lane in the rhs kernel
+constexpr int RHS_COLS = 256 * RHS_CPT;     // control points per rhs workgroup
+
+static GramPlan make_plan(int64_t n, int64_t m) {
+    GramPlan p;
+    p.nt = (int)cdiv(m, GT);
+    p.npairs = p.nt * (p.nt + 1) / 2;
+    const int64_t target_jobs = 2048;
+    int64_t want_slices = std::max<int64_t>(1, cdiv(target_jobs, std::max(1, p.npairs)));
+    int64_t sl = cdiv(cdiv(n, want_slices), GCHUNK) * GCHUNK;
+    sl = std::min<int64_t>(std::max<int64_t>(sl, GCHUNK), 262144);
+    p.slice_len = sl;
+    p.nslices = std::max<int64_t>(1, cdiv(n, sl));
+    p.gram_bytes = (size_t)p.nslices * p.npairs * GT * GT * sizeof(double);
+    p.rcolblocks = (int)cdiv(m, RHS_COLS);
+    int64_t want_r = std::max<int64_t>(1, cdiv(1024, std::max(1, p.rcolblocks)));
+    int64_t rsl = cdiv(cdiv(n, want_r), GCHUNK) * GCHUNK;
+    rsl = std::max<int64_t>(rsl, GCHUNK);
+    p.rslice_len = rsl;
+    p.rslices = std::max<int64_t>(1, cdiv(n, rsl));
+    p.rhs_bytes = (size_t)p.rslices * m * 4 * sizeof(double);
+    return p;
+}
+
+__device__ __forceinline__ void decode_pair(int pair, int nt, int& ti, int& tj) {
+    int p = pair, t = 0;
+    while (p >= nt - t) {
+        p -= nt - t;
+        ++t;
+    }
+    ti = t;
+    tj = t + p;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// float32 MFMA Gram kernel
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gram_f32_kernel(const float4* __restrict__ x4, const float* __restrict__ P,
+                                                          int64_t n, const float4* __restrict__ ctrl4, int64_t m,
+                                                          float s, int nt, int npairs, int64_t slice_len,
+                                                          double* __restrict__ partial) {
+    __shared__ float4 cells[2][GCHUNK];  // (s*x, s*y, s*z, P)
+
+    const int pair = blockIdx.x % npairs;
+    const int64_t slice = blockIdx.x / npairs;
+    int ti, tj;
+    decode_pair(pair, nt, ti, tj);
+    const int64_t n0 = slice * slice_len;
+    const int64_t n1 = min(n, n0 + slice_len);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+
+    // this lane's control points (scaled), 2 row blocks (A side) + 2 column blocks (B side)
+    float ax[2], ay[2], az[2], bx[2], by[2], bz[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int64_t ia = (int64_t)ti * GT + wi * 64 + a * 32 + (lane & 31);
+        const int64_t ib = (int64_t)tj * GT + wj * 64 + a * 32 + (lane & 31);
+        if (ia < m) {
+            const float4 c = ctrl4[ia];
+            ax[a] = c.x * s, ay[a] = c.y * s, az[a] = c.z * s;
+        } else {
+            ax[a] = ay[a] = az[a] = PAD_COORD;
+        }
+        if (ib < m) {
+            const float4 c = ctrl4[ib];
+            bx[a] = c.x * s, by[a] = c.y * s, bz[a] = c.z * s;
+        } else {
+            bx[a] = by[a] = bz[a] = PAD_COORD;
+        }
+    }
+
+    f32x16 acc[2][2];
+    double acc2[2][2][16];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[a][b][r] = 0.f;
+                acc2[a][b][r] = 0.0;
+            }
+        }
+
+    auto load_cell = [&](int64_t i) -> float4 {
+        if (i < n1) {
+            const float4 xv = x4[i];
+            return float4{xv.x * s, xv.y * s, xv.z * s, P[i]};
+        }
+        return float4{0.f, 0.f, 0.f, 0.f};  // P = 0: the A operand vanishes
+    };
+
+    const int nchunks = (int)((n1 - n0 + GCHUNK - 1) / GCHUNK);
+    float4 stage = load_cell(n0 + tid);
+    cells[0][tid] = stage;
+    const int half = lane >> 5;
+
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();
+        if (c + 1 < nchunks) stage = load_cell(n0 + (int64_t)(c + 1) * GCHUNK + tid);
+        const float4* cb = cells[c & 1];
+#pragma unroll 4
+        for (int st = 0; st < GCHUNK / 2; ++st) {
+            const float4 cell = cb[2 * st + half];
+            float fa[2], fb[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                float dx = cell.x - ax[a], dy = cell.y - ay[a], dz = cell.z - az[a];
+                float e = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                fa[a] = __builtin_amdgcn_exp2f(-e) * cell.w;
+                dx = cell.x - bx[a], dy = cell.y - by[a], dz = cell.z - bz[a];
+                e = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                fb[a] = __builtin_amdgcn_exp2f(-e);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+        // fold the short float32 chain into float64
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc2[a][b][r] += (double)acc[a][b][r];
+                    acc[a][b][r] = 0.f;
+                }
+        if (c + 1 < nchunks) cells[(c + 1) & 1][tid] = stage;
+    }
+
+    // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    double* out = partial + ((size_t)slice * npairs + pair) * (size_t)(GT * GT);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wi * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int col = wj * 64 + b * 32 + (lane & 31);
+                out[row * GT + col] = acc2[a][b][r];
+            }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// float64 MFMA Gram kernel (v_mfma_f64_16x16x4_f64: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15];
+// C/D: col = l & 15, row = (l >> 4) + 4 * reg)
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void gram_f64_kernel(const double4* __restrict__ x4, const double* __restrict__ P,
+                                                          int64_t n, const double4* __restrict__ ctrl4, int64_t m,
+                                                          double s, int nt, int npairs, int64_t slice_len,
+                                                          double* __restrict__ partial) {
+    __shared__ double4 cells[2][GCHUNK];
+
+    const int pair = blockIdx.x % npairs;
+    const int64_t slice = blockIdx.x / npairs;
+    int ti, tj;
+    decode_pair(pair, nt, ti, tj);
+    const int64_t n0 = slice * slice_len;
+    const int64_t n1 = min(n, n0 + slice_len);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+
+    double ax[4], ay[4], az[4], bx[4], by[4], bz[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int64_t ia = (int64_t)ti * GT + wi * 64 + a * 16 + (lane & 15);
+        const int64_t ib = (int64_t)tj * GT + wj * 64 + a * 16 + (lane & 15);
+        if (ia < m) {
+            const double4 c = ctrl4[ia];
+            ax[a] = c.x * s, ay[a] = c.y * s, az[a] = c.z * s;
+        } else {
+            ax[a] = ay[a] = az[a] = 1.0e150;
+        }
+        if (ib < m) {
+            const double4 c = ctrl4[ib];
+            bx[a] = c.x * s, by[a] = c.y * s, bz[a] = c.z * s;
+        } else {
+            bx[a] = by[a] = bz[a] = 1.0e150;
+        }
+    }
+
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    auto load_cell = [&](int64_t i) -> double4 {
+        if (i < n1) {
+            const double4 xv = x4[i];
+            return double4{xv.x * s, xv.y * s, xv.z * s, P[i]};
+        }
+        return double4{0.0, 0.0, 0.0, 0.0};
+    };
+
+    const int nchunks = (int)((n1 - n0 + GCHUNK - 1) / GCHUNK);
+    double4 stage = load_cell(n0 + tid);
+    cells[0][tid] = stage;
+    const int quarter = lane >> 4;
+
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();
+        if (c + 1 < nchunks) stage = load_cell(n0 + (int64_t)(c + 1) * GCHUNK + tid);
+        const double4* cb = cells[c & 1];
+#pragma unroll 2
+        for (int st = 0; st < GCHUNK / 4; ++st) {
+            const double4 cell = cb[4 * st + quarter];
+            double fa[4], fb[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                double dx = cell.x - ax[a], dy = cell.y - ay[a], dz = cell.z - az[a];
+                double e = fma(dz, dz, fma(dy, dy, dx * dx));
+                fa[a] = exp2(-e) * cell.w;
+                dx = cell.x - bx[a], dy = cell.y - by[a], dz = cell.z - bz[a];
+                e = fma(dz, dz, fma(dy, dy, dx * dx));
+                fb[a] = exp2(-e);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) cells[(c + 1) & 1][tid] = stage;
+    }
+
+    double* out = partial + ((size_t)slice * npairs + pair) * (size_t)(GT * GT);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wi * 64 + a * 16 + quarter + 4 * r;
+                const int col = wj * 64 + b * 16 + (lane & 15);
+                out[row * GT + col] = acc[a][b][r];
+            }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// rhs:  R[j, :] = sum_n K(x_n, c_j) P_n y_n   (VALU kernel; a lane owns RHS_CPT control points, cells broadcast
+// from LDS; float32 partial sums per 256-cell stage folded into float64)
+// ----------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rhs_kernel(const T* __restrict__ x4, const T* __restrict__ P,
+                                                  const T* __restrict__ y4, int64_t n, const T* __restrict__ ctrl4,
+                                                  int64_t m, T s, int64_t slice_len, double* __restrict__ rpart) {
+    using V4T = typename Vec4<T>::type;
+    __shared__ V4T sx[GCHUNK];
+    __shared__ V4T sw[GCHUNK];
+    const int64_t slice = blockIdx.y;
+    const int64_t n0 = slice * slice_len, n1 = min(n, n0 + slice_len);
+    T cx[RHS_CPT], cy[RHS_CPT], cz[RHS_CPT];
+    double r0[RHS_CPT], r1[RHS_CPT], r2[RHS_CPT];
+#pragma unroll
+    for (int c = 0; c < RHS_CPT; ++c) {
+        const int64_t j = (int64_t)blockIdx.x * RHS_COLS + c * 256 + threadIdx.x;
+        if (j < m) {
+            const V4T cv = reinterpret_cast<const V4T*>(ctrl4)[j];
+            cx[c] = cv.x * s, cy[c] = cv.y * s, cz[c] = cv.z * s;
+        } else {
+            cx[c] = cy[c] = cz[c] = T(0);
+        }
+        r0[c] = r1[c] = r2[c] = 0.0;
+    }
+    for (int64_t c0 = n0; c0 < n1; c0 += GCHUNK) {
+        __syncthreads();
+        const int64_t i = c0 + threadIdx.x;
+        if (i < n1) {
+            const V4T xv = reinterpret_cast<const V4T*>(x4)[i];
+            const V4T yv = reinterpret_cast<const V4T*>(y4)[i];
+            const T p = P[i];
+            sx[threadIdx.x] = V4T{xv.x * s, xv.y * s, xv.z * s, 0};
+            sw[threadIdx.x] = V4T{yv.x * p, yv.y * p, yv.z * p, 0};
+        } else {
+            sx[threadIdx.x] = V4T{0, 0, 0, 0};
+            sw[threadIdx.x] = V4T{0, 0, 0, 0};  // zero weight
+        }
+        __syncthreads();
+        T t0[RHS_CPT], t1[RHS_CPT], t2[RHS_CPT];
+#pragma unroll
+        for (int c = 0; c < RHS_CPT; ++c) t0[c] = t1[c] = t2[c] = T(0);
+#pragma unroll 4
+        for (int q = 0; q < GCHUNK; ++q) {
+            const V4T xv = sx[q];
+            const V4T wv = sw[q];
+#pragma unroll
+            for (int c = 0; c < RHS_CPT; ++c) {
+                const T dx = xv.x - cx[c], dy = xv.y - cy[c], dz = xv.z - cz[c];
+                const T e = fma(dz, dz, fma(dy, dy, dx * dx));
+                const T k = exp2_neg(-e);
+                t0[c] = fma(k, wv.x, t0[c]);
+                t1[c] = fma(k, wv.y, t1[c]);
+                t2[c] = fma(k, wv.z, t2[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < RHS_CPT; ++c) {
+            r0[c] += (double)t0[c];
+            r1[c] += (double)t1[c];
+            r2[c] += (double)t2[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < RHS_CPT; ++c) {
+        const int64_t j = (int64_t)blockIdx.x * RHS_COLS + c * 256 + threadIdx.x;
+        if (j < m) {
+            double4* o = reinterpret_cast<double4*>(rpart + ((size_t)slice * m + j) * 4);
+            *o = double4{r0[c], r1[c], r2[c], 0.0};
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// deterministic reductions of the per-slice partials
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ partial, int64_t nslices, int nt,
+                                                          int npairs, int64_t m, double* __restrict__ G) {
+    const int pair = blockIdx.y;
+    int ti, tj;
+    decode_pair(pair, nt, ti, tj);
+    const int e = blockIdx.x * 256 + threadIdx.x;  // element of the 128 x 128 tile
+    const int row = e / GT, col = e % GT;
+    const int64_t i = (int64_t)ti * GT + row, j = (int64_t)tj * GT + col;
+    if (i >= m || j >= m) return;
+    double acc = 0.0;
+    const double* p = partial + (size_t)pair * (GT * GT) + e;
+    const size_t stride = (size_t)npairs * (GT * GT);
+    for (int64_t s = 0; s < nslices; ++s) acc += p[s * stride];
+    G[i * m + j] = acc;
+    if (ti != tj) G[j * m + i] = acc;
+}
+
+__global__ __launch_bounds__(256) void rhs_reduce_kernel(const double* __restrict__ rpart, int64_t rslices, int64_t m,
+                                                         double* __restrict__ R /* m x 3 */) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int64_t s = 0; s < rslices; ++s) {
+        const double4 v = *reinterpret_cast<const double4*>(rpart + ((size_t)s * m + j) * 4);
+        a0 += v.x, a1 += v.y, a2 += v.z;
+    }
+    R[j * 3 + 0] = a0;
+    R[j * 3 + 1] = a1;
+    R[j * 3 + 2] = a2;
+}
+
+}  // namespace mvf
+
+using namespace mvf;
+
+extern "C" size_t mvf_gram_workspace_bytes(int64_t n, int64_t m, mvf_dtype dtype) {
+    (void)dtype;
+    if (n <= 0 || m <= 0) return 0;
+    const GramPlan p = make_plan(n, m);
+    return align_up(p.gram_bytes, 256) + align_up(p.rhs_bytes, 256);
+}
+
+extern "C" int mvf_gram_stages(int stages, const void* x4, const void* P, const void* y4, int64_t n,
+                               const void* ctrl4, int64_t m, double beta, double* G, double* R, void* workspace,
+                               size_t workspace_bytes, mvf_dtype dtype, void* stream) {
+    MVF_REQUIRE(n >= 0 && m >= 0, "mvf_gram: bad shape");
+    MVF_REQUIRE(beta >= 0.0 && std::isfinite(beta), "mvf_gram: beta must be finite and >= 0");
+    MVF_REQUIRE(dtype == MVF_F32 || dtype == MVF_F64, "mvf_gram: bad dtype %d", (int)dtype);
+    MVF_REQUIRE(stages > 0 && stages <= 7, "mvf_gram: bad stage mask %d", stages);
+    if (m == 0) return 0;
+    MVF_REQUIRE(G && R, "mvf_gram: null output");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        if (stages & MVF_GRAM_STAGE_REDUCE) {
+            MVF_CHECK_HIP(hipMemsetAsync(G, 0, sizeof(double) * m * m, st));
+            MVF_CHECK_HIP(hipMemsetAsync(R, 0, sizeof(double) * m * 3, st));
+        }
+        return 0;
+    }
+    MVF_REQUIRE(x4 && P && y4 && ctrl4, "mvf_gram: null input");
+    const GramPlan p = make_plan(n, m);
+    const size_t need = align_up(p.gram_bytes, 256) + align_up(p.rhs_bytes, 256);
+    MVF_REQUIRE(workspace && workspace_bytes >= need, "mvf_gram: workspace too small (%zu < %zu)", workspace_bytes, need);
+    MVF_REQUIRE((int64_t)p.nslices * p.npairs < (1LL << 31), "mvf_gram: too many jobs");
+    MVF_REQUIRE(p.rslices <= 65535, "mvf_gram: rhs slice count too large");
+    double* gpart = (double*)workspace;
+    double* rpart = (double*)((char*)workspace + align_up(p.gram_bytes, 256));
+    const double s = std::sqrt(beta * LOG2E);
+    const unsigned njobs = (unsigned)(p.nslices * p.npairs);
+    dim3 rgrid((unsigned)p.rcolblocks, (unsigned)p.rslices);
+    if (stages & MVF_GRAM_STAGE_TILES) {
+        if (dtype == MVF_F32)
+            hipLaunchKernelGGL(gram_f32_kernel, dim3(njobs), dim3(256), 0, st, (const float4*)x4, (const float*)P, n,
+                               (const float4*)ctrl4, m, (float)s, p.nt, p.npairs, p.slice_len, gpart);
+        else
+            hipLaunchKernelGGL(gram_f64_kernel, dim3(njobs), dim3(256), 0, st, (const double4*)x4, (const double*)P,
+                               n, (const double4*)ctrl4, m, s, p.nt, p.npairs, p.slice_len, gpart);
+        MVF_LAUNCH_CHECK();
+    }
+    if (stages & MVF_GRAM_STAGE_RHS) {
+        if (dtype == MVF_F32)
+            hipLaunchKernelGGL(rhs_kernel<float>, rgrid, dim3(256), 0, st, (const float*)x4, (const float*)P,
+                               (const float*)y4, n, (const float*)ctrl4, m, (float)s, p.rslice_len, rpart);
+        else
+            hipLaunchKernelGGL(rhs_kernel<double>, rgrid, dim3(256), 0, st, (const double*)x4, (const double*)P,
+                               (const double*)y4, n, (const double*)ctrl4, m, s, p.rslice_len, rpart);
+        MVF_LAUNCH_CHECK();
+    }
+    if (stages & MVF_GRAM_STAGE_REDUCE) {
+        hipLaunchKernelGGL(gram_reduce_kernel, dim3(GT * GT / 256, (unsigned)p.npairs), dim3(256), 0, st, gpart,
+                           p.nslices, p.nt, p.npairs, m, G);
+        MVF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(rhs_reduce_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, rpart, p.rslices, m, R);
+        MVF_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int mvf_gram(const void* x4, const void* P, const void* y4, int64_t n, const void* ctrl4, int64_t m,
+                        double beta, double* G, double* R, void* workspace, size_t workspace_bytes, mvf_dtype dtype,
+                        void* stream) {
+    return mvf_gram_stages(MVF_GRAM_STAGE_TILES | MVF_GRAM_STAGE_RHS | MVF_GRAM_STAGE_REDUCE, x4, P, y4, n, ctrl4, m,
+                           beta, G, R, workspace, workspace_bytes, dtype, stream);
+}

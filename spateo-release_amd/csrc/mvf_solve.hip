@@ -1,0 +1,277 @@
+// Coefficient solve  (G + ls2 * K + jitter * mean(diag) * I) C = R   in float64.
+//
+// Reference: dynamo `lstsq_solver(lhs, rhs, "scipy")` as Spateo calls it (spateo/tdr/morphometrics/morphofield/
+// sparsevfc.py:110,194,250).  lhs is symmetric PSD (U^T P U + lambda sigma^2 K) and
+// numerically rank deficient; the reference's gelsd truncates at eps*s_max.  Here: blocked right-looking Cholesky
+// (NB = 64) of the jitter-regularised matrix.  DESIGN.md ("Solve parity") explains why the FIELD, not C, is the
+// parity quantity and shows the measured noise floor of the reference itself.
+//
+// Structure per block column k (all kernels on one stream, no host sync):
+//   potrf_diag : one workgroup factors the 64x64 diagonal block in LDS
+//   trsm_panel : one lane per row below solves  x L_kk^T = a  (right-looking inside the lane -> independent FMAs)
+//   syrk_update: one workgroup per 64x64 trailing tile, v_mfma_f64_16x16x4_f64 on LDS-staged panels
+// The right-hand sides ride along as extra ROWS of the trapezoidal matrix, so the forward substitution L Y = R falls
+// out of trsm/syrk for free; the back substitution L^T C = Y is one small kernel per block column.
+#include "mvf_common.h"
+
+namespace mvf {
+
+constexpr int NB = 64;
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// mean of the diagonal of G + ls2*K  ->  scal[0];  scal[1] = jitter * mean
+__global__ __launch_bounds__(256) void diag_mean_kernel(const double* __restrict__ G, const double* __restrict__ K,
+                                                        double ls2, double jitter, int64_t m,
+                                                        double* __restrict__ scal) {
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < m; i += 256) s += G[i * m + i] + ls2 * K[i * m + i];
+    __shared__ double red[4];
+    const double t = block_sum<256>(s, red);
+    if (threadIdx.x == 0) {
+        const double mean = t / (double)m;
+        scal[0] = mean;
+        scal[1] = jitter * mean;
+    }
+}
+
+// W (mr x mp, row-major):  rows < mp hold the regularised matrix (identity on the padding), rows mp.. hold R^T
+__global__ __launch_bounds__(256) void chol_prepare_kernel(const double* __restrict__ G, const double* __restrict__ K,
+                                                           double ls2, const double* __restrict__ scal,
+                                                           const double* __restrict__ R, int64_t m, int nrhs,
+                                                           int64_t mp, int64_t mr, double* __restrict__ W) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j >= mp) return;
+    double v = 0.0;
+    if (i < mp) {
+        if (i < m && j < m) {
+            v = G[i * m + j] + ls2 * K[i * m + j];
+            if (i == j) v += scal[1];
+        } else if (i == j) {
+            v = 1.0;
+        }
+    } else {
+        const int d = (int)(i - mp);
+        if (d < nrhs && j < m) v = R[j * nrhs + d];
+    }
+    W[i * mp + j] = v;
+}
+
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ W, int64_t mp, int k, int* __restrict__ info) {
+    __shared__ double a[NB][NB + 1];
+    __shared__ double dsh;
+    double* blk = W + ((int64_t)k * NB) * mp + (int64_t)k * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) a[e / NB][e % NB] = blk[(int64_t)(e / NB) * mp + (e % NB)];
+    __syncthreads();
+    for (int j = 0; j < NB; ++j) {
+        if (threadIdx.x == 0) {
+            double d = a[j][j];
+            if (!(d > 0.0)) {  // also catches NaN
+                atomicCAS(info, 0, 1 + k * NB + j);
+                d = 1.0;
+            }
+            dsh = sqrt(d);
+            a[j][j] = dsh;
+        }
+        __syncthreads();
+        const double inv = 1.0 / dsh;
+        if (threadIdx.x > j && threadIdx.x < NB) a[threadIdx.x][j] *= inv;
+        __syncthreads();
+        // trailing update of the lower triangle: a[i][c] -= a[i][j] a[c][j],  j < c <= i < NB
+        const int rem = NB - 1 - j;
+        for (int e = threadIdx.x; e < rem * rem; e += 256) {
+            const int i = j + 1 + e / rem, c = j + 1 + e % rem;
+            if (c <= i) a[i][c] -= a[i][j] * a[c][j];
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int i = e / NB, c = e % NB;
+        blk[(int64_t)i * mp + c] = (c <= i) ? a[i][c] : 0.0;
+    }
+}
+
+// rows below the diagonal block: x L^T = a  ->  for c: x_c = a_c / L_cc ; a_j -= x_c L_jc (j > c)
+__global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ W, int64_t mp, int64_t mr, int k) {
+    __shared__ double L[NB][NB];
+    const double* blk = W + ((int64_t)k * NB) * mp + (int64_t)k * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += 64) L[e / NB][e % NB] = blk[(int64_t)(e / NB) * mp + (e % NB)];
+    __syncthreads();
+    const int64_t row = (int64_t)(k + 1) * NB + (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (row >= mr) return;
+    double* rp = W + row * mp + (int64_t)k * NB;
+    double x[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) x[c] = rp[c];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        const double xc = x[c] / L[c][c];
+        x[c] = xc;
+#pragma unroll
+        for (int j = c + 1; j < NB; ++j) x[j] = fma(-xc, L[j][c], x[j]);
+    }
+#pragma unroll
+    for (int c = 0; c < NB; ++c) rp[c] = x[c];
+}
+
+// W[i, j] -= W[i, k] W[j, k]^T  for block rows i > k (incl. the rhs block row) and block cols k < j <= min(i, nb-1)
+constexpr int LDP = NB + 2;  // padded LDS row stride (doubles): conflict-free ds_read_b64 of MFMA operands
+__global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ W, int64_t mp, int k, int nb, int nbr) {
+    // decode (i, j) from the linear tile index: i in (k, nbr), j in (k, min(i, nb-1)]
+    int t = blockIdx.x, i = k + 1;
+    while (true) {
+        const int cnt = min(i, nb - 1) - k;
+        if (t < cnt) break;
+        t -= cnt;
+        ++i;
+    }
+    const int j = k + 1 + t;
+    __shared__ double sa[NB * LDP];
+    __shared__ double sb[NB * LDP];
+    const double* pa = W + ((int64_t)i * NB) * mp + (int64_t)k * NB;
+    const double* pb = W + ((int64_t)j * NB) * mp + (int64_t)k * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int r = e / NB, c = e % NB;
+        sa[r * LDP + c] = pa[(int64_t)r * mp + c];
+        sb[r * LDP + c] = pb[(int64_t)r * mp + c];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll 4
+    for (int kk = 0; kk < NB; kk += 4) {
+        double fa[2], fb[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            fa[a] = sa[(wr + a * 16 + li) * LDP + kk + lk];  // A[i][k]
+            fb[a] = sb[(wc + a * 16 + li) * LDP + kk + lk];  // B[k][j] = Wj[j][k]
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+    double* pc = W + ((int64_t)i * NB) * mp + (int64_t)j * NB;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr + a * 16 + lk + 4 * r;
+                const int col = wc + b * 16 + li;
+                pc[(int64_t)row * mp + col] -= acc[a][b][r];
+            }
+}
+
+// back substitution for block column k:  C_k = L_kk^{-T} (Y_k - sum_{rows r >= (k+1) NB} L[r, kblock]^T C[r, :])
+template <int MAXR>
+__global__ __launch_bounds__(256) void bsub_kernel(const double* __restrict__ W, int64_t mp, int k, int nrhs,
+                                                   double* __restrict__ Cp /* mp x nrhs */) {
+    __shared__ double part[4][NB][MAXR];
+    __shared__ double L[NB][NB + 1];
+    __shared__ double t[NB][MAXR];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    double acc[MAXR];
+#pragma unroll
+    for (int d = 0; d < MAXR; ++d) acc[d] = 0.0;
+    for (int64_t r = (int64_t)(k + 1) * NB + q; r < mp; r += 4) {
+        const double l = W[r * mp + (int64_t)k * NB + c];
+#pragma unroll
+        for (int d = 0; d < MAXR; ++d)
+            if (d < nrhs) acc[d] = fma(l, Cp[r * nrhs + d], acc[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < MAXR; ++d) part[q][c][d] = acc[d];
+    const double* blk = W + ((int64_t)k * NB) * mp + (int64_t)k * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) L[e / NB][e % NB] = blk[(int64_t)(e / NB) * mp + (e % NB)];
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        for (int d = 0; d < nrhs; ++d) {
+            const double y = W[(mp + d) * mp + (int64_t)k * NB + threadIdx.x];  // forward-substituted rhs (row mp+d)
+            t[threadIdx.x][d] = y - (part[0][threadIdx.x][d] + part[1][threadIdx.x][d] + part[2][threadIdx.x][d] +
+                                     part[3][threadIdx.x][d]);
+        }
+    }
+    __syncthreads();
+    // solve L^T z = t  (upper triangular, backwards); lane d handles rhs column d
+    if (threadIdx.x < nrhs) {
+        const int d = threadIdx.x;
+        for (int cc = NB - 1; cc >= 0; --cc) {
+            double z = t[cc][d];
+            for (int j = cc + 1; j < NB; ++j) z -= L[j][cc] * t[j][d];
+            z /= L[cc][cc];
+            t[cc][d] = z;
+        }
+        for (int cc = 0; cc < NB; ++cc) Cp[((int64_t)k * NB + cc) * nrhs + d] = t[cc][d];
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const double* __restrict__ src, int64_t count,
+                                                        double* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) dst[i] = src[i];
+}
+
+}  // namespace mvf
+
+using namespace mvf;
+
+static inline int64_t solve_mp(int64_t m) { return cdiv(m, NB) * NB; }
+
+extern "C" size_t mvf_solve_workspace_bytes(int64_t m, int nrhs) {
+    if (m <= 0) return 0;
+    const int64_t mp = solve_mp(m), mr = mp + NB;
+    return align_up((size_t)mr * mp * sizeof(double), 256) + align_up((size_t)mp * std::max(nrhs, 1) * sizeof(double), 256) + 256;
+}
+
+extern "C" int mvf_solve(const double* G, const double* K, double lambda_sigma2, double jitter, const double* R,
+                         int64_t m, int nrhs, double* C, int* info, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+    MVF_REQUIRE(m >= 0 && nrhs >= 1 && nrhs <= 8, "mvf_solve: need m >= 0 and 1 <= nrhs <= 8 (got m=%lld nrhs=%d)",
+                (long long)m, nrhs);
+    MVF_REQUIRE(info, "mvf_solve: null info");
+    hipStream_t st = (hipStream_t)stream;
+    MVF_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+    if (m == 0) return 0;
+    MVF_REQUIRE(G && K && R && C, "mvf_solve: null pointer");
+    MVF_REQUIRE(std::isfinite(lambda_sigma2) && lambda_sigma2 >= 0.0 && jitter >= 0.0, "mvf_solve: bad regularisation");
+    const size_t need = mvf_solve_workspace_bytes(m, nrhs);
+    MVF_REQUIRE(workspace && workspace_bytes >= need, "mvf_solve: workspace too small (%zu < %zu)", workspace_bytes, need);
+    const int64_t mp = solve_mp(m), mr = mp + NB;
+    const int nb = (int)(mp / NB), nbr = nb + 1;
+    double* W = (double*)workspace;
+    double* Cp = (double*)((char*)workspace + align_up((size_t)mr * mp * sizeof(double), 256));
+    double* scal = (double*)((char*)Cp + align_up((size_t)mp * nrhs * sizeof(double), 256));
+
+    hipLaunchKernelGGL(diag_mean_kernel, dim3(1), dim3(256), 0, st, G, K, lambda_sigma2, jitter, m, scal);
+    MVF_LAUNCH_CHECK();
+    MVF_REQUIRE(mr <= 65535, "mvf_solve: m too large (%lld)", (long long)m);
+    hipLaunchKernelGGL(chol_prepare_kernel, dim3((unsigned)cdiv(mp, 256), (unsigned)mr), dim3(256), 0, st, G, K,
+                       lambda_sigma2, scal, R, m, nrhs, mp, mr, W);
+    MVF_LAUNCH_CHECK();
+    for (int k = 0; k < nb; ++k) {
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, W, mp, k, info);
+        const int64_t rows_below = mr - (int64_t)(k + 1) * NB;
+        hipLaunchKernelGGL(trsm_panel_kernel, dim3((unsigned)cdiv(rows_below, 64)), dim3(64), 0, st, W, mp, mr, k);
+        // tiles: sum over i in (k, nbr) of (min(i, nb-1) - k)
+        int64_t ntiles = 0;
+        for (int i = k + 1; i < nbr; ++i) ntiles += std::min(i, nb - 1) - k;
+        if (ntiles > 0)
+            hipLaunchKernelGGL(syrk_update_kernel, dim3((unsigned)ntiles), dim3(256), 0, st, W, mp, k, nb, nbr);
+    }
+    MVF_LAUNCH_CHECK();
+    for (int k = nb - 1; k >= 0; --k)
+        hipLaunchKernelGGL(bsub_kernel<8>, dim3(1), dim3(256), 0, st, W, mp, k, nrhs, Cp);
+    MVF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)cdiv(m * nrhs, 256)), dim3(256), 0, st, Cp, m * nrhs, C);
+    MVF_LAUNCH_CHECK();
+    return 0;
+}

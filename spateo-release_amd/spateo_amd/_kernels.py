@@ -1,0 +1,157 @@
+"""Thin Python layer over the libmvf C ABI: torch supplies device memory and the HIP stream, nothing else.
+
+Every method launches hand-written HIP kernels asynchronously on torch's current stream of ``device`` and returns
+device tensors.  Nothing here computes on the host and nothing falls back to torch/NumPy arithmetic.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DT = {"float32": (torch.float32, _lib.MVF_F32), "float64": (torch.float64, _lib.MVF_F64)}
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class HipKernels:
+    """libmvf kernels bound to one GPU and one cell dtype ("float32" | "float64")."""
+
+    def __init__(self, device=None, dtype="float32"):
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "spateo_amd needs an AMD GPU (HIP device) - torch.cuda.is_available() is False and there is no "
+                "CPU fallback for the SparseVFC path."
+            )
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if dtype not in _DT:
+            raise ValueError(f"dtype must be 'float32' or 'float64', got {dtype!r}")
+        self.dtype_name = dtype
+        self.tdtype, self.cdtype = _DT[dtype]
+        self._gram_ws = None
+        self._solve_ws = None
+        self._mins = torch.empty(_lib.MVF_ESTEP_MIN_DOUBLES, dtype=torch.float64, device=self.device)
+        # optional per-launch timing of the dominant (Gram MFMA) kernel: list of (start, end) torch events recorded
+        # on the launch stream; bench.py sets this to [] to enable it
+        self.gram_events = None
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def to_x4(self, arr, center=None):
+        """Host (n, d<=3) float64 array -> device (n, 4) tensor of the cell dtype (zero padded), optionally centred."""
+        a = np.asarray(arr, dtype=np.float64)
+        if a.ndim != 2 or not (1 <= a.shape[1] <= 3):
+            raise ValueError(f"expected an (n, d) array with d <= 3, got shape {a.shape}")
+        if center is not None:
+            a = a - np.asarray(center, dtype=np.float64)[None, : a.shape[1]]
+        buf = np.zeros((a.shape[0], 4), dtype=np.float32 if self.tdtype == torch.float32 else np.float64)
+        buf[:, : a.shape[1]] = a
+        return torch.from_numpy(buf).to(self.device)
+
+    def empty(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.tdtype, device=self.device)
+
+    def zeros(self, *shape, dtype=None):
+        return torch.zeros(*shape, dtype=dtype or self.tdtype, device=self.device)
+
+    # ------------------------------------------------------------------ kernels
+    def con_k(self, x, y, beta, return_d=False, dtype=None):
+        """x: (n, d), y: (m, d) device tensors (cell dtype, or `dtype`) -> K (n, m) [and D (n, d, m)]."""
+        tdtype, cdtype = _DT[dtype] if dtype is not None else (self.tdtype, self.cdtype)
+        if x.dtype != tdtype or y.dtype != tdtype:
+            raise TypeError(f"con_k: expected {tdtype} tensors, got {x.dtype} / {y.dtype}")
+        n, d = x.shape
+        m = y.shape[0]
+        x, y = x.contiguous(), y.contiguous()
+        K = self.empty(n, m, dtype=tdtype)
+        if return_d:
+            D = self.empty(n, d, m, dtype=tdtype)
+            _lib.check(self.lib.mvf_con_k_d(_ptr(x), n, _ptr(y), m, d, float(beta), _ptr(K), _ptr(D), cdtype,
+                                            self._stream()), "mvf_con_k_d")
+            return K, D
+        _lib.check(self.lib.mvf_con_k(_ptr(x), n, _ptr(y), m, d, float(beta), _ptr(K), cdtype, self._stream()),
+                   "mvf_con_k")
+        return K
+
+    def apply(self, x4, ctrl4, beta, C, y4=None, P=None, stats=None):
+        """V4 = con_K(x, ctrl) @ C; with y4 also r = ||y - V||^2 and stats[0] += sum P r.  Returns (V4, r)."""
+        n, m = x4.shape[0], ctrl4.shape[0]
+        V4 = self.empty(n, 4)
+        r = self.empty(n) if y4 is not None else None
+        _lib.check(self.lib.mvf_apply(_ptr(x4), n, _ptr(ctrl4), m, float(beta), _ptr(C), _ptr(V4), _ptr(y4), _ptr(P),
+                                      _ptr(r), _ptr(stats), self.cdtype, self._stream()), "mvf_apply")
+        return V4, r
+
+    def estep_min(self, r, sigma2):
+        """Returns a device float64 view (2,): [min non-zero t1, #zeros]."""
+        _lib.check(self.lib.mvf_estep_min(_ptr(r), r.shape[0], float(sigma2), _ptr(self._mins), self.cdtype,
+                                          self._stream()), "mvf_estep_min")
+        return self._mins[:2]
+
+    def estep_p(self, r, sigma2, gamma, a, dy, minP, theta, zero_fill, P_out, stats):
+        _lib.check(self.lib.mvf_estep_p(_ptr(r), r.shape[0], float(sigma2), float(gamma), float(a), int(dy),
+                                        float(minP), float(theta), float(zero_fill), _ptr(P_out), _ptr(stats),
+                                        self.cdtype, self._stream()), "mvf_estep_p")
+
+    def gram(self, x4, P, y4, ctrl4, beta, G, R):
+        n, m = x4.shape[0], ctrl4.shape[0]
+        need = self.lib.mvf_gram_workspace_bytes(n, m, self.cdtype)
+        if self._gram_ws is None or self._gram_ws.numel() < need:
+            self._gram_ws = None
+            self._gram_ws = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
+        args = (_ptr(x4), _ptr(P), _ptr(y4), n, _ptr(ctrl4), m, float(beta), _ptr(G), _ptr(R), _ptr(self._gram_ws),
+                self._gram_ws.numel(), self.cdtype, self._stream())
+        if self.gram_events is None:
+            _lib.check(self.lib.mvf_gram(*args), "mvf_gram")
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(self.lib.mvf_gram_stages(_lib.GRAM_TILES, *args), "mvf_gram_stages")
+        e1.record()
+        self.gram_events.append((e0, e1))
+        _lib.check(self.lib.mvf_gram_stages(_lib.GRAM_RHS | _lib.GRAM_REDUCE, *args), "mvf_gram_stages")
+
+    def solve(self, G, K, lambda_sigma2, jitter, R, C_out, info):
+        m, nrhs = R.shape
+        need = self.lib.mvf_solve_workspace_bytes(m, nrhs)
+        if self._solve_ws is None or self._solve_ws.numel() < need:
+            self._solve_ws = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.mvf_solve(_ptr(G), _ptr(K), float(lambda_sigma2), float(jitter), _ptr(R), m, nrhs,
+                                      _ptr(C_out), _ptr(info), _ptr(self._solve_ws), self._solve_ws.numel(),
+                                      self._stream()), "mvf_solve")
+
+    def quadform(self, K, C, out):
+        _lib.check(self.lib.mvf_quadform(_ptr(K), _ptr(C), K.shape[0], C.shape[1], _ptr(out), self._stream()),
+                   "mvf_quadform")
+
+    def eval(self, x4, ctrl4, beta, C, flags):
+        """Fused evaluator.  Returns a dict of float64 device tensors for the requested MVF_EVAL_* flags."""
+        n, m = x4.shape[0], ctrl4.shape[0]
+        f64 = torch.float64
+        out = {}
+
+        def buf(flag, *shape):
+            if flags & flag:
+                t = torch.empty(*shape, dtype=f64, device=self.device)
+                out[flag] = t
+                return t
+            return None
+
+        v = buf(_lib.EVAL_V, n, 3)
+        jac = buf(_lib.EVAL_JAC, 3, 3, n)
+        div = buf(_lib.EVAL_DIV, n)
+        curl = buf(_lib.EVAL_CURL, n, 3)
+        acc = buf(_lib.EVAL_ACC, n, 3)
+        curv = buf(_lib.EVAL_CURV, n, 3)
+        tors = buf(_lib.EVAL_TORS, n, 3)
+        jdet = buf(_lib.EVAL_JDET, n)
+        _lib.check(self.lib.mvf_eval(_ptr(x4), n, _ptr(ctrl4), m, float(beta), _ptr(C), int(flags), _ptr(v), _ptr(jac),
+                                     _ptr(div), _ptr(curl), _ptr(acc), _ptr(curv), _ptr(tors), _ptr(jdet),
+                                     self.cdtype, self._stream()), "mvf_eval")
+        return out

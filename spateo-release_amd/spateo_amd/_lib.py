@@ -1,0 +1,76 @@
+"""ctypes binding of ``libmvf.so`` (C ABI declared in ``include/mvf.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C spateo-release_amd/csrc`` and is the ONLY
+compute path of this package: there is no CPU fallback.  ``load()`` raises if the shared object is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmvf.so")
+
+MVF_F32, MVF_F64 = 0, 1
+MVF_ESTEP_MIN_DOUBLES = 4098
+
+GRAM_TILES, GRAM_RHS, GRAM_REDUCE = 1, 2, 4
+EVAL_V, EVAL_JAC, EVAL_DIV, EVAL_CURL, EVAL_ACC, EVAL_CURV, EVAL_TORS, EVAL_JDET = 1, 2, 4, 8, 16, 32, 64, 128
+
+_p, _i64, _i, _d, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/mvf.h one to one
+SIGNATURES = {
+    "mvf_last_error": (C.c_char_p, []),
+    "mvf_version": (_i, []),
+    "mvf_device_count": (_i, [C.POINTER(C.c_int)]),
+    "mvf_con_k": (_i, [_p, _i64, _p, _i64, _i, _d, _p, _i, _p]),
+    "mvf_con_k_d": (_i, [_p, _i64, _p, _i64, _i, _d, _p, _p, _i, _p]),
+    "mvf_apply": (_i, [_p, _i64, _p, _i64, _d, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "mvf_estep_min": (_i, [_p, _i64, _d, _p, _i, _p]),
+    "mvf_estep_p": (_i, [_p, _i64, _d, _d, _d, _i, _d, _d, _d, _p, _p, _i, _p]),
+    "mvf_gram_workspace_bytes": (_sz, [_i64, _i64, _i]),
+    "mvf_gram": (_i, [_p, _p, _p, _i64, _p, _i64, _d, _p, _p, _p, _sz, _i, _p]),
+    "mvf_gram_stages": (_i, [_i, _p, _p, _p, _i64, _p, _i64, _d, _p, _p, _p, _sz, _i, _p]),
+    "mvf_solve_workspace_bytes": (_sz, [_i64, _i]),
+    "mvf_solve": (_i, [_p, _p, _d, _d, _p, _i64, _i, _p, _p, _p, _sz, _p]),
+    "mvf_quadform": (_i, [_p, _p, _i64, _i, _p, _p]),
+    "mvf_eval": (_i, [_p, _i64, _p, _i64, _d, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+}
+
+_lib = None
+
+
+class MVFError(RuntimeError):
+    """Raised when a libmvf entry point returns a non-zero status."""
+
+
+def load():
+    """Load libmvf.so (once).  Fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C spateo-release_amd/csrc`). There is no CPU fallback for this path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mvf_last_error().decode("utf-8", "replace")
+        raise MVFError(f"libmvf {what} failed: {msg}")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(load().mvf_device_count(C.byref(n)), "mvf_device_count")
+    return n.value

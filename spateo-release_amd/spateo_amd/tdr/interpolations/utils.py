@@ -1,0 +1,44 @@
+"""Grid construction for the morphofield (reference: ``spateo/tdr/interpolations/utils.py:10-55``)."""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from ...logging import logger_manager as lm
+
+
+def _in_hull(p: np.ndarray, hull_points: np.ndarray) -> np.ndarray:
+    """Points of `p` inside the convex hull of `hull_points` (reference: ``spateo/tools/utils.py:205-221``)."""
+    from scipy.spatial import Delaunay
+
+    return Delaunay(hull_points).find_simplex(p) >= 0
+
+
+def get_X_Y_grid(
+    adata=None,
+    genes: Optional[List] = None,
+    X: Optional[np.ndarray] = None,
+    Y: Optional[np.ndarray] = None,
+    grid_num: List = [50, 50, 50],
+) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+    """Returns ``(X, Y, Grid, grid_in_hull)``: a regular grid over the bounding box of X padded by 1 % per side
+    (``utils.py:40-47``; note the reference pads ``max`` with the ALREADY padded ``min``), plus the convex-hull mask
+    (``:50-53``).  Like the reference this is 3-D only (``:50`` indexes ``X[:, 2]``)."""
+    lm.main_info("Learn a continuous mapping from space to gene expression pattern")
+    X, Y = adata.obsm["spatial"] if X is None else X, adata[:, genes].X if Y is None else Y
+
+    lm.main_info("Generate grid...")
+    min_vec, max_vec = X.min(0), X.max(0)
+    min_vec = min_vec - 0.01 * np.abs(max_vec - min_vec)
+    max_vec = max_vec + 0.01 * np.abs(max_vec - min_vec)
+    axes = [np.linspace(lo, hi, k) for lo, hi, k in zip(min_vec, max_vec, grid_num)]
+    Grid = np.stack([g.flatten() for g in np.meshgrid(*axes)], axis=1)
+
+    lm.main_info("Creating a Convex Hull...")
+    from scipy.spatial import ConvexHull
+
+    hull = ConvexHull(np.column_stack((X[:, 0], X[:, 1], X[:, 2])))
+    lm.main_info("Identify grid points within the Convex Hull...")
+    grid_in_hull = _in_hull(Grid, hull.points[hull.vertices, :])
+    return X, Y, Grid, grid_in_hull

@@ -1,0 +1,10 @@
+from .morphofield import _morphofield_sparsevfc, morphofield_sparsevfc
+from .morphofield_dg import (
+    morphofield_acceleration,
+    morphofield_curl,
+    morphofield_curvature,
+    morphofield_divergence,
+    morphofield_jacobian,
+    morphofield_torsion,
+    morphofield_velocity,
+)

@@ -1,0 +1,130 @@
+"""``morphofield_sparsevfc`` / ``_morphofield_sparsevfc`` with the reference's signatures
+(``spateo/tdr/morphometrics/morphofield/sparsevfc.py:103-115,241-256``); the fit itself runs on the MI355X through
+:func:`spateo_amd.vectorfield.SparseVFC` instead of ``dynamo.vectorfield.scVectorField.SparseVFC`` (``:167``).
+
+``cell_directions`` (``:18-100``, PASTE optimal-transport mapping) is upstream of the hot path and out of tier.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+
+from ....logging import logger_manager as lm
+from ....vectorfield import SparseVFC
+from ...interpolations import get_X_Y_grid
+
+
+def _cosine_score(vf_dict: dict) -> float:
+    """Acceptance metric of the restart loop (``sparsevfc.py:201-207``): mean over all entries of the product of the
+    unit-normalised (with +1e-20) input and learned velocities, times the number of columns."""
+    ref = vf_dict["Y"][vf_dict["valid_ind"]]
+    pred = vf_dict["V"][vf_dict["valid_ind"]]  # reference quirk: N_valid-row V indexed by valid_ind (IndexError if
+    # a non-finite row is not at the end) - kept, it is the reference's observable behaviour
+    ref_n = ref / (np.linalg.norm(ref, axis=1).reshape(-1, 1) + 1e-20)
+    pred_n = pred / (np.linalg.norm(pred, axis=1).reshape(-1, 1) + 1e-20)
+    return float(np.mean(ref_n * pred_n) * pred.shape[1])
+
+
+def _morphofield_sparsevfc(
+    X: np.ndarray,
+    V: np.ndarray,
+    NX: Optional[np.ndarray] = None,
+    grid_num: Optional[List[int]] = None,
+    M: int = 100,
+    lambda_: float = 0.02,
+    lstsq_method: str = "scipy",
+    min_vel_corr: float = 0.8,
+    restart_num: int = 10,
+    restart_seed: Union[List[int], Tuple[int], np.ndarray] = (0, 100, 200, 300, 400),
+    **kwargs,
+) -> dict:
+    """Learn the morphometric vector field with SparseVFC; restart with other seeds while the cosine correlation of
+    input and learned velocities stays below ``min_vel_corr`` (``sparsevfc.py:103-238``).  Returns the vf dict
+    (keys of SURVEY.md Appendix A step 6 + ``method = "sparsevfc"``).  Extra ``**kwargs`` go to ``SparseVFC``
+    (dynamo's ``a, beta, ecr, gamma, minP, MaxIter, theta, velocity_based_sampling`` and this package's
+    ``dtype, device, distributed``)."""
+    if NX is not None:
+        predict_X = NX
+    else:
+        if grid_num is None:
+            grid_num = [50, 50, 50]
+            lm.main_warning("grid_num and NX are both None, using `grid_num = [50,50,50]`.", indent_level=1)
+        _, _, predict_X, _ = get_X_Y_grid(X=X.copy(), Y=V.copy(), grid_num=grid_num)
+
+    fit = lambda **kw: SparseVFC(  # noqa: E731
+        X=X, Y=V, Grid=predict_X, M=M, lstsq_method=lstsq_method, lambda_=lambda_, **kw, **kwargs
+    )
+    if restart_num > 0:
+        restart_seed = np.asarray(restart_seed)
+        if len(restart_seed) != restart_num:
+            # reference quirk: the defaults (10 restarts, 5 seeds) always take this branch (:180-185)
+            lm.main_warning(
+                f"The length of {restart_seed} is different from {restart_num}, using `np.range(restart_num) * 100",
+                indent_level=1,
+            )
+            restart_seed = np.arange(restart_num) * 100
+        trials, scores, attempt = [], [], 0
+        while True:
+            cur = fit(seed=restart_seed[attempt])
+            score = _cosine_score(cur)
+            trials.append(cur)
+            scores.append(score)
+            if score >= min_vel_corr:
+                vf_dict = cur
+                break
+            attempt += 1
+            lm.main_info(
+                f"Current cosine correlation ({round(score, 5)}) between input velocities and learned velocities is "
+                f"less than {min_vel_corr}. Make a {attempt}-th vector field reconstruction trial.",
+                indent_level=1,
+            )
+            if attempt > restart_num - 1:
+                lm.main_warning(
+                    f"Cosine correlation between ({round(score, 5)}) input velocities and learned velocities is less "
+                    f"than {min_vel_corr} after {restart_num} trials of vector field reconstruction.",
+                    indent_level=1,
+                )
+                vf_dict = trials[int(np.argmax(np.array(scores)))]
+                break
+    else:
+        vf_dict = fit()
+
+    vf_dict["method"] = "sparsevfc"
+    lm.main_finish_progress(progress_name="morphofield")
+    return vf_dict
+
+
+def morphofield_sparsevfc(
+    adata,
+    spatial_key: str = "align_spatial",
+    V_key: str = "V_mapping",
+    key_added: str = "VecFld_morpho",
+    NX: Optional[np.ndarray] = None,
+    grid_num: Optional[List[int]] = None,
+    M: int = 100,
+    lambda_: float = 0.02,
+    lstsq_method: str = "scipy",
+    min_vel_corr: float = 0.8,
+    restart_num: int = 10,
+    restart_seed: Union[List[int], Tuple[int], np.ndarray] = (0, 100, 200, 300, 400),
+    inplace: bool = True,
+    **kwargs,
+):
+    """AnnData wrapper (``sparsevfc.py:241-328``): reads ``obsm[spatial_key]`` / ``obsm[V_key]`` as float64, stores
+    the vf dict in ``uns[key_added]``; returns ``None`` if ``inplace`` else the modified copy."""
+    adata = adata if inplace else adata.copy()
+    adata.uns[key_added] = _morphofield_sparsevfc(
+        X=np.asarray(adata.obsm[spatial_key], dtype=float),
+        V=np.asarray(adata.obsm[V_key], dtype=float),
+        NX=NX,
+        grid_num=grid_num,
+        M=M,
+        lambda_=lambda_,
+        lstsq_method=lstsq_method,
+        min_vel_corr=min_vel_corr,
+        restart_num=restart_num,
+        restart_seed=restart_seed,
+        **kwargs,
+    )
+    return None if inplace else adata

@@ -1,0 +1,531 @@
+"""MI355X-native replacement of the ``dynamo.vectorfield`` seam that Spateo's morphofield path calls.
+
+Seam being replaced: ``SparseVFC(X, Y, Grid, M=, lstsq_method=, lambda_=, seed=, **kw) -> dict``
+(call sites ``spateo/tdr/morphometrics/morphofield/sparsevfc.py:189-198,234``,
+``spateo/tdr/interpolations/interpolation_sparseVFC.py:63``) and the ``SvcVectorField`` class
+(``spateo/tdr/morphometrics/morphofield_dg/differential_geometry.py:25-28`` and the call shapes at
+``:68,108-109,154-157,197-198,242-243,291-292,331-335``).  Same names, argument meaning, dict keys, NumPy float64
+outputs and exceptions; the arithmetic runs in hand-written HIP kernels behind ``include/mvf.h``.
+
+Host (NumPy, bit-identical across implementations on purpose): finite-row filter, ``np.unique`` rows, control-point
+sampling, bandwidth -> beta.  Device: con_K, E-step, weighted Gram + rhs (MFMA), Cholesky solve, field application,
+sigma^2 / gamma statistics, evaluators.  Cells are block-sharded across ranks (one process per GPU); one all-reduce
+of ``[G | R | scalars]`` per EM step.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._kernels import HipKernels
+
+__all__ = [
+    "con_K",
+    "vector_field_function",
+    "SparseVFC",
+    "SparseVFCEngine",
+    "SvcVectorField",
+    "sparsevfc_preprocess",
+    "bandwidth_selector",
+    "sample_by_velocity",
+]
+
+_DEFAULT_DTYPE = "float64"
+
+
+def set_default_dtype(dtype: str):
+    """Cell dtype used when a call does not pass ``dtype=``: "float64" (parity mode) or "float32" (fast mode)."""
+    global _DEFAULT_DTYPE
+    if dtype not in ("float32", "float64"):
+        raise ValueError("dtype must be 'float32' or 'float64'")
+    _DEFAULT_DTYPE = dtype
+
+
+# =====================================================================================================================
+# host-side preprocessing (dynamo SparseVFC steps 1-3) - NumPy on purpose
+# =====================================================================================================================
+def bandwidth_selector(X: np.ndarray) -> float:
+    """dynamo ``bandwidth_selector``: exact kNN, k = max(2, int(0.2 n)) incl. self; h = sqrt(2) mean(d[:, 1:]) / 1.5."""
+    from scipy.spatial import cKDTree
+
+    n = X.shape[0]
+    k = max(2, int(0.2 * n))
+    distances, _ = cKDTree(X).query(X, k=k)
+    d = np.mean(distances[:, 1:]) / 1.5
+    return float(np.sqrt(2) * d)
+
+
+def sample_by_velocity(V: np.ndarray, n: int, seed: int = 19491001) -> np.ndarray:
+    """dynamo ``sample_by_velocity``: |V|-weighted sampling without replacement (re-seeds the global RNG, as dynamo)."""
+    np.random.seed(seed)
+    tmp_V = np.linalg.norm(V, axis=1)
+    p = tmp_V / np.sum(tmp_V)
+    return np.random.choice(np.arange(len(V)), size=n, p=p, replace=False)
+
+
+def sparsevfc_preprocess(X, Y, M=100, beta=None, velocity_based_sampling=True, seed=0):
+    """valid rows, unique rows, control points and beta exactly as dynamo's SparseVFC picks them."""
+    valid_ind = np.where(np.isfinite(Y.sum(1)))[0]
+    Xv, Yv = X[valid_ind], Y[valid_ind]
+    if len(Xv) == 0:
+        raise ValueError("SparseVFC: no row of Y is finite - nothing to fit.")
+    tmp_X, uid = np.unique(Xv, axis=0, return_index=True)
+    M = min(M, tmp_X.shape[0])
+    if velocity_based_sampling:
+        np.random.seed(seed)
+        idx = sample_by_velocity(Yv[uid], M)
+    else:
+        idx = np.random.RandomState(seed=seed).permutation(tmp_X.shape[0])
+        idx = idx[range(M)]
+    ctrl_pts = tmp_X[idx, :]
+    if beta is None:
+        h = bandwidth_selector(ctrl_pts)
+        beta = 1 / h**2
+    return valid_ind, Xv, Yv, idx, ctrl_pts, float(beta)
+
+
+# =====================================================================================================================
+# distributed helpers (one process per GPU; RCCL = torch.distributed "nccl" on ROCm; "gloo" in the CPU tests)
+# =====================================================================================================================
+def _dist_info(distributed, group):
+    if not distributed:
+        return 0, 1
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("distributed=True but torch.distributed is not initialised (launch with torchrun).")
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def shard_bounds(n: int, rank: int, world: int):
+    """Contiguous block shard [lo, hi) of n cells for `rank` (the first n % world ranks get one extra cell)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+# =====================================================================================================================
+# the engine
+# =====================================================================================================================
+class SparseVFCEngine:
+    """Device-resident SparseVFC EM loop over this rank's block of cells.
+
+    X, Y: this rank's cells (n_local x D, n_local x Dy, host float64, finite rows only).  ctrl (M x D) and beta are
+    identical on every rank.  ``n_total`` = global number of cells (for gamma and the initial sigma^2).
+    """
+
+    def __init__(self, X, Y, ctrl, beta, *, dtype=None, device=None, distributed=False, group=None, n_total=None,
+                 kernels=None):
+        dtype = dtype or _DEFAULT_DTYPE
+        X = np.asarray(X, dtype=np.float64)
+        Y = np.asarray(Y, dtype=np.float64)
+        ctrl = np.asarray(ctrl, dtype=np.float64)
+        if X.ndim != 2 or Y.ndim != 2 or len(X) != len(Y):
+            raise ValueError("X and Y must be 2-D with the same number of rows")
+        self.D, self.Dy = X.shape[1], Y.shape[1]
+        if not (1 <= self.D <= 3):
+            raise NotImplementedError(f"the HIP path supports 1-3 spatial dimensions, got {self.D}")
+        if not (1 <= self.Dy <= 3):
+            raise NotImplementedError(
+                f"the HIP path supports 1-3 output dimensions, got Dy={self.Dy} (kernel_interpolation's wide Dy is a "
+                f"'next' row, SURVEY.md 8f)"
+            )
+        self.k = kernels if kernels is not None else HipKernels(device, dtype)
+        self.distributed = bool(distributed)
+        self.group = group
+        self.rank, self.world = _dist_info(distributed, group)
+        self.n_local = len(X)
+        self.n_total = int(n_total) if n_total is not None else self.n_local
+        self.M = len(ctrl)
+        self.beta = float(beta)
+        self.ctrl = ctrl
+        # the kernel is translation invariant: centre on the control points so float32 keeps its bits for geometry
+        self.center = ctrl.mean(0) if self.M else np.zeros(self.D)
+
+        k = self.k
+        self.x4 = k.to_x4(X, self.center)
+        self.y4 = k.to_x4(Y)
+        self.ctrl4 = k.to_x4(ctrl, self.center)
+        f64 = torch.float64
+        M = self.M
+        # K = con_K(ctrl, ctrl) always float64 (regulariser + energy)
+        cc = np.zeros((M, 3))
+        cc[:, : self.D] = ctrl - self.center[None, :]
+        ctrl64 = torch.from_numpy(cc).to(k.device)
+        self.K = k.con_k(ctrl64, ctrl64, self.beta, dtype="float64")
+        # one contiguous float64 buffer for the all-reduce: [G (M*M) | R (M*3) | stats (4)]
+        self.red = k.zeros(M * M + 3 * M + 4, dtype=f64)
+        self.G = self.red[: M * M].view(M, M)
+        self.R = self.red[M * M : M * M + 3 * M].view(M, 3)
+        self.st = self.red[M * M + 3 * M :]
+        self.C = k.zeros(M, 3, dtype=f64)
+        self.C_new = k.zeros(M, 3, dtype=f64)
+        self.quad = k.zeros(1, dtype=f64)
+        self.spr = k.zeros(1, dtype=f64)
+        self.info = k.zeros(1, dtype=torch.int32)
+        self.P = torch.ones(self.n_local, dtype=k.tdtype, device=k.device)
+        self.V4 = k.zeros(self.n_local, 4)
+        self.r = None
+        # Cholesky jitter (relative to the mean diagonal): start with none - then the solve equals the reference's
+        # lstsq wherever the system has full numerical rank - and escalate only when a pivot fails (sticky afterwards)
+        self.jitter = 0.0
+        self.jitter_first = 1e-15 if dtype == "float64" else 1e-12
+        self.jitter_max = 1e-3
+        self.solve_retries = 0
+        self.E = 1.0
+        self.tecr = 1.0
+        self.iteration = 0
+
+    # ------------------------------------------------------------------ collectives
+    def _all_reduce(self, t, op="sum"):
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MIN, group=self.group)
+        return t
+
+    # ------------------------------------------------------------------ EM
+    def init_state(self, gamma=0.9):
+        """V = 0, C = 0, sigma^2 = sum ||Y||^2 / (N Dy)  (Appendix A step 4)."""
+        k = self.k
+        self.C.zero_()
+        self.spr.zero_()
+        empty_ctrl = self.ctrl4[:0]
+        self.V4, self.r = k.apply(self.x4, empty_ctrl, self.beta, self.C, self.y4, self.P, self.spr)
+        self._all_reduce(self.spr)
+        s2 = float(self.spr.cpu()[0]) / (self.n_total * self.Dy)
+        self.sigma2 = 1e-7 if s2 < 1e-8 else s2
+        self.gamma = float(gamma)
+        self.E, self.tecr, self.iteration = 1.0, 1.0, 0
+
+    def em_step(self, *, a=5.0, lambda_=3.0, minP=1e-5, theta=0.75):
+        """One EM iteration (Appendix A step 5 a-e).  Returns (E, tecr)."""
+        k = self.k
+        # ---- E-step: global min-non-zero rule, then posterior + statistics
+        mins = k.estep_min(self.r, self.sigma2)
+        m2 = torch.stack([mins[0], -mins[1]])
+        self._all_reduce(m2, "min")
+        mh = m2.cpu()
+        zero_fill = float(mh[0]) if (float(mh[1]) < 0 and math.isfinite(float(mh[0]))) else 0.0
+        self.st.zero_()
+        k.estep_p(self.r, self.sigma2, self.gamma, a, self.Dy, minP, theta, zero_fill, self.P, self.st)
+        # ---- M-step assembly (MFMA) + energy regulariser with the OLD coefficients
+        k.gram(self.x4, self.P, self.y4, self.ctrl4, self.beta, self.G, self.R)
+        k.quadform(self.K, self.C, self.quad)
+        self._all_reduce(self.red)  # the one big collective per EM step: [G | R | stats]
+        # ---- coefficient solve (jitter escalates only if a pivot fails; it is sticky afterwards)
+        ls2 = lambda_ * self.sigma2
+        while True:
+            k.solve(self.G, self.K, ls2, self.jitter, self.R, self.C_new, self.info)
+            host = torch.cat([self.st, self.quad, self.info.to(torch.float64)]).cpu()
+            if int(host[5]) == 0:
+                break
+            self.solve_retries += 1
+            self.jitter = max(self.jitter * 10.0, self.jitter_first)
+            if self.jitter > self.jitter_max:
+                raise _lib.MVFError(
+                    f"coefficient solve failed: non-positive pivot at {int(host[5]) - 1} even with jitter "
+                    f"{self.jitter:g}; the system is not numerically PSD (NaN/Inf in the inputs?)"
+                )
+        s_pr, s_p, s_pf, s_cnt, quad = (float(host[i]) for i in range(5))
+        E_old = self.E
+        E = s_pr / (2 * self.sigma2) + s_p * math.log(self.sigma2) * self.Dy / 2 + lambda_ / 2 * quad
+        self.tecr = abs((E - E_old) / E)
+        self.E = E
+        self.C, self.C_new = self.C_new, self.C
+        # ---- field + sigma^2 + gamma
+        self.spr.zero_()
+        self.V4, self.r = k.apply(self.x4, self.ctrl4, self.beta, self.C, self.y4, self.P, self.spr)
+        self._all_reduce(self.spr)
+        self.sigma2 = float(self.spr.cpu()[0]) / (s_pf * self.Dy)
+        g = s_cnt / self.n_total
+        self.gamma = 0.95 if g > 0.95 else (0.05 if g < 0.05 else g)
+        self.iteration += 1
+        return self.E, self.tecr
+
+    def fit(self, *, a=5, gamma=0.9, lambda_=3, minP=1e-5, MaxIter=500, theta=0.75, ecr=1e-5):
+        self.init_state(gamma)
+        tecr_vec, E_vec = [], []
+        while self.iteration < MaxIter and self.tecr > ecr and self.sigma2 > 1e-8:
+            E, tecr = self.em_step(a=a, lambda_=lambda_, minP=minP, theta=theta)
+            E_vec.append(E)
+            tecr_vec.append(tecr)
+        return np.asarray(tecr_vec), np.asarray(E_vec)
+
+    # ------------------------------------------------------------------ outputs
+    def predict(self, pts):
+        """v(pts) = con_K(pts, ctrl, beta) @ C on the device -> host float64 (n, Dy)."""
+        pts = np.asarray(pts, dtype=np.float64)
+        p4 = self.k.to_x4(pts, self.center)
+        V4, _ = self.k.apply(p4, self.ctrl4, self.beta, self.C)
+        return V4[:, : self.Dy].to(torch.float64).cpu().numpy()
+
+    def _gather_rows(self, t):
+        """Concatenate per-rank row blocks (sizes from shard_bounds) on every rank."""
+        if self.world == 1:
+            return t
+        import torch.distributed as dist
+
+        sizes = [shard_bounds(self.n_total, r, self.world) for r in range(self.world)]
+        mx = max(hi - lo for lo, hi in sizes)
+        pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        outs = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(outs, pad, group=self.group)
+        return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(outs, sizes)], dim=0)
+
+    def results(self):
+        """(V (N, Dy), P (N, 1), C (M, Dy)) as host float64, gathered over ranks."""
+        V = self._gather_rows(self.V4[:, : self.Dy].contiguous()).to(torch.float64).cpu().numpy()
+        P = self._gather_rows(self.P[:, None].contiguous()).to(torch.float64).cpu().numpy()
+        C = self.C[:, : self.Dy].cpu().numpy().copy()
+        return V, P, C
+
+
+# =====================================================================================================================
+# drop-in functions
+# =====================================================================================================================
+def con_K(x, y, beta: float = 0.1, method: str = "cdist", return_d: bool = False, *, dtype=None, device=None):
+    """GPU ``con_K`` with the reference's signature and shape rules (``gaussian_process.py:16-36``): 1-D ``x`` is
+    promoted to one row, a single-row result is flattened to 1-D (cdist path), ``return_d`` also returns
+    ``D[n, :, m] = x_n - y_m``.  ``method`` is accepted for compatibility (both paths give the same K)."""
+    dtype = dtype or _DEFAULT_DTYPE
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    if x.ndim == 1:
+        x = x[None, :]
+    k = HipKernels(device, dtype)
+    npdt = np.float32 if dtype == "float32" else np.float64
+    # translation invariance: centre before a possible cast to float32
+    c = y.mean(0) if len(y) else np.zeros(x.shape[1])
+    xd = torch.from_numpy(np.ascontiguousarray((x - c).astype(npdt))).to(k.device)
+    yd = torch.from_numpy(np.ascontiguousarray((y - c).astype(npdt))).to(k.device)
+    if return_d or method != "cdist":
+        K, D = k.con_k(xd, yd, beta, return_d=True)
+        K = K.to(torch.float64).cpu().numpy()
+        K = np.squeeze(K)
+        if return_d:
+            return K, D.to(torch.float64).cpu().numpy()
+        return K
+    K = k.con_k(xd, yd, beta).to(torch.float64).cpu().numpy()
+    if len(K) == 1:
+        K = K.flatten()
+    return K
+
+
+def _field_on_device(x, vf_dict, flags, dtype=None, device=None):
+    """Run the fused evaluator for points x (n, d) against vf_dict's control points / coefficients."""
+    dtype = dtype or _DEFAULT_DTYPE
+    Xc = np.asarray(vf_dict["X_ctrl"], dtype=np.float64)
+    Cc = np.asarray(vf_dict["C"], dtype=np.float64)
+    d = Xc.shape[1]
+    if x.shape[1] != d:
+        raise ValueError(f"query points have {x.shape[1]} dimensions, the vector field has {d}")
+    if d > 3 or Cc.shape[1] > 3:
+        raise NotImplementedError("the HIP evaluators support up to 3 dimensions")
+    k = HipKernels(device, dtype)
+    center = Xc.mean(0)
+    x4 = k.to_x4(x, center)
+    c4 = k.to_x4(Xc, center)
+    C3 = np.zeros((len(Xc), 3))
+    C3[:, : Cc.shape[1]] = Cc
+    Cd = torch.from_numpy(C3).to(k.device)
+    out = k.eval(x4, c4, float(vf_dict["beta"]), Cd, flags)
+    return {f: t.cpu().numpy() for f, t in out.items()}
+
+
+def vector_field_function(x, vf_dict, dim=None, *, dtype=None, device=None):
+    """``v(x) = con_K(x, X_ctrl, beta) @ C`` (dynamo ``vector_field_function``; call site
+    ``differential_geometry.py:67-68``).  1-D ``x`` -> 1-D output, like the reference's flattened single-row K."""
+    x = np.array(x, dtype=np.float64)
+    one = x.ndim == 1
+    if one:
+        x = x[None, :]
+    dy = np.asarray(vf_dict["C"]).shape[1]
+    v = _field_on_device(x, vf_dict, _lib.EVAL_V, dtype, device)[_lib.EVAL_V][:, :dy]
+    if dim is not None:
+        v = v[:, :dim] if np.isscalar(dim) else v[:, dim]
+    return v[0] if one else v
+
+
+def SparseVFC(
+    X,
+    Y,
+    Grid,
+    M=100,
+    a=5,
+    beta=None,
+    ecr=1e-5,
+    gamma=0.9,
+    lambda_=3,
+    minP=1e-5,
+    MaxIter=500,
+    theta=0.75,
+    div_cur_free_kernels=False,
+    velocity_based_sampling=True,
+    sigma=0.8,
+    eta=0.5,
+    seed=0,
+    lstsq_method="drouin",
+    verbose=1,
+    *,
+    dtype=None,
+    device=None,
+    distributed=False,
+    group=None,
+    _kernels=None,
+) -> dict:
+    """Drop-in for ``dynamo.vectorfield.scVectorField.SparseVFC`` (defaults identical).
+
+    Extra keyword-only arguments: ``dtype`` ("float64" parity mode | "float32" fast mode), ``device``,
+    ``distributed``/``group`` (every rank passes the same full X, Y; cells are block-sharded across ranks).
+    ``lstsq_method`` is accepted for compatibility: both "scipy" and "drouin" map to the device Cholesky solve
+    (DESIGN.md "Solve parity").  Returns the reference's dict with host NumPy float64 arrays.
+    """
+    if div_cur_free_kernels:
+        raise NotImplementedError("div_cur_free_kernels=True is out of scope (SURVEY.md Appendix A)")
+    X = np.asarray(X, dtype=float)
+    Y = np.asarray(Y, dtype=float)
+    if X.ndim != 2 or Y.ndim != 2 or len(X) != len(Y):
+        raise ValueError("X and Y must be 2-D arrays with the same number of rows")
+    X_ori, Y_ori = X.copy(), Y.copy()
+    valid_ind, Xv, Yv, idx, ctrl_pts, beta = sparsevfc_preprocess(
+        X, Y, M=M, beta=beta, velocity_based_sampling=velocity_based_sampling, seed=seed
+    )
+    N = len(Xv)
+    rank, world = _dist_info(distributed, group)
+    lo, hi = shard_bounds(N, rank, world)
+    eng = SparseVFCEngine(Xv[lo:hi], Yv[lo:hi], ctrl_pts, beta, dtype=dtype, device=device, distributed=distributed,
+                          group=group, n_total=N, kernels=_kernels)
+    tecr_vec, E_vec = eng.fit(a=a, gamma=gamma, lambda_=lambda_, minP=minP, MaxIter=MaxIter, theta=theta, ecr=ecr)
+    V, P, C = eng.results()
+    grid_V = eng.predict(Grid) if Grid is not None else None
+    i = eng.iteration
+    return {
+        "X": X_ori,
+        "valid_ind": valid_ind,
+        "X_ctrl": ctrl_pts,
+        "ctrl_idx": idx,
+        "Y": Y_ori,
+        "beta": beta,
+        "V": V,
+        "C": C,
+        "P": P,
+        "VFCIndex": np.where(P > theta)[0],
+        "sigma2": eng.sigma2,
+        "grid": Grid,
+        "grid_V": grid_V,
+        "iteration": i - 1,
+        "tecr_traj": tecr_vec[:i],
+        "E_traj": E_vec[:i],
+    }
+
+
+# =====================================================================================================================
+# SvcVectorField (the class shape Spateo uses) backed by the fused evaluator kernel
+# =====================================================================================================================
+class SvcVectorField:
+    """Counterpart of ``dynamo.vectorfield.scVectorField.SvcVectorField`` as used by
+    ``differential_geometry.py:25-28``; in-tree twin ``GPVectorField.py:193-266``.  Every ``compute_*`` keeps the
+    reference's return shapes, including the (n, 3, 3) broadcast of 3-D curl / torsion."""
+
+    def __init__(self, dtype=None, device=None):
+        self.data = {}
+        self.vf_dict = None
+        self.func = None
+        self._dtype, self._device = dtype, device
+
+    def from_adata(self, adata, basis=None, vf_key="VecFld"):
+        if basis is not None and len(basis) > 0:
+            vf_key = "%s_%s" % (vf_key, basis)
+        if vf_key not in adata.uns.keys():
+            raise ValueError(f"Vector field function {vf_key} is not included in the adata object!")
+        vf_dict = adata.uns[vf_key]
+        self.vf_dict = vf_dict
+        self.func = lambda x: vector_field_function(x, vf_dict, dtype=self._dtype, device=self._device)
+        self.data["X"] = vf_dict["X"]
+        self.data["V"] = vf_dict["Y"]  # dynamo keeps the raw input velocities here
+        return self
+
+    def get_data(self):
+        return self.data["X"], self.data["V"]
+
+    def _eval(self, X, flags):
+        X = np.asarray(X, dtype=np.float64)
+        return _field_on_device(X, self.vf_dict, flags, self._dtype, self._device)
+
+    @staticmethod
+    def _check_method(method):
+        if method != "analytical":
+            raise NotImplementedError("only method='analytical' is supported (numdifftools path is out of scope)")
+
+    def get_Jacobian(self, method="analytical", **kwargs):
+        """Returns ``f(x) -> (d, d, n)`` (``(d, d)`` for a 1-D x); ``J[f, i] = d f_f / d x_i``."""
+        self._check_method(method)
+
+        def jac(x):
+            x = np.asarray(x, dtype=np.float64)
+            one = x.ndim == 1
+            xx = x[None, :] if one else x
+            d = xx.shape[1]
+            J = self._eval(xx, _lib.EVAL_JAC)[_lib.EVAL_JAC][:d, :d, :]
+            return J[:, :, 0] if one else J
+
+        return jac
+
+    def compute_velocity(self, X):
+        return self.func(X)
+
+    def compute_acceleration(self, X=None, method="analytical", **kwargs):
+        self._check_method(method)
+        X = self.data["X"] if X is None else X
+        d = np.asarray(X).shape[1]
+        acc = self._eval(X, _lib.EVAL_ACC)[_lib.EVAL_ACC][:, :d]
+        return np.linalg.norm(acc, axis=1), acc
+
+    def compute_curvature(self, X=None, method="analytical", formula=2, **kwargs):
+        self._check_method(method)
+        X = self.data["X"] if X is None else X
+        d = np.asarray(X).shape[1]
+        if formula == 2:
+            cm = self._eval(X, _lib.EVAL_CURV)[_lib.EVAL_CURV][:, :d]
+            return np.linalg.norm(cm, axis=1), cm
+        elif formula == 1:
+            o = self._eval(X, _lib.EVAL_V | _lib.EVAL_ACC)
+            v, a = o[_lib.EVAL_V], o[_lib.EVAL_ACC]
+            # ||v a^T||_F / ||v||^3  ==  ||v|| ||a|| / ||v||^3
+            nv, na = np.linalg.norm(v, axis=1), np.linalg.norm(a, axis=1)
+            return nv * na / nv**3, None
+        n = len(np.asarray(X))
+        return np.zeros(n), None  # the reference leaves zeros for any other formula value
+
+    def compute_curl(self, X=None, method="analytical", dim1=0, dim2=1, dim3=2, **kwargs):
+        self._check_method(method)
+        X = self.data["X"] if X is None else np.asarray(X)
+        if dim3 is None or X.shape[1] == 2:
+            X = X[:, [dim1, dim2]]
+        else:
+            X = X[:, [dim1, dim2, dim3]]
+        if X.shape[1] == 2:
+            return self._eval(X, _lib.EVAL_CURL)[_lib.EVAL_CURL][:, 2].copy()  # J10 - J01
+        elif X.shape[1] == 3:
+            c = self._eval(X, _lib.EVAL_CURL)[_lib.EVAL_CURL]
+            # reference quirk (GPVectorField.py:64-68): the 3-vector is assigned into zeros((n, 3, 3))
+            return np.repeat(c[:, None, :], 3, axis=1)
+        raise ValueError("X has incorrect dimensions.")
+
+    def compute_torsion(self, X=None, method="analytical", **kwargs):
+        self._check_method(method)
+        X = self.data["X"] if X is None else np.asarray(X)
+        if X.shape[1] != 3:
+            raise Exception("torsion is only defined in 3 dimension.")
+        t = self._eval(X, _lib.EVAL_TORS)[_lib.EVAL_TORS]
+        return np.repeat(t[:, None, :], 3, axis=1)  # same broadcast as GPVectorField.py:87-92
+
+    def compute_divergence(self, X=None, method="analytical", vectorize_size=1000, **kwargs):
+        self._check_method(method)
+        X = self.data["X"] if X is None else X
+        return self._eval(X, _lib.EVAL_DIV)[_lib.EVAL_DIV]

@@ -1,0 +1,267 @@
+"""GPU parity tests, kernel by kernel: every libmvf entry point (called through the C ABI) against the float64
+NumPy oracle on the same seeded inputs, plus the reference twins' golden vectors.
+
+Tolerances (written here, per BASELINE.json north_star): float64 mode 1e-5 relative or far tighter where the
+quantity is well conditioned; float32 mode 1e-3 relative (kernels are well inside it)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dg_oracle as dgo  # noqa: E402
+from oracle import sparsevfc_oracle as svo  # noqa: E402
+
+DTYPES = [("float64", 1e-11), ("float32", 2e-5)]
+
+
+@pytest.fixture(scope="module")
+def st():
+    import spateo_amd
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return spateo_amd
+
+
+def _k(dtype):
+    from spateo_amd._kernels import HipKernels
+
+    return HipKernels("cuda:0", dtype)
+
+
+def _relmax(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-300))
+
+
+def _cloud(seed, n, m, d=3, scale=30.0):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1, 1, (n, d)) * scale
+    ctrl = X[rng.choice(n, m, replace=False)].copy()
+    return rng, X, ctrl
+
+
+# ------------------------------------------------------------------------------------------------- con_K
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+def test_con_k_golden_and_shapes(st, golden, dtype, tol):
+    g = golden
+    x, y, beta = g["conk_x"], g["conk_y"], float(g["conk_beta"])
+    K = st.con_K(x, y, beta, dtype=dtype)
+    assert K.shape == (7, 5) and K.dtype == np.float64
+    assert _relmax(K, g["conk_K_cdist"]) < tol
+    Kd, D = st.con_K(x, y, beta, return_d=True, dtype=dtype)
+    assert D.shape == (7, 3, 5)
+    assert _relmax(Kd, g["conk_K_diff"]) < tol
+    # D is computed on centred coordinates in the cell dtype: exact in float64 up to the centring round-off
+    assert np.abs(D - g["conk_D"]).max() < (1e-12 if dtype == "float64" else 1e-5)
+    Krow = st.con_K(x[2], y, beta, dtype=dtype)
+    assert Krow.shape == (5,)  # single row flattened like the reference
+    assert _relmax(Krow, g["conk_K_row"]) < tol
+    assert _relmax(st.con_K(g["conk_x2"], g["conk_y2"], 0.5, dtype=dtype), g["conk_K_2d"]) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("n,m,d", [(1000, 300, 3), (513, 257, 2), (130, 1030, 5), (1, 7, 3), (33, 1, 1)])
+def test_con_k_vs_oracle(st, dtype, tol, n, m, d):
+    rng = np.random.default_rng(n + m)
+    x = rng.standard_normal((n, d)) * 5
+    y = rng.standard_normal((m, d)) * 5
+    beta = 0.02
+    K = st.con_K(x, y, beta, dtype=dtype)
+    Kr = svo.con_K(x, y, beta)
+    assert K.shape == Kr.shape
+    assert np.abs(K - Kr).max() < tol  # K <= 1: absolute == relative to max
+
+
+def test_con_k_empty(st):
+    k = _k("float32")
+    x = torch.zeros((0, 3), dtype=torch.float32, device="cuda:0")
+    y = torch.zeros((5, 3), dtype=torch.float32, device="cuda:0")
+    assert k.con_k(x, y, 0.1).shape == (0, 5)
+    assert k.con_k(y, x, 0.1).shape == (5, 0)
+
+
+# ------------------------------------------------------------------------------------------------- apply
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-11), ("float32", 5e-5)])
+@pytest.mark.parametrize("n,m", [(2000, 700), (257, 5), (1025, 513)])
+def test_apply_vs_oracle(st, dtype, tol, n, m):
+    rng, X, ctrl = _cloud(n * 7 + m, n, m)
+    beta = 0.004
+    C = rng.standard_normal((m, 3))
+    Y = rng.standard_normal((n, 3))
+    P = rng.uniform(0.0, 1.0, n)
+    k = _k(dtype)
+    center = ctrl.mean(0)
+    x4, c4, y4 = k.to_x4(X, center), k.to_x4(ctrl, center), k.to_x4(Y)
+    Cd = torch.from_numpy(C).to("cuda:0")
+    Pd = torch.from_numpy(P.astype(np.float32 if dtype == "float32" else np.float64)).to("cuda:0")
+    stats = torch.zeros(1, dtype=torch.float64, device="cuda:0")
+    V4, r = k.apply(x4, c4, beta, Cd, y4, Pd, stats)
+    V = V4[:, :3].double().cpu().numpy()
+    Vr = svo.con_K(X, ctrl, beta) @ C
+    assert _relmax(V, Vr) < tol
+    assert np.all(V4[:, 3].cpu().numpy() == 0)
+    rr = np.sum((Y - Vr) ** 2, 1)
+    assert _relmax(r.double().cpu().numpy(), rr) < 10 * tol
+    assert abs(float(stats[0]) - float(Pd.double().cpu().numpy() @ rr)) / (P @ rr) < 10 * tol
+
+
+# ------------------------------------------------------------------------------------------------- E-step
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_estep_vs_oracle(st, dtype):
+    rng = np.random.default_rng(11)
+    n = 5000
+    Y = rng.standard_normal((n, 3))
+    V = Y + 0.2 * rng.standard_normal((n, 3))
+    V[:50] += 30.0  # gross outliers
+    sigma2, gamma, a, minP, theta = 0.05, 0.9, 5.0, 1e-5, 0.75
+    r = np.sum((Y - V) ** 2, 1)
+    npdt = np.float32 if dtype == "float32" else np.float64
+    r_dev = r.astype(npdt)
+    k = _k(dtype)
+    rd = torch.from_numpy(r_dev).to("cuda:0")
+    mins = k.estep_min(rd, sigma2).cpu().numpy()
+    t1 = np.exp(-r_dev.astype(np.float64) / (2 * sigma2))
+    assert mins[1] == (t1 == 0).sum()
+    assert mins[1] > 0  # the outliers underflow: the min-non-zero rule is exercised
+    np.testing.assert_allclose(mins[0], t1[t1 != 0].min(), rtol=1e-12)
+    Pd = torch.empty(n, dtype=rd.dtype, device="cuda:0")
+    stats = torch.zeros(4, dtype=torch.float64, device="cuda:0")
+    k.estep_p(rd, sigma2, gamma, a, 3, minP, theta, float(mins[0]), Pd, stats)
+    # oracle on the SAME (possibly float32-rounded) residuals: V' chosen so that ||Y - V'||^2 == r_dev
+    Vp = Y.copy()
+    Vp[:, 0] -= np.sqrt(r_dev.astype(np.float64))
+    Vp[:, 1:] = Y[:, 1:]
+    Pr, _ = svo.get_P(Y, Vp, sigma2, gamma, a)
+    rq = np.sum((Y - Vp) ** 2, 1)
+    Pf = np.maximum(Pr[:, 0], minP)
+    tol = 1e-9 if dtype == "float64" else 2e-6
+    np.testing.assert_allclose(Pd.double().cpu().numpy(), Pf, rtol=tol, atol=1e-12)
+    s = stats.cpu().numpy()
+    np.testing.assert_allclose(s[0], Pr[:, 0] @ rq, rtol=1e-6)
+    np.testing.assert_allclose(s[1], Pr.sum(), rtol=1e-9)
+    np.testing.assert_allclose(s[2], Pf.sum(), rtol=1e-6)
+    assert s[3] == (Pd.double().cpu().numpy() > theta).sum()
+
+
+# ------------------------------------------------------------------------------------------------- Gram + rhs
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-11), ("float32", 3e-6)])
+@pytest.mark.parametrize("n,m", [(3000, 300), (1000, 128), (700, 130), (5000, 40)])
+def test_gram_vs_oracle(st, dtype, tol, n, m):
+    rng, X, ctrl = _cloud(n + 3 * m, n, m)
+    beta = 0.003
+    Y = rng.standard_normal((n, 3))
+    P = rng.uniform(1e-5, 1.0, n)
+    npdt = np.float32 if dtype == "float32" else np.float64
+    k = _k(dtype)
+    center = ctrl.mean(0)
+    x4, c4, y4 = k.to_x4(X, center), k.to_x4(ctrl, center), k.to_x4(Y)
+    Pd = torch.from_numpy(P.astype(npdt)).to("cuda:0")
+    G = torch.empty(m, m, dtype=torch.float64, device="cuda:0")
+    R = torch.empty(m, 3, dtype=torch.float64, device="cuda:0")
+    k.gram(x4, Pd, y4, c4, beta, G, R)
+    U = svo.con_K(X, ctrl, beta)
+    Pq = Pd.double().cpu().numpy()
+    UP = U.T * Pq[None, :]
+    Gr, Rr = UP @ U, UP @ Y
+    Gd, Rd = G.cpu().numpy(), R.cpu().numpy()
+    assert np.array_equal(Gd, Gd.T), "G must be exactly symmetric (mirrored tiles)"
+    assert _relmax(Gd, Gr) < tol  # catches row/col transposition: off-diagonal tile blocks are not symmetric
+    assert _relmax(Rd, Rr) < 10 * tol
+    # run-to-run determinism (fixed-order reduction)
+    G2 = torch.empty_like(G)
+    R2 = torch.empty_like(R)
+    k.gram(x4, Pd, y4, c4, beta, G2, R2)
+    assert torch.equal(G, G2) and torch.equal(R, R2)
+
+
+# ------------------------------------------------------------------------------------------------- solve
+@pytest.mark.parametrize("m,nrhs", [(64, 3), (100, 3), (300, 2), (517, 1)])
+def test_solve_spd_vs_numpy(st, m, nrhs):
+    rng = np.random.default_rng(m)
+    A = rng.standard_normal((m, 2 * m))
+    G = A @ A.T / (2 * m)
+    Kc = rng.standard_normal((m, m))
+    K = Kc @ Kc.T / m
+    R = rng.standard_normal((m, nrhs))
+    ls2 = 0.37
+    k = _k("float64")
+    dev = "cuda:0"
+    Gd, Kd, Rd = (torch.from_numpy(a).to(dev) for a in (G, K, R))
+    C = torch.empty(m, nrhs, dtype=torch.float64, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    k.solve(Gd, Kd, ls2, 0.0, Rd, C, info)
+    assert int(info.cpu()[0]) == 0
+    Cr = np.linalg.solve(G + ls2 * K, R)
+    assert _relmax(C.cpu().numpy(), Cr) < 1e-9
+
+
+def test_solve_reports_non_psd(st):
+    m = 96
+    G = -np.eye(m)
+    K = np.zeros((m, m))
+    k = _k("float64")
+    dev = "cuda:0"
+    C = torch.empty(m, 3, dtype=torch.float64, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    k.solve(torch.from_numpy(G).to(dev), torch.from_numpy(K).to(dev), 0.0, 0.0,
+            torch.ones(m, 3, dtype=torch.float64, device=dev), C, info)
+    assert int(info.cpu()[0]) == 1  # first pivot fails -> 1 + index 0
+
+
+def test_quadform(st):
+    rng = np.random.default_rng(2)
+    m = 333
+    K = rng.standard_normal((m, m))
+    C = rng.standard_normal((m, 3))
+    k = _k("float64")
+    out = torch.zeros(1, dtype=torch.float64, device="cuda:0")
+    k.quadform(torch.from_numpy(K).to("cuda:0"), torch.from_numpy(C).to("cuda:0"), out)
+    np.testing.assert_allclose(float(out.cpu()[0]), np.trace(C.T @ K @ C), rtol=1e-11)
+
+
+# ------------------------------------------------------------------------------------------------- evaluators
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-10), ("float32", 1e-4)])
+def test_evaluators_golden(st, golden, dtype, tol):
+    g = golden
+    vfd = {"X_ctrl": g["dg_Xc"], "C": g["dg_C"], "beta": float(g["dg_beta"])}
+    Xq = g["dg_Xq"]
+    vf = st.SvcVectorField(dtype=dtype, device="cuda:0")
+    vf.vf_dict = vfd
+    vf.func = lambda x: st.vector_field_function(x, vfd, dtype=dtype)
+    assert _relmax(vf.func(Xq), g["dg_v"]) < tol
+    J = vf.get_Jacobian()(Xq)
+    assert J.shape == (3, 3, len(Xq))
+    assert _relmax(J, g["dg_J_loop"]) < tol
+    J1 = vf.get_Jacobian()(Xq[3])
+    assert J1.shape == (3, 3) and _relmax(J1, g["dg_J_1d"]) < tol
+    acc, acc_mat = vf.compute_acceleration(Xq)
+    assert _relmax(acc, g["dg_acc"]) < tol and _relmax(acc_mat, g["dg_acc_mat"]) < tol
+    c2, c2m = vf.compute_curvature(Xq, formula=2)
+    assert _relmax(c2, g["dg_curv2"]) < tol and _relmax(c2m, g["dg_curv2_mat"]) < tol
+    c1, c1m = vf.compute_curvature(Xq, formula=1)
+    assert c1m is None and _relmax(c1, g["dg_curv1"]) < tol
+    curl = vf.compute_curl(Xq)
+    assert curl.shape == (len(Xq), 3, 3) and _relmax(curl, g["dg_curl"]) < tol
+    tor = vf.compute_torsion(Xq)
+    assert tor.shape == (len(Xq), 3, 3) and _relmax(tor, g["dg_tor"]) < 10 * tol
+    assert _relmax(vf.compute_divergence(Xq, vectorize_size=4), g["dg_div"]) < tol
+    # 2-D
+    vfd2 = {"X_ctrl": g["dg_Xc"][:, :2].copy(), "C": g["dg_C"][:, :2].copy(), "beta": vfd["beta"]}
+    vf2 = st.SvcVectorField(dtype=dtype, device="cuda:0")
+    vf2.vf_dict = vfd2
+    curl2 = vf2.compute_curl(Xq[:, :2].copy())
+    assert curl2.shape == (len(Xq),) and _relmax(curl2, g["dg_curl2d"]) < tol
+    with pytest.raises(Exception, match="torsion is only defined in 3 dimension"):
+        vf2.compute_torsion(Xq[:, :2].copy())
+
+
+def test_evaluators_large_vs_oracle(st):
+    rng, X, ctrl = _cloud(5, 3000, 700)
+    vfd = {"X_ctrl": ctrl, "C": rng.standard_normal((700, 3)), "beta": 0.004}
+    vf = st.SvcVectorField(dtype="float64", device="cuda:0")
+    vf.vf_dict = vfd
+    J = vf.get_Jacobian()(X)
+    Jr = dgo.Jacobian_rkhs_gaussian(X, vfd, vectorize=True)
+    assert _relmax(J, Jr) < 1e-10
+    div = vf.compute_divergence(X)
+    assert _relmax(div, np.trace(Jr)) < 1e-10
