@@ -28,6 +28,7 @@ for _p in (ROOT, os.path.join(ROOT, "spateo-release_amd")):
         sys.path.insert(0, _p)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (spec; 155 measured)
+PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X datasheet: FP64 matrix (v_mfma_f64_16x16x4_f64) dense peak
 PEAK_HBM_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 
 
@@ -88,6 +89,9 @@ def main():
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
     ap.add_argument("--lambda_", type=float, default=0.02, help="Spateo's default regularisation")
     ap.add_argument("--cpu-cells", type=int, default=20_000, help="sample size of the CPU baseline (0 = skip)")
+    ap.add_argument("--gram-mode", default="f64acc", choices=["f64acc", "f32mfma"],
+                    help="float32 Gram kernel: f64acc = float32 operands + float64 MFMA accumulation (default, meets "
+                         "the 1e-3 field tolerance); f32mfma = all-float32 MFMA (2x peak, noisier)")
     ap.add_argument("--no-conk", action="store_true", help="skip the con_K bandwidth run")
     args = ap.parse_args()
 
@@ -126,7 +130,7 @@ def main():
     if rank == 0:
         log(f"[bench] generated + preprocessed N={N} M={len(ctrl)} beta={beta:.4g} in {time.perf_counter() - t0:.1f}s; "
             f"rank shard = {hi - lo} cells")
-    kern = HipKernels(device, args.dtype)
+    kern = HipKernels(device, args.dtype, gram_mode=args.gram_mode)
     eng = SparseVFCEngine(Xv[lo:hi], Yv[lo:hi], ctrl, beta, dtype=args.dtype, device=device, distributed=distributed,
                           n_total=N, kernels=kern)
     del X, V
@@ -163,13 +167,16 @@ def main():
     gram_avg_ms = float(np.mean(gram_ms))
     alg_flops = float(n_loc) * Mc * (Mc + 1)  # symmetric Gram: n m (m+1) flops
     achieved = alg_flops / (gram_avg_ms * 1e-3) / 1e12
+    f32mfma = args.dtype == "float32" and args.gram_mode == "f32mfma"
+    peak = PEAK_F32_MFMA_TFLOPS if f32mfma else PEAK_F64_MFMA_TFLOPS
     roofline = {
-        "kernel": "gram_f32_kernel" if args.dtype == "float32" else "gram_f64_kernel",
+        "kernel": "gram_f32_kernel (v_mfma_f32_32x32x2_f32)" if f32mfma else
+                  f"gram_f64acc_kernel<{'float' if args.dtype == 'float32' else 'double'}> (v_mfma_f64_16x16x4_f64)",
         "bound": "mfma",
         "achieved": achieved,
-        "peak": PEAK_F32_MFMA_TFLOPS if args.dtype == "float32" else 78.6,
+        "peak": peak,
         "unit": "TFLOP/s",
-        "frac": achieved / (PEAK_F32_MFMA_TFLOPS if args.dtype == "float32" else 78.6),
+        "frac": achieved / peak,
         "traffic": None,
         "avg_kernel_ms": gram_avg_ms,
         "launches": len(gram_ms),
@@ -199,6 +206,7 @@ def main():
             "sigma2_after": eng.sigma2,
             "solve_jitter": eng.jitter,
             "solve_retries": eng.solve_retries,
+            "gram_mode": args.gram_mode,
         },
         "roofline": roofline,
     }

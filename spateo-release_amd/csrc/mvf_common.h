@@ -48,6 +48,19 @@ struct Vec4<double> {
 __device__ __forceinline__ float exp2_neg(float e) { return __builtin_amdgcn_exp2f(e); }  // v_exp_f32
 __device__ __forceinline__ double exp2_neg(double e) { return exp2(e); }
 
+// THE Gaussian kernel value, on coordinates pre-scaled by sqrt(beta*log2e).  Every kernel (Gram, rhs, apply, eval,
+// con_K) must produce bit-identical K(x, c) for the same inputs: the coefficients C are fitted to the U implied by the
+// Gram/rhs kernels and carry large cancelling entries, so a 1e-6 relative disagreement between "the U that was fitted"
+// and "the U that is applied" shows up as a 1e-2 error in V = U C.  Hence one function, explicit fma, and the whole
+// library is built with -ffp-contract=off so the compiler cannot fuse the scaling multiply into the subtraction in
+// one kernel and not in another.
+template <typename T>
+__device__ __forceinline__ T kernel_value(T px, T py, T pz, T cx, T cy, T cz) {
+    const T dx = px - cx, dy = py - cy, dz = pz - cz;
+    const T e = fma(dz, dz, fma(dy, dy, dx * dx));
+    return exp2_neg(-e);
+}
+
 // ---- wave / block reductions (wave64 shuffles, then LDS across waves) ----
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

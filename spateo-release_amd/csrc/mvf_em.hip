@@ -60,9 +60,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const T* __restrict__ x4, in
             const double4 cc = sC[j];
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
-                const T dx = px[c] - cv.x, dy = py[c] - cv.y, dz = pz[c] - cv.z;
-                const T e = fma(dz, dz, fma(dy, dy, dx * dx));
-                const double k = (double)exp2_neg(-e);
+                const double k = (double)kernel_value(px[c], py[c], pz[c], cv.x, cv.y, cv.z);
                 v0[c] = fma(k, cc.x, v0[c]);
                 v1[c] = fma(k, cc.y, v1[c]);
                 v2[c] = fma(k, cc.z, v2[c]);

@@ -66,8 +66,7 @@ __global__ __launch_bounds__(256) void eval_kernel(const T* __restrict__ x4, int
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
                 const T dx = px[c] - cv.x, dy = py[c] - cv.y, dz = pz[c] - cv.z;
-                const T e = fma(dz, dz, fma(dy, dy, dx * dx));
-                const double k = (double)exp2_neg(-e);
+                const double k = (double)kernel_value(px[c], py[c], pz[c], cv.x, cv.y, cv.z);
                 const double t0 = k * cc.x, t1 = k * cc.y, t2 = k * cc.z;
                 const double ddx = (double)dx, ddy = (double)dy, ddz = (double)dz;
                 v[c][0] += t0, v[c][1] += t1, v[c][2] += t2;

@@ -143,12 +143,8 @@ __global__ __launch_bounds__(256, 2) void gram_f32_kernel(const float4* __restri
             float fa[2], fb[2];
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                float dx = cell.x - ax[a], dy = cell.y - ay[a], dz = cell.z - az[a];
-                float e = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                fa[a] = __builtin_amdgcn_exp2f(-e) * cell.w;
-                dx = cell.x - bx[a], dy = cell.y - by[a], dz = cell.z - bz[a];
-                e = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                fb[a] = __builtin_amdgcn_exp2f(-e);
+                fa[a] = kernel_value(cell.x, cell.y, cell.z, ax[a], ay[a], az[a]) * cell.w;
+                fb[a] = kernel_value(cell.x, cell.y, cell.z, bx[a], by[a], bz[a]);
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -184,14 +180,22 @@ __global__ __launch_bounds__(256, 2) void gram_f32_kernel(const float4* __restri
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// float64 MFMA Gram kernel (v_mfma_f64_16x16x4_f64: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15];
-// C/D: col = l & 15, row = (l >> 4) + 4 * reg)
+// float64-ACCUMULATE MFMA Gram kernel (v_mfma_f64_16x16x4_f64: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15];
+// C/D: col = l & 15, row = (l >> 4) + 4 * reg).  TIn = double: the float64 mode.  TIn = float: the default float32
+// mode - operands are generated in float32 (6 VALU + v_exp_f32) and widened; a product of two float32 values is exact
+// in float64, so G is the EXACT Gram matrix of the float32-rounded kernel values (error ~1e-16 sqrt(n)), whereas the
+// all-float32 MFMA kernel above leaves ~1e-9 relative noise that the ill-conditioned solve amplifies to percent level
+// (DESIGN.md "Why the float32 mode accumulates in float64").
 // ----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void gram_f64_kernel(const double4* __restrict__ x4, const double* __restrict__ P,
-                                                          int64_t n, const double4* __restrict__ ctrl4, int64_t m,
-                                                          double s, int nt, int npairs, int64_t slice_len,
-                                                          double* __restrict__ partial) {
-    __shared__ double4 cells[2][GCHUNK];
+template <typename TIn>
+__global__ __launch_bounds__(256, 1) void gram_f64acc_kernel(const typename Vec4<TIn>::type* __restrict__ x4,
+                                                             const TIn* __restrict__ P, int64_t n,
+                                                             const typename Vec4<TIn>::type* __restrict__ ctrl4,
+                                                             int64_t m, TIn s, int nt, int npairs, int64_t slice_len,
+                                                             double* __restrict__ partial) {
+    using V4 = typename Vec4<TIn>::type;
+    __shared__ V4 cells[2][GCHUNK];
+    const TIn PAD = sizeof(TIn) == 4 ? (TIn)1.0e18f : (TIn)1.0e150;
 
     const int pair = blockIdx.x % npairs;
     const int64_t slice = blockIdx.x / npairs;
@@ -202,22 +206,22 @@ __global__ __launch_bounds__(256, 1) void gram_f64_kernel(const double4* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
 
-    double ax[4], ay[4], az[4], bx[4], by[4], bz[4];
+    TIn ax[4], ay[4], az[4], bx[4], by[4], bz[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int64_t ia = (int64_t)ti * GT + wi * 64 + a * 16 + (lane & 15);
         const int64_t ib = (int64_t)tj * GT + wj * 64 + a * 16 + (lane & 15);
         if (ia < m) {
-            const double4 c = ctrl4[ia];
+            const V4 c = ctrl4[ia];
             ax[a] = c.x * s, ay[a] = c.y * s, az[a] = c.z * s;
         } else {
-            ax[a] = ay[a] = az[a] = 1.0e150;
+            ax[a] = ay[a] = az[a] = PAD;
         }
         if (ib < m) {
-            const double4 c = ctrl4[ib];
+            const V4 c = ctrl4[ib];
             bx[a] = c.x * s, by[a] = c.y * s, bz[a] = c.z * s;
         } else {
-            bx[a] = by[a] = bz[a] = 1.0e150;
+            bx[a] = by[a] = bz[a] = PAD;
         }
     }
 
@@ -227,35 +231,32 @@ __global__ __launch_bounds__(256, 1) void gram_f64_kernel(const double4* __restr
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-    auto load_cell = [&](int64_t i) -> double4 {
+    auto load_cell = [&](int64_t i) -> V4 {
         if (i < n1) {
-            const double4 xv = x4[i];
-            return double4{xv.x * s, xv.y * s, xv.z * s, P[i]};
+            const V4 xv = x4[i];
+            return V4{xv.x * s, xv.y * s, xv.z * s, P[i]};
         }
-        return double4{0.0, 0.0, 0.0, 0.0};
+        return V4{0, 0, 0, 0};
     };
 
     const int nchunks = (int)((n1 - n0 + GCHUNK - 1) / GCHUNK);
-    double4 stage = load_cell(n0 + tid);
+    V4 stage = load_cell(n0 + tid);
     cells[0][tid] = stage;
     const int quarter = lane >> 4;
 
     for (int c = 0; c < nchunks; ++c) {
         __syncthreads();
         if (c + 1 < nchunks) stage = load_cell(n0 + (int64_t)(c + 1) * GCHUNK + tid);
-        const double4* cb = cells[c & 1];
+        const V4* cb = cells[c & 1];
 #pragma unroll 2
         for (int st = 0; st < GCHUNK / 4; ++st) {
-            const double4 cell = cb[4 * st + quarter];
+            const V4 cell = cb[4 * st + quarter];
             double fa[4], fb[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                double dx = cell.x - ax[a], dy = cell.y - ay[a], dz = cell.z - az[a];
-                double e = fma(dz, dz, fma(dy, dy, dx * dx));
-                fa[a] = exp2(-e) * cell.w;
-                dx = cell.x - bx[a], dy = cell.y - by[a], dz = cell.z - bz[a];
-                e = fma(dz, dz, fma(dy, dy, dx * dx));
-                fb[a] = exp2(-e);
+                // P K: exact product in float64
+                fa[a] = (double)kernel_value(cell.x, cell.y, cell.z, ax[a], ay[a], az[a]) * (double)cell.w;
+                fb[a] = (double)kernel_value(cell.x, cell.y, cell.z, bx[a], by[a], bz[a]);
             }
 #pragma unroll
             for (int a = 0; a < 4; ++a)
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256, 1) void gram_f64_kernel(const double4* __restr
 
 // ----------------------------------------------------------------------------------------------------------------
 // rhs:  R[j, :] = sum_n K(x_n, c_j) P_n y_n   (VALU kernel; a lane owns RHS_CPT control points, cells broadcast
-// from LDS; float32 partial sums per 256-cell stage folded into float64)
+// from LDS; float64 accumulation)
 // ----------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void rhs_kernel(const T* __restrict__ x4, const T* __restrict__ P,
@@ -319,28 +320,19 @@ __global__ __launch_bounds__(256) void rhs_kernel(const T* __restrict__ x4, cons
             sw[threadIdx.x] = V4T{0, 0, 0, 0};  // zero weight
         }
         __syncthreads();
-        T t0[RHS_CPT], t1[RHS_CPT], t2[RHS_CPT];
-#pragma unroll
-        for (int c = 0; c < RHS_CPT; ++c) t0[c] = t1[c] = t2[c] = T(0);
+        // float64 accumulation on purpose: rounding noise in R is NOT of the form U^T P (dY), so the ill-conditioned
+        // solve amplifies it by 1/sigma_min(U) (a float32 accumulation here cost 1e-2 in V)
 #pragma unroll 4
         for (int q = 0; q < GCHUNK; ++q) {
             const V4T xv = sx[q];
             const V4T wv = sw[q];
 #pragma unroll
             for (int c = 0; c < RHS_CPT; ++c) {
-                const T dx = xv.x - cx[c], dy = xv.y - cy[c], dz = xv.z - cz[c];
-                const T e = fma(dz, dz, fma(dy, dy, dx * dx));
-                const T k = exp2_neg(-e);
-                t0[c] = fma(k, wv.x, t0[c]);
-                t1[c] = fma(k, wv.y, t1[c]);
-                t2[c] = fma(k, wv.z, t2[c]);
+                const double k = (double)kernel_value(xv.x, xv.y, xv.z, cx[c], cy[c], cz[c]);
+                r0[c] = fma(k, (double)wv.x, r0[c]);
+                r1[c] = fma(k, (double)wv.y, r1[c]);
+                r2[c] = fma(k, (double)wv.z, r2[c]);
             }
-        }
-#pragma unroll
-        for (int c = 0; c < RHS_CPT; ++c) {
-            r0[c] += (double)t0[c];
-            r1[c] += (double)t1[c];
-            r2[c] += (double)t2[c];
         }
     }
 #pragma unroll
@@ -365,12 +357,13 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restri
     const int row = e / GT, col = e % GT;
     const int64_t i = (int64_t)ti * GT + row, j = (int64_t)tj * GT + col;
     if (i >= m || j >= m) return;
+    if (ti == tj && col < row) return;  // diagonal tiles: keep the upper triangle, mirror it -> G exactly symmetric
     double acc = 0.0;
     const double* p = partial + (size_t)pair * (GT * GT) + e;
     const size_t stride = (size_t)npairs * (GT * GT);
     for (int64_t s = 0; s < nslices; ++s) acc += p[s * stride];
     G[i * m + j] = acc;
-    if (ti != tj) G[j * m + i] = acc;
+    if (i != j) G[j * m + i] = acc;
 }
 
 __global__ __launch_bounds__(256) void rhs_reduce_kernel(const double* __restrict__ rpart, int64_t rslices, int64_t m,
@@ -390,6 +383,14 @@ __global__ __launch_bounds__(256) void rhs_reduce_kernel(const double* __restric
 }  // namespace mvf
 
 using namespace mvf;
+
+static int g_gram_mode = MVF_GRAM_MODE_F64_ACC;
+
+extern "C" int mvf_set_gram_mode(int mode) {
+    MVF_REQUIRE(mode == MVF_GRAM_MODE_F64_ACC || mode == MVF_GRAM_MODE_F32_MFMA, "mvf_set_gram_mode: bad mode %d", mode);
+    g_gram_mode = mode;
+    return 0;
+}
 
 extern "C" size_t mvf_gram_workspace_bytes(int64_t n, int64_t m, mvf_dtype dtype) {
     (void)dtype;
@@ -427,12 +428,16 @@ extern "C" int mvf_gram_stages(int stages, const void* x4, const void* P, const 
     const unsigned njobs = (unsigned)(p.nslices * p.npairs);
     dim3 rgrid((unsigned)p.rcolblocks, (unsigned)p.rslices);
     if (stages & MVF_GRAM_STAGE_TILES) {
-        if (dtype == MVF_F32)
+        if (dtype == MVF_F32 && g_gram_mode == MVF_GRAM_MODE_F32_MFMA)
             hipLaunchKernelGGL(gram_f32_kernel, dim3(njobs), dim3(256), 0, st, (const float4*)x4, (const float*)P, n,
                                (const float4*)ctrl4, m, (float)s, p.nt, p.npairs, p.slice_len, gpart);
+        else if (dtype == MVF_F32)
+            hipLaunchKernelGGL(gram_f64acc_kernel<float>, dim3(njobs), dim3(256), 0, st, (const float4*)x4,
+                               (const float*)P, n, (const float4*)ctrl4, m, (float)s, p.nt, p.npairs, p.slice_len,
+                               gpart);
         else
-            hipLaunchKernelGGL(gram_f64_kernel, dim3(njobs), dim3(256), 0, st, (const double4*)x4, (const double*)P,
-                               n, (const double4*)ctrl4, m, s, p.nt, p.npairs, p.slice_len, gpart);
+            hipLaunchKernelGGL(gram_f64acc_kernel<double>, dim3(njobs), dim3(256), 0, st, (const double4*)x4,
+                               (const double*)P, n, (const double4*)ctrl4, m, s, p.nt, p.npairs, p.slice_len, gpart);
         MVF_LAUNCH_CHECK();
     }
     if (stages & MVF_GRAM_STAGE_RHS) {

@@ -20,7 +20,7 @@ def _ptr(t):
 class HipKernels:
     """libmvf kernels bound to one GPU and one cell dtype ("float32" | "float64")."""
 
-    def __init__(self, device=None, dtype="float32"):
+    def __init__(self, device=None, dtype="float32", gram_mode=None):
         if not torch.cuda.is_available():
             raise RuntimeError(
                 "spateo_amd needs an AMD GPU (HIP device) - torch.cuda.is_available() is False and there is no "
@@ -38,6 +38,13 @@ class HipKernels:
         # optional per-launch timing of the dominant (Gram MFMA) kernel: list of (start, end) torch events recorded
         # on the launch stream; bench.py sets this to [] to enable it
         self.gram_events = None
+        if gram_mode is not None:
+            self.set_gram_mode(gram_mode)
+
+    def set_gram_mode(self, mode):
+        """"f64acc" (default: float32 operands, float64 MFMA accumulation) or "f32mfma" (fast, noisier G).  Process-wide."""
+        code = {"f64acc": _lib.GRAM_MODE_F64_ACC, "f32mfma": _lib.GRAM_MODE_F32_MFMA}[mode]
+        _lib.check(self.lib.mvf_set_gram_mode(code), "mvf_set_gram_mode")
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):

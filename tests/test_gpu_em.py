@@ -265,7 +265,8 @@ def test_large_n_properties_float32(st):
     assert float((R12 - R1 - R2).abs().max() / R12.abs().max()) < 1e-5  # linearity in Y
     Gh = G.cpu().numpy()
     assert np.array_equal(Gh, Gh.T)
-    assert np.linalg.eigvalsh(Gh).min() > -1e-9 * np.abs(Gh).max()
+    ev = np.linalg.eigvalsh(Gh)
+    assert ev.min() > -1e-12 * ev.max()  # float64-accumulated Gram: PSD up to round-off
     # Gram from a materialised float32 con_K on a row sample == recompute path restricted to that sample
     sel = np.sort(rng.choice(len(X), 20000, replace=False))
     xs = torch.from_numpy((X[sel] - c).astype(np.float32)).to("cuda:0")
