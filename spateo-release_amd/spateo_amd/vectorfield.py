@@ -36,6 +36,11 @@ __all__ = [
 _DEFAULT_DTYPE = "float64"
 
 
+def _make_kernels(device, dtype):
+    """The one place that binds the HIP kernels (tests/ monkeypatch this seam to exercise the host logic on CPU)."""
+    return HipKernels(device, dtype)
+
+
 def set_default_dtype(dtype: str):
     """Cell dtype used when a call does not pass ``dtype=``: "float64" (parity mode) or "float32" (fast mode)."""
     global _DEFAULT_DTYPE
@@ -133,7 +138,7 @@ class SparseVFCEngine:
                 f"the HIP path supports 1-3 output dimensions, got Dy={self.Dy} (kernel_interpolation's wide Dy is a "
                 f"'next' row, SURVEY.md 8f)"
             )
-        self.k = kernels if kernels is not None else HipKernels(device, dtype)
+        self.k = kernels if kernels is not None else _make_kernels(device, dtype)
         self.distributed = bool(distributed)
         self.group = group
         self.rank, self.world = _dist_info(distributed, group)
@@ -297,7 +302,7 @@ def con_K(x, y, beta: float = 0.1, method: str = "cdist", return_d: bool = False
     y = np.asarray(y, dtype=np.float64)
     if x.ndim == 1:
         x = x[None, :]
-    k = HipKernels(device, dtype)
+    k = _make_kernels(device, dtype)
     npdt = np.float32 if dtype == "float32" else np.float64
     # translation invariance: centre before a possible cast to float32
     c = y.mean(0) if len(y) else np.zeros(x.shape[1])
@@ -326,7 +331,7 @@ def _field_on_device(x, vf_dict, flags, dtype=None, device=None):
         raise ValueError(f"query points have {x.shape[1]} dimensions, the vector field has {d}")
     if d > 3 or Cc.shape[1] > 3:
         raise NotImplementedError("the HIP evaluators support up to 3 dimensions")
-    k = HipKernels(device, dtype)
+    k = _make_kernels(device, dtype)
     center = Xc.mean(0)
     x4 = k.to_x4(x, center)
     c4 = k.to_x4(Xc, center)

@@ -1,0 +1,134 @@
+"""TEST DOUBLE (never imported by the product): the ``HipKernels`` interface implemented on CPU tensors with the
+float64 NumPy oracle, so that the HOST logic of the product - the EM driver, the restart loop, the AnnData wrappers,
+the sharding / all-reduce protocol - can be exercised by the ``-m "not gpu"`` suite and by world_size-2 ``gloo`` runs.
+
+It is the checker standing in for the device; it is not a fallback: the product constructs only ``HipKernels``
+(``spateo_amd.vectorfield._make_kernels``) and fails loudly without a GPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg
+import torch
+
+from oracle import dg_oracle as dgo
+from oracle import sparsevfc_oracle as svo
+
+EVAL_V, EVAL_JAC, EVAL_DIV, EVAL_CURL, EVAL_ACC, EVAL_CURV, EVAL_TORS, EVAL_JDET = 1, 2, 4, 8, 16, 32, 64, 128
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+class CpuKernels:
+    def __init__(self, device=None, dtype="float64", gram_mode=None):
+        self.device = torch.device("cpu")
+        self.dtype_name = "float64"
+        self.tdtype = torch.float64
+        self.gram_events = None
+
+    # ---- helpers
+    def to_x4(self, arr, center=None):
+        a = np.asarray(arr, dtype=np.float64)
+        if center is not None:
+            a = a - np.asarray(center, dtype=np.float64)[None, : a.shape[1]]
+        buf = np.zeros((a.shape[0], 4))
+        buf[:, : a.shape[1]] = a
+        return torch.from_numpy(buf)
+
+    def empty(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.tdtype)
+
+    def zeros(self, *shape, dtype=None):
+        return torch.zeros(*shape, dtype=dtype or self.tdtype)
+
+    # ---- kernels
+    def con_k(self, x, y, beta, return_d=False, dtype=None):
+        xn, yn = _np(x).astype(np.float64), _np(y).astype(np.float64)
+        if return_d:
+            K, D = svo.con_K(xn, yn, beta, return_d=True)
+            return torch.from_numpy(np.atleast_2d(K)), torch.from_numpy(D)
+        K = svo.con_K(xn, yn, beta)
+        return torch.from_numpy(K.reshape(len(xn), len(yn)))
+
+    def apply(self, x4, ctrl4, beta, C, y4=None, P=None, stats=None):
+        X, ctrl = _np(x4)[:, :3], _np(ctrl4)[:, :3]
+        n, m = len(X), len(ctrl)
+        V = np.zeros((n, 4))
+        if m:
+            V[:, :3] = svo.con_K(X, ctrl, beta).reshape(n, m) @ _np(C)
+        r = None
+        if y4 is not None:
+            rr = np.sum((_np(y4)[:, :3] - V[:, :3]) ** 2, 1)
+            r = torch.from_numpy(rr)
+            if P is not None:
+                stats[0] += float(_np(P) @ rr)
+        return torch.from_numpy(V), r
+
+    def estep_min(self, r, sigma2):
+        t1 = np.exp(-_np(r) / (2 * sigma2))
+        nz = t1[t1 != 0]
+        return torch.tensor([nz.min() if len(nz) else np.inf, float((t1 == 0).sum())], dtype=torch.float64)
+
+    def estep_p(self, r, sigma2, gamma, a, dy, minP, theta, zero_fill, P_out, stats):
+        rr = _np(r)
+        t1 = np.exp(-rr / (2 * sigma2))
+        t1[t1 == 0] = zero_fill
+        t2 = (2 * np.pi * sigma2) ** (dy / 2) * (1 - gamma) / (gamma * a)
+        p = t1 / (t1 + t2)
+        pf = np.maximum(p, minP)
+        P_out.copy_(torch.from_numpy(pf))
+        stats += torch.tensor([p @ rr, p.sum(), pf.sum(), float((pf > theta).sum())], dtype=torch.float64)
+
+    def gram(self, x4, P, y4, ctrl4, beta, G, R):
+        X, ctrl = _np(x4)[:, :3], _np(ctrl4)[:, :3]
+        U = svo.con_K(X, ctrl, beta).reshape(len(X), len(ctrl))
+        UP = U.T * _np(P)[None, :]
+        G.copy_(torch.from_numpy(UP @ U))
+        R.copy_(torch.from_numpy(UP @ _np(y4)[:, :3]))
+
+    def solve(self, G, K, lambda_sigma2, jitter, R, C_out, info):
+        A = _np(G) + lambda_sigma2 * _np(K)
+        A = A + jitter * np.trace(A) / len(A) * np.eye(len(A))
+        try:
+            c = scipy.linalg.cho_solve(scipy.linalg.cho_factor(A, lower=True), _np(R))
+            info.zero_()
+            C_out.copy_(torch.from_numpy(c))
+        except np.linalg.LinAlgError:
+            info.fill_(1)
+
+    def quadform(self, K, C, out):
+        c = _np(C)
+        out[0] = float(np.trace(c.T @ _np(K) @ c))
+
+    def eval(self, x4, ctrl4, beta, C, flags):
+        X, ctrl, Cn = _np(x4)[:, :3], _np(ctrl4)[:, :3], _np(C)
+        vfd = {"X_ctrl": ctrl, "C": Cn, "beta": beta}
+        n = len(X)
+        out = {}
+        v = svo.con_K(X, ctrl, beta).reshape(n, len(ctrl)) @ Cn
+        J = dgo.Jacobian_rkhs_gaussian(X, vfd, vectorize=True)
+        a = np.einsum("fin,ni->nf", J, v)
+        if flags & EVAL_V:
+            out[EVAL_V] = v
+        if flags & EVAL_JAC:
+            out[EVAL_JAC] = J
+        if flags & EVAL_DIV:
+            out[EVAL_DIV] = np.trace(J)
+        if flags & EVAL_JDET:
+            out[EVAL_JDET] = np.linalg.det(np.moveaxis(J, 2, 0))
+        if flags & EVAL_CURL:
+            out[EVAL_CURL] = np.stack([J[2, 1] - J[1, 2], J[0, 2] - J[2, 0], J[1, 0] - J[0, 1]], axis=1)
+        if flags & EVAL_ACC:
+            out[EVAL_ACC] = a
+        if flags & EVAL_CURV:
+            vv = np.sum(v * v, 1)
+            va = np.sum(v * a, 1)
+            out[EVAL_CURV] = (a * vv[:, None] - v * va[:, None]) / (np.sqrt(vv) ** 4)[:, None]
+        if flags & EVAL_TORS:
+            Ja = np.einsum("fin,ni->nf", J, a)
+            aJa = np.sum(a * Ja, 1)
+            den = np.sum(v * v, 1) * np.sum(a * a, 1)
+            out[EVAL_TORS] = v * (aJa / den)[:, None]
+        return {k: torch.from_numpy(np.ascontiguousarray(val)) for k, val in out.items()}

@@ -1,0 +1,256 @@
+"""CPU tests of the product's HOST logic with the device replaced by the oracle-backed test double
+(tests/_cpu_kernels.py): preprocessing, the EM driver (energy, tecr, gamma, stopping rule, jitter escalation), the
+restart loop and the AnnData wrappers against the goldens produced by the REAL reference wrappers, sharding."""
+import numpy as np
+import pytest
+
+import spateo_amd as st
+from spateo_amd import vectorfield as vfm
+from oracle import sparsevfc_oracle as svo
+
+from _cpu_kernels import CpuKernels
+
+
+@pytest.fixture
+def cpu_kernels(monkeypatch):
+    monkeypatch.setattr(vfm, "_make_kernels", lambda device, dtype: CpuKernels(device, dtype))
+    return CpuKernels()
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(b).max())
+
+
+def _data(n=600, seed=0):
+    from spateo_amd._synthetic import make_config
+
+    X, V, _ = make_config("C2", N=n)
+    return X, V
+
+
+# ------------------------------------------------------------------------------------------------ preprocessing
+@pytest.mark.parametrize("vbs", [True, False])
+def test_preprocess_matches_oracle_bit_for_bit(vbs):
+    X, V = _data(800)
+    V[3] = np.nan
+    X[20] = X[21]
+    got = vfm.sparsevfc_preprocess(X, V, M=60, seed=7, velocity_based_sampling=vbs)
+    ref = svo.sparsevfc_setup(X, V, M=60, seed=7, velocity_based_sampling=vbs)
+    for g, r in zip(got, ref):
+        np.testing.assert_array_equal(g, r) if isinstance(r, np.ndarray) else None
+    assert got[5] == pytest.approx(ref[5], rel=1e-13)  # beta: cKDTree vs sklearn kd-tree, both exact kNN
+
+
+def test_preprocess_clips_M_to_unique_rows_and_rejects_all_nan():
+    X = np.repeat(np.arange(12.0).reshape(4, 3), 3, axis=0)
+    Y = np.ones_like(X)
+    valid, Xv, Yv, idx, ctrl, beta = vfm.sparsevfc_preprocess(X, Y, M=10, beta=0.5)
+    assert ctrl.shape == (4, 3) and beta == 0.5
+    with pytest.raises(ValueError, match="no row of Y is finite"):
+        vfm.sparsevfc_preprocess(X, np.full_like(Y, np.nan), M=3)
+
+
+def test_shard_bounds_partition():
+    for n, w in [(10, 3), (7, 8), (8_000_000, 8), (5, 1)]:
+        b = [vfm.shard_bounds(n, r, w) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n
+        assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+
+
+# ------------------------------------------------------------------------------------------------ EM driver
+def test_em_driver_reproduces_oracle_sparsevfc(cpu_kernels):
+    X, V = _data(700)
+    Grid = X[::25] + 0.5
+    kw = dict(M=40, lambda_=3.0, lstsq_method="scipy", MaxIter=40, seed=0)
+    ref = svo.SparseVFC(X, V, Grid, **kw)
+    got = st.SparseVFC(X, V, Grid, _kernels=cpu_kernels, **kw)
+    assert set(got) == set(ref)
+    assert got["iteration"] == ref["iteration"] and len(got["E_traj"]) == got["iteration"] + 1
+    np.testing.assert_array_equal(got["ctrl_idx"], ref["ctrl_idx"])
+    np.testing.assert_array_equal(got["valid_ind"], ref["valid_ind"])
+    assert _rel(got["V"], ref["V"]) < 1e-8 and _rel(got["grid_V"], ref["grid_V"]) < 1e-8
+    np.testing.assert_allclose(got["E_traj"], ref["E_traj"], rtol=1e-8)
+    np.testing.assert_allclose(got["tecr_traj"], ref["tecr_traj"], rtol=1e-4, atol=1e-10)
+    np.testing.assert_allclose(got["sigma2"], ref["sigma2"], rtol=1e-8)
+    np.testing.assert_allclose(got["P"], ref["P"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_array_equal(got["VFCIndex"], ref["VFCIndex"])
+    assert got["P"].shape == (700, 1) and got["C"].shape == (40, 3)
+
+
+def test_em_driver_stops_like_the_reference(cpu_kernels):
+    X, V = _data(300)
+    for kw in (dict(MaxIter=3), dict(MaxIter=50, ecr=1e-2), dict(MaxIter=1)):
+        full = dict(M=20, lambda_=3.0, lstsq_method="scipy", seed=0, **kw)
+        ref = svo.SparseVFC(X, V, None, **full)
+        got = st.SparseVFC(X, V, None, _kernels=cpu_kernels, **full)
+        assert got["iteration"] == ref["iteration"], kw
+        assert got["grid_V"] is None and got["grid"] is None
+
+
+def test_jitter_escalates_only_on_failed_pivots(cpu_kernels):
+    from spateo_amd.vectorfield import SparseVFCEngine
+
+    X, V = _data(400)
+    valid, Xv, Yv, idx, ctrl, beta = vfm.sparsevfc_preprocess(X, V, M=30, seed=0)
+    eng = SparseVFCEngine(Xv, Yv, ctrl, beta, kernels=cpu_kernels)
+    eng.init_state()
+    eng.em_step(lambda_=3.0)
+    assert eng.jitter == 0.0 and eng.solve_retries == 0  # well conditioned: solved without regularisation
+
+    class FailTwice(CpuKernels):
+        calls = 0
+
+        def solve(self, G, K, ls2, jitter, R, C_out, info):
+            FailTwice.calls += 1
+            if FailTwice.calls <= 2:
+                info.fill_(5)
+                return
+            super().solve(G, K, ls2, jitter, R, C_out, info)
+
+    eng2 = SparseVFCEngine(Xv, Yv, ctrl, beta, kernels=FailTwice())
+    eng2.init_state()
+    eng2.em_step(lambda_=3.0)
+    assert eng2.solve_retries == 2 and eng2.jitter == pytest.approx(1e-14)  # 0 -> 1e-15 -> 1e-14, then sticky
+    eng2.em_step(lambda_=3.0)
+    assert eng2.jitter == pytest.approx(1e-14)
+
+    class AlwaysFail(CpuKernels):
+        def solve(self, G, K, ls2, jitter, R, C_out, info):
+            info.fill_(1)
+
+    eng3 = SparseVFCEngine(Xv, Yv, ctrl, beta, kernels=AlwaysFail())
+    eng3.init_state()
+    with pytest.raises(RuntimeError, match="non-positive pivot"):
+        eng3.em_step(lambda_=3.0)
+
+
+def test_engine_rejects_unsupported_shapes(cpu_kernels):
+    from spateo_amd.vectorfield import SparseVFCEngine
+
+    X = np.zeros((10, 4))
+    with pytest.raises(NotImplementedError, match="spatial dimensions"):
+        SparseVFCEngine(X, X[:, :3], X[:3], 0.1, kernels=cpu_kernels)
+    with pytest.raises(NotImplementedError, match="kernel_interpolation"):
+        SparseVFCEngine(X[:, :3], np.zeros((10, 7)), X[:3, :3], 0.1, kernels=cpu_kernels)
+    with pytest.raises(ValueError):
+        SparseVFCEngine(X[:, :3], X[:5, :3], X[:3, :3], 0.1, kernels=cpu_kernels)
+    with pytest.raises(NotImplementedError):
+        st.SparseVFC(X[:, :3], X[:, :3], None, div_cur_free_kernels=True)
+
+
+# ------------------------------------------------------------------------------------------------ wrappers vs goldens
+def test_get_X_Y_grid_matches_reference(golden):
+    g = golden
+    X, Y, Grid, in_hull = st.tdr.get_X_Y_grid(X=g["grid_X"].copy(), Y=g["grid_X"].copy(), grid_num=[4, 5, 6])
+    np.testing.assert_array_equal(Grid, g["grid_Grid"])
+    np.testing.assert_array_equal(in_hull, g["grid_in_hull"])
+    assert Grid.shape == (120, 3)
+
+
+def test_restart_loop_matches_reference_wrapper(golden, cpu_kernels):
+    g = golden
+    res = st.tdr._morphofield_sparsevfc(
+        g["w_X"][:300], g["w_V"][:300], NX=None, grid_num=[5, 4, 3], M=30, lambda_=0.02, lstsq_method="scipy",
+        min_vel_corr=0.5, restart_num=3, restart_seed=[0, 100, 200], MaxIter=30, _kernels=cpu_kernels)
+    assert res["method"] == "sparsevfc"
+    for k in ["valid_ind", "X_ctrl", "ctrl_idx", "grid", "VFCIndex"]:
+        np.testing.assert_array_equal(res[k], g[f"w1_{k}"])
+    assert res["iteration"] == int(g["w1_iteration"])
+    assert _rel(res["V"], g["w1_V"]) < 1e-8 and _rel(res["grid_V"], g["w1_grid_V"]) < 1e-8
+    np.testing.assert_allclose(res["E_traj"], g["w1_E_traj"], rtol=1e-8)
+    # forced restarts + default seed-length quirk (5 seeds for restart_num=2 -> seeds become arange(2)*100)
+    Xf, Vf = g["w_X"][300:], g["w_V"][300:]
+    res2 = st.tdr._morphofield_sparsevfc(Xf, Vf, NX=Xf[:10], M=12, min_vel_corr=2.0, restart_num=2,
+                                         restart_seed=(0, 100, 200, 300, 400), MaxIter=8, _kernels=cpu_kernels)
+    np.testing.assert_array_equal(res2["X_ctrl"], g["w2_X_ctrl"])
+    assert res2["iteration"] == int(g["w2_iteration"])
+    assert _rel(res2["V"], g["w2_V"]) < 1e-8 and _rel(res2["grid_V"], g["w2_grid_V"]) < 1e-8
+    # restart_num = 0 -> a single fit, no acceptance test
+    res3 = st.tdr._morphofield_sparsevfc(Xf, Vf, NX=Xf[:10], M=12, restart_num=0, MaxIter=8, _kernels=cpu_kernels)
+    assert _rel(res3["V"], g["w2_V"]) < 1e-8
+
+
+def test_non_finite_row_reproduces_reference_indexerror(cpu_kernels):
+    """The reference wrapper indexes the N_valid-row V with valid_ind (sparsevfc.py:201-204): IndexError unless the
+    non-finite rows are the last ones.  Observable reference behaviour, kept."""
+    X, V = _data(120)
+    V[7, 1] = np.nan
+    with pytest.raises(IndexError):
+        st.tdr._morphofield_sparsevfc(X, V, NX=X[:5], M=10, MaxIter=3, restart_num=1, restart_seed=[0],
+                                      _kernels=cpu_kernels)
+
+
+def test_anndata_wrappers_match_reference_wrappers(golden, cpu_kernels):
+    g = golden
+    ad = st.AnnDataLite(obsm={"align_spatial": g["a_X"], "V_mapping": g["a_V"]})
+    ad2 = st.tdr.morphofield_sparsevfc(ad, NX=g["a_X"][:5], M=15, MaxIter=20, restart_num=1, restart_seed=[0],
+                                       inplace=False)
+    assert "VecFld_morpho" not in ad.uns and ad2 is not ad  # inplace=False works on a copy
+    assert st.tdr.morphofield_sparsevfc(ad, NX=g["a_X"][:5], M=15, MaxIter=20, restart_num=1, restart_seed=[0]) is None
+    vf = ad.uns["VecFld_morpho"]
+    for k in ["X_ctrl", "C", "beta", "V", "grid_V"]:
+        assert _rel(vf[k], g[f"a_vf_{k}"]) < 1e-7, k
+    assert vf["method"] == "sparsevfc" and vf["X"].dtype == np.float64
+    for fn in (st.tdr.morphofield_velocity, st.tdr.morphofield_acceleration, st.tdr.morphofield_curvature,
+               st.tdr.morphofield_curl, st.tdr.morphofield_torsion, st.tdr.morphofield_divergence,
+               st.tdr.morphofield_jacobian):
+        assert fn(ad) is None
+    tol = 1e-6
+    assert _rel(ad.obsm["velocity"], g["a_velocity"]) < tol
+    assert _rel(ad.obs["acceleration"], g["a_acceleration_obs"]) < tol
+    assert _rel(ad.obsm["acceleration"], g["a_acceleration_obsm"]) < tol
+    assert _rel(ad.obs["curvature"], g["a_curvature_obs"]) < tol
+    assert _rel(ad.obsm["curvature"], g["a_curvature_obsm"]) < tol
+    assert ad.obsm["curl"].shape == (len(g["a_X"]), 3, 3)
+    assert _rel(ad.obs["curl"], g["a_curl_obs"]) < tol and _rel(ad.obsm["curl"], g["a_curl_obsm"]) < tol
+    assert _rel(ad.obs["torsion"], g["a_torsion_obs"]) < 1e-4 and _rel(ad.uns["torsion"], g["a_torsion_uns"]) < 1e-4
+    assert _rel(ad.obs["divergence"], g["a_divergence_obs"]) < tol
+    assert ad.uns["jacobian"].shape == (3, 3, len(g["a_X"]))
+    assert _rel(ad.uns["jacobian"], g["a_jacobian_uns"]) < tol
+    assert _rel(ad.obs["jacobian"], g["a_jacobian_obs"]) < 1e-4
+    # custom keys + inplace=False on an evaluator
+    ad3 = st.tdr.morphofield_divergence(ad, key_added="div2", inplace=False)
+    assert "div2" in ad3.obs and "div2" not in ad.obs
+
+
+def test_wrapper_error_conventions():
+    ad = st.AnnDataLite(obsm={"align_spatial": np.zeros((3, 3))})
+    ad.uns["bad"] = {"method": "nope"}
+    ad.uns["gp"] = {"method": "gaussian_process"}
+    with pytest.raises(Exception, match="is not in ``anndata.uns"):
+        st.tdr.morphofield_velocity(ad, vf_key="bad")
+    with pytest.raises(NotImplementedError):
+        st.tdr.morphofield_velocity(ad, vf_key="gp")
+    with pytest.raises(KeyError):
+        st.tdr.morphofield_jacobian(ad, vf_key="absent")
+
+
+def test_svcvectorfield_shapes_and_errors(cpu_kernels):
+    rng = np.random.default_rng(0)
+    vfd = {"X_ctrl": rng.standard_normal((8, 3)), "C": rng.standard_normal((8, 3)), "beta": 0.3,
+           "X": rng.standard_normal((5, 3)), "Y": rng.standard_normal((5, 3))}
+    ad = st.AnnDataLite(obsm={"s": vfd["X"]}, uns={"VecFld_morpho": vfd})
+    vf = st.SvcVectorField().from_adata(ad, basis=None, vf_key="VecFld_morpho")
+    X, V = vf.get_data()
+    assert X is vfd["X"] and V is vfd["Y"]
+    assert vf.func(X).shape == (5, 3) and vf.func(X[0]).shape == (3,)
+    assert vf.get_Jacobian()(X).shape == (3, 3, 5) and vf.get_Jacobian()(X[0]).shape == (3, 3)
+    with pytest.raises(NotImplementedError):
+        vf.get_Jacobian(method="numerical")
+    with pytest.raises(ValueError):
+        st.SvcVectorField().from_adata(ad, vf_key="missing")
+    with pytest.raises(ValueError, match="dimensions"):
+        vf.func(np.zeros((2, 2)))
+    # basis suffix
+    ad.uns["VecFld_pca"] = vfd
+    assert st.SvcVectorField().from_adata(ad, basis="pca", vf_key="VecFld").vf_dict is vfd
+
+
+def test_anndata_lite_copy_is_deep():
+    ad = st.AnnDataLite(obsm={"a": np.zeros((4, 3))}, obs={"x": [1, 2, 3, 4]})
+    assert ad.n_obs == 4 and isinstance(ad.obs["x"], np.ndarray)
+    c = ad.copy()
+    c.obsm["a"][0, 0] = 5
+    c.uns["k"] = 1
+    assert ad.obsm["a"][0, 0] == 0 and "k" not in ad.uns
