@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--gram-mode", default="f64acc", choices=["f64acc", "f32mfma"],
                     help="float32 Gram kernel: f64acc = float32 operands + float64 MFMA accumulation (default, meets "
                          "the 1e-3 field tolerance); f32mfma = all-float32 MFMA (2x peak, noisier)")
+    ap.add_argument("--cache-u", default="auto", choices=["auto", "on", "off"],
+                    help="materialise the float32 kernel values once (96 GB at 8M x 3000) and stream them in the Gram "
+                         "kernel instead of regenerating them every EM iteration")
     ap.add_argument("--no-conk", action="store_true", help="skip the con_K bandwidth run")
     args = ap.parse_args()
 
@@ -131,8 +134,11 @@ def main():
         log(f"[bench] generated + preprocessed N={N} M={len(ctrl)} beta={beta:.4g} in {time.perf_counter() - t0:.1f}s; "
             f"rank shard = {hi - lo} cells")
     kern = HipKernels(device, args.dtype, gram_mode=args.gram_mode)
+    cache_u = {"auto": "auto", "on": True, "off": False}[args.cache_u]
+    if args.gram_mode == "f32mfma":
+        cache_u = False
     eng = SparseVFCEngine(Xv[lo:hi], Yv[lo:hi], ctrl, beta, dtype=args.dtype, device=device, distributed=distributed,
-                          n_total=N, kernels=kern)
+                          n_total=N, kernels=kern, cache_u=cache_u)
     del X, V
     eng.init_state(gamma=0.9)
     step_kw = dict(a=5.0, lambda_=args.lambda_, minP=1e-5, theta=0.75)
@@ -171,7 +177,8 @@ def main():
     peak = PEAK_F32_MFMA_TFLOPS if f32mfma else PEAK_F64_MFMA_TFLOPS
     roofline = {
         "kernel": "gram_f32_kernel (v_mfma_f32_32x32x2_f32)" if f32mfma else
-                  f"gram_f64acc_kernel<{'float' if args.dtype == 'float32' else 'double'}> (v_mfma_f64_16x16x4_f64)",
+                  ("gram_cached_kernel (v_mfma_f64_16x16x4_f64, float32 U streamed from HBM)" if eng.cached_u else
+                   f"gram_f64acc_kernel<{'float' if args.dtype == 'float32' else 'double'}> (v_mfma_f64_16x16x4_f64)"),
         "bound": "mfma",
         "achieved": achieved,
         "peak": peak,
@@ -207,12 +214,14 @@ def main():
             "solve_jitter": eng.jitter,
             "solve_retries": eng.solve_retries,
             "gram_mode": args.gram_mode,
+            "cached_u": bool(eng.cached_u),
         },
         "roofline": roofline,
     }
 
     # ---------------------------------------------------------------- con_K HBM bandwidth (N = 1, rank 0)
     if rank == 0 and world == 1 and not args.no_conk:
+        kern.drop_ublk()
         del eng
         torch.cuda.empty_cache()
         nk, mk = 2_000_000, 2000  # BASELINE config 3: con_K roofline run (16 GB of float32 output)

@@ -38,14 +38,48 @@ struct GramPlan {
 constexpr int RHS_CPT = 2;                  // control points per lane in the rhs kernel
 constexpr int RHS_COLS = 256 * RHS_CPT;     // control points per rhs workgroup
 
+// Resident workgroup slots of the Gram kernels: 2 workgroups (8 waves) per CU (register-limited), 256 CUs.
+static int gram_slots() {
+    static int slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                cus = prop.multiProcessorCount;
+        }
+        (void)hipGetLastError();
+        slots = 2 * cus;
+    }
+    return slots;
+}
+
 static GramPlan make_plan(int64_t n, int64_t m) {
     GramPlan p;
     p.nt = (int)cdiv(m, GT);
     p.npairs = p.nt * (p.nt + 1) / 2;
-    const int64_t target_jobs = 2048;
-    int64_t want_slices = std::max<int64_t>(1, cdiv(target_jobs, std::max(1, p.npairs)));
-    int64_t sl = cdiv(cdiv(n, want_slices), GCHUNK) * GCHUNK;
-    sl = std::min<int64_t>(std::max<int64_t>(sl, GCHUNK), 262144);
+    // Jobs = tile pairs x cell slices.  All jobs cost the same, so the launch runs in ceil(jobs / slots) rounds: pick
+    // the slice count (within a memory budget of ~1.5 GB of float64 partial tiles) that wastes the least of the
+    // last round.  (At 1 M cells x 300 pairs the naive 4 slices = 1200 jobs on 512 slots lost 22 % to the tail.)
+    const int64_t max_chunks = cdiv(n, GCHUNK);
+    const int64_t budget_jobs = std::max<int64_t>(p.npairs, (int64_t)(1.5e9 / (GT * GT * sizeof(double))));
+    const int64_t s_max = std::max<int64_t>(1, std::min<int64_t>(max_chunks, budget_jobs / p.npairs));
+    const int64_t s_min = std::max<int64_t>(1, std::min<int64_t>(s_max, cdiv(4 * (int64_t)gram_slots(), p.npairs)));
+    const double slots = (double)gram_slots();
+    int64_t best_s = s_max;
+    double best_eff = -1.0;
+    for (int64_t s = s_min; s <= s_max; ++s) {
+        const int64_t sl = cdiv(cdiv(n, s), GCHUNK) * GCHUNK;
+        const int64_t ns = cdiv(n, sl);
+        const double jobs = (double)ns * p.npairs;
+        const double eff = (jobs / slots) / std::ceil(jobs / slots) * ((double)n / ((double)ns * sl));
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best_s = ns;
+        }
+    }
+    int64_t sl = cdiv(cdiv(n, best_s), GCHUNK) * GCHUNK;
+    if (const char* e = getenv("MVF_SLICE_LEN")) sl = std::max<int64_t>(GCHUNK, atoll(e) / GCHUNK * GCHUNK);  // probes
     p.slice_len = sl;
     p.nslices = std::max<int64_t>(1, cdiv(n, sl));
     p.gram_bytes = (size_t)p.nslices * p.npairs * GT * GT * sizeof(double);
@@ -281,6 +315,167 @@ __global__ __launch_bounds__(256, 1) void gram_f64acc_kernel(const typename Vec4
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// Cached-U variant (float32 mode).  U = con_K(x, ctrl) does not change across EM iterations - only P does - so when
+// HBM has room (4 n M bytes: 96 GB at 8 M x 3000) the float32 kernel values are materialised ONCE per fit, in the
+// blocked layout  Ublk[cb][cell][16]  (cb = control point / 16), which is exactly the v_mfma_f64_16x16x4 operand
+// shape: for one MFMA block and one k-step the 64 lanes read 4 cells x 16 control points = 256 contiguous bytes.
+// Measured motivation (tools/mfma_peak2.hip): VALU work is NOT hidden behind f64 MFMAs on gfx950 - a pure f64 MFMA
+// stream runs 77.8 TF, the same stream with 8 VALU ops per MFMA 59.4 TF - so the exp/convert work per operand of the
+// recompute kernel is additive.  Here the loop holds only 9 coalesced dword loads, 8 converts and 4 f64 multiplies
+// per 16 MFMAs; the values are bit-identical to kernel_value() in every other kernel.
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int UB = 16;  // control points per cached block
+
+__global__ __launch_bounds__(256) void ublk_build_kernel(const float4* __restrict__ x4, int64_t n, int64_t n_pad,
+                                                         const float4* __restrict__ ctrl4, int64_t m, int64_t m_pad,
+                                                         float s, int cb_per_block, float* __restrict__ ublk) {
+    extern __shared__ __attribute__((aligned(16))) float4 sctrl[];  // cb_per_block * 16 scaled control points
+    const int64_t cb0 = (int64_t)blockIdx.y * cb_per_block;
+    const int ncb = (int)min((int64_t)cb_per_block, m_pad / UB - cb0);
+    for (int j = threadIdx.x; j < ncb * UB; j += 256) {
+        const int64_t c = cb0 * UB + j;
+        if (c < m) {
+            const float4 cv = ctrl4[c];
+            sctrl[j] = float4{cv.x * s, cv.y * s, cv.z * s, 1.f};
+        } else {
+            sctrl[j] = float4{0.f, 0.f, 0.f, 0.f};  // w = 0 marks a padded control point
+        }
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pad) return;
+    const bool live = i < n;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (live) {
+        const float4 xv = x4[i];
+        px = xv.x * s, py = xv.y * s, pz = xv.z * s;
+    }
+    for (int b = 0; b < ncb; ++b) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 o[4];
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+            const float4 cv = sctrl[b * UB + j];
+            const float k = kernel_value(px, py, pz, cv.x, cv.y, cv.z);
+            o[j >> 2][j & 3] = (live && cv.w != 0.f) ? k : 0.f;
+        }
+        f4* dst = reinterpret_cast<f4*>(ublk + ((cb0 + b) * n_pad + i) * UB);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) __builtin_nontemporal_store(o[q], dst + q);
+    }
+}
+
+#ifndef MVF_UG
+#define MVF_UG 2
+#endif
+constexpr int UG = MVF_UG;  // k-steps (of 4 cells) per software-pipeline group
+
+#ifndef MVF_CACHED_WPS
+#define MVF_CACHED_WPS 2
+#endif
+__global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const float* __restrict__ ublk, const float* __restrict__ P,
+                                                             int64_t n, int64_t n_pad, int nt, int npairs,
+                                                             int64_t slice_len, double* __restrict__ partial) {
+    const int pair = blockIdx.x % npairs;
+    const int64_t slice = blockIdx.x / npairs;
+    int ti, tj;
+    decode_pair(pair, nt, ti, tj);
+    const int64_t n0 = slice * slice_len;
+    const int64_t n1 = min(n_pad, n0 + slice_len);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+
+    const float* pa[4];
+    const float* pb[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int64_t cba = ((int64_t)ti * GT + wi * 64) / UB + a;
+        const int64_t cbb = ((int64_t)tj * GT + wj * 64) / UB + a;
+        pa[a] = ublk + (cba * n_pad + n0 + lk) * UB + li;
+        pb[a] = ublk + (cbb * n_pad + n0 + lk) * UB + li;
+    }
+
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    float ua[2][UG][4], ub[2][UG][4], pp[2][UG];
+    const int ngroups = (int)((n1 - n0) / (4 * UG));  // slices are multiples of 256 cells: ngroups is even
+
+    auto load_group = [&](int g, float(&A)[UG][4], float(&B)[UG][4], float(&Pq)[UG]) {
+#pragma unroll
+        for (int q = 0; q < UG; ++q) {
+            const int64_t off = ((int64_t)g * UG + q) * (4 * UB);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#ifdef MVF_PROBE_NO_LOAD
+                A[q][a] = 0.5f + (float)lane * 1e-3f + (float)off * 1e-9f;
+                B[q][a] = 0.25f + (float)lane * 1e-3f;
+#else
+                A[q][a] = pa[a][off];
+                B[q][a] = pb[a][off];
+#endif
+            }
+            const int64_t cell = n0 + ((int64_t)g * UG + q) * 4 + lk;
+#if defined(MVF_PROBE_NO_LOAD) || defined(MVF_PROBE_NO_P)
+            Pq[q] = 1.0f;
+#else
+            Pq[q] = cell < n ? P[cell] : 0.f;
+#endif
+        }
+    };
+    auto compute_group = [&](const float(&A)[UG][4], const float(&B)[UG][4], const float(&Pq)[UG]) {
+#pragma unroll
+        for (int q = 0; q < UG; ++q) {
+            double fa[4], fb[4];
+            const double pd = (double)Pq[q];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#ifdef MVF_PROBE_NO_P
+                fa[a] = (double)A[q][a];
+#else
+                fa[a] = (double)A[q][a] * pd;  // exact in float64
+#endif
+                fb[a] = (double)B[q][a];
+            }
+#ifdef MVF_PROBE_NO_MFMA
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a][a][0] += fa[a] + fb[a];
+#else
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+#endif
+        }
+    };
+
+    if (ngroups > 0) load_group(0, ua[0], ub[0], pp[0]);
+    for (int g = 0; g < ngroups; g += 2) {
+        if (g + 1 < ngroups) load_group(g + 1, ua[1], ub[1], pp[1]);
+        compute_group(ua[0], ub[0], pp[0]);
+        if (g + 2 < ngroups) load_group(g + 2, ua[0], ub[0], pp[0]);
+        if (g + 1 < ngroups) compute_group(ua[1], ub[1], pp[1]);
+    }
+
+    double* out = partial + ((size_t)slice * npairs + pair) * (size_t)(GT * GT);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wi * 64 + a * 16 + lk + 4 * r;
+                const int col = wj * 64 + b * 16 + li;
+                out[row * GT + col] = acc[a][b][r];
+            }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // rhs:  R[j, :] = sum_n K(x_n, c_j) P_n y_n   (VALU kernel; a lane owns RHS_CPT control points, cells broadcast
 // from LDS; float64 accumulation)
 // ----------------------------------------------------------------------------------------------------------------
@@ -456,6 +651,57 @@ extern "C" int mvf_gram_stages(int stages, const void* x4, const void* P, const 
         hipLaunchKernelGGL(rhs_reduce_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, rpart, p.rslices, m, R);
         MVF_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+static inline int64_t ublk_npad(int64_t n) { return cdiv(n, GCHUNK) * GCHUNK; }
+static inline int64_t ublk_mpad(int64_t m) { return cdiv(m, GT) * GT; }
+
+extern "C" size_t mvf_ublk_bytes(int64_t n, int64_t m) {
+    if (n <= 0 || m <= 0) return 0;
+    return (size_t)ublk_npad(n) * (size_t)ublk_mpad(m) * sizeof(float);
+}
+
+extern "C" int mvf_ublk_build(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, void* ublk,
+                              size_t ublk_bytes, void* stream) {
+    MVF_REQUIRE(n > 0 && m > 0, "mvf_ublk_build: need n > 0 and m > 0");
+    MVF_REQUIRE(beta >= 0.0 && std::isfinite(beta), "mvf_ublk_build: beta must be finite and >= 0");
+    MVF_REQUIRE(x4 && ctrl4 && ublk, "mvf_ublk_build: null pointer");
+    MVF_REQUIRE(ublk_bytes >= mvf_ublk_bytes(n, m), "mvf_ublk_build: buffer too small (%zu < %zu)", ublk_bytes,
+                mvf_ublk_bytes(n, m));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n_pad = ublk_npad(n), m_pad = ublk_mpad(m);
+    const int cb_per_block = 32;  // 512 control points (8 KiB of LDS) per workgroup column
+    dim3 grid((unsigned)(n_pad / 256), (unsigned)cdiv(m_pad / UB, cb_per_block));
+    MVF_REQUIRE(grid.y <= 65535, "mvf_ublk_build: m too large");
+    const float s = (float)std::sqrt(beta * LOG2E);
+    hipLaunchKernelGGL(ublk_build_kernel, grid, dim3(256), cb_per_block * UB * sizeof(float4), st, (const float4*)x4, n,
+                       n_pad, (const float4*)ctrl4, m, m_pad, s, cb_per_block, (float*)ublk);
+    MVF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mvf_gram_cached(int stages, const void* ublk, const void* x4, const void* P, const void* y4, int64_t n,
+                               const void* ctrl4, int64_t m, double beta, double* G, double* R, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    MVF_REQUIRE(n > 0 && m > 0, "mvf_gram_cached: need n > 0 and m > 0");
+    MVF_REQUIRE(stages > 0 && stages <= 7, "mvf_gram_cached: bad stage mask %d", stages);
+    MVF_REQUIRE(ublk && P && G && R, "mvf_gram_cached: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (stages & MVF_GRAM_STAGE_TILES) {
+        const GramPlan p = make_plan(n, m);
+        const size_t need = align_up(p.gram_bytes, 256) + align_up(p.rhs_bytes, 256);
+        MVF_REQUIRE(workspace && workspace_bytes >= need, "mvf_gram_cached: workspace too small (%zu < %zu)",
+                    workspace_bytes, need);
+        MVF_REQUIRE((int64_t)p.nslices * p.npairs < (1LL << 31), "mvf_gram_cached: too many jobs");
+        const unsigned njobs = (unsigned)(p.nslices * p.npairs);
+        hipLaunchKernelGGL(gram_cached_kernel, dim3(njobs), dim3(256), 0, st, (const float*)ublk, (const float*)P, n,
+                           ublk_npad(n), p.nt, p.npairs, p.slice_len, (double*)workspace);
+        MVF_LAUNCH_CHECK();
+    }
+    const int rest = stages & (MVF_GRAM_STAGE_RHS | MVF_GRAM_STAGE_REDUCE);
+    if (rest)
+        return mvf_gram_stages(rest, x4, P, y4, n, ctrl4, m, beta, G, R, workspace, workspace_bytes, MVF_F32, stream);
     return 0;
 }
 

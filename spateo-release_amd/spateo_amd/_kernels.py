@@ -38,6 +38,8 @@ class HipKernels:
         # optional per-launch timing of the dominant (Gram MFMA) kernel: list of (start, end) torch events recorded
         # on the launch stream; bench.py sets this to [] to enable it
         self.gram_events = None
+        self._ublk = None       # cached float32 kernel values (layout Ublk[m/16][n][16]) for the Gram kernel
+        self._ublk_key = None
         if gram_mode is not None:
             self.set_gram_mode(gram_mode)
 
@@ -106,6 +108,26 @@ class HipKernels:
                                         float(minP), float(theta), float(zero_fill), _ptr(P_out), _ptr(stats),
                                         self.cdtype, self._stream()), "mvf_estep_p")
 
+    def ublk_bytes(self, n, m):
+        return int(self.lib.mvf_ublk_bytes(n, m))
+
+    def build_ublk(self, x4, ctrl4, beta):
+        """Materialise the float32 kernel values once per fit (U is constant across EM iterations); later `gram`
+        calls with the same (x4, ctrl4, beta) stream them instead of regenerating them."""
+        if self.tdtype != torch.float32:
+            raise TypeError("the cached-U Gram path is float32 only")
+        n, m = x4.shape[0], ctrl4.shape[0]
+        need = self.ublk_bytes(n, m)
+        self._ublk = None
+        self._ublk = torch.empty(need // 4, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mvf_ublk_build(_ptr(x4), n, _ptr(ctrl4), m, float(beta), _ptr(self._ublk), need,
+                                           self._stream()), "mvf_ublk_build")
+        self._ublk_key = (x4.data_ptr(), ctrl4.data_ptr(), n, m, float(beta))
+
+    def drop_ublk(self):
+        self._ublk = None
+        self._ublk_key = None
+
     def gram(self, x4, P, y4, ctrl4, beta, G, R):
         n, m = x4.shape[0], ctrl4.shape[0]
         need = self.lib.mvf_gram_workspace_bytes(n, m, self.cdtype)
@@ -113,16 +135,23 @@ class HipKernels:
             self._gram_ws = None
             self._gram_ws = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
         args = (_ptr(x4), _ptr(P), _ptr(y4), n, _ptr(ctrl4), m, float(beta), _ptr(G), _ptr(R), _ptr(self._gram_ws),
-                self._gram_ws.numel(), self.cdtype, self._stream())
+                self._gram_ws.numel())
+        cached = self._ublk is not None and self._ublk_key == (x4.data_ptr(), ctrl4.data_ptr(), n, m, float(beta))
+        if cached:
+            def run(stages):
+                _lib.check(self.lib.mvf_gram_cached(stages, _ptr(self._ublk), *args, self._stream()), "mvf_gram_cached")
+        else:
+            def run(stages):
+                _lib.check(self.lib.mvf_gram_stages(stages, *args, self.cdtype, self._stream()), "mvf_gram_stages")
         if self.gram_events is None:
-            _lib.check(self.lib.mvf_gram(*args), "mvf_gram")
+            run(_lib.GRAM_TILES | _lib.GRAM_RHS | _lib.GRAM_REDUCE)
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _lib.check(self.lib.mvf_gram_stages(_lib.GRAM_TILES, *args), "mvf_gram_stages")
+        run(_lib.GRAM_TILES)
         e1.record()
         self.gram_events.append((e0, e1))
-        _lib.check(self.lib.mvf_gram_stages(_lib.GRAM_RHS | _lib.GRAM_REDUCE, *args), "mvf_gram_stages")
+        run(_lib.GRAM_RHS | _lib.GRAM_REDUCE)
 
     def solve(self, G, K, lambda_sigma2, jitter, R, C_out, info):
         m, nrhs = R.shape

@@ -123,7 +123,7 @@ class SparseVFCEngine:
     """
 
     def __init__(self, X, Y, ctrl, beta, *, dtype=None, device=None, distributed=False, group=None, n_total=None,
-                 kernels=None):
+                 kernels=None, cache_u="auto"):
         dtype = dtype or _DEFAULT_DTYPE
         X = np.asarray(X, dtype=np.float64)
         Y = np.asarray(Y, dtype=np.float64)
@@ -176,6 +176,15 @@ class SparseVFCEngine:
         self.r = None
         # Cholesky jitter (relative to the mean diagonal): start with none - then the solve equals the reference's
         # lstsq wherever the system has full numerical rank - and escalate only when a pivot fails (sticky afterwards)
+        # U = con_K(X, ctrl) is constant across EM iterations: cache its float32 values for the Gram kernel when HBM
+        # has room ("auto": needs 4 n M bytes plus headroom), else the Gram kernel regenerates them every iteration
+        self.cached_u = False
+        if dtype == "float32" and cache_u and hasattr(k, "build_ublk") and self.n_local and M:
+            need = k.ublk_bytes(self.n_local, M)
+            free = torch.cuda.mem_get_info(k.device)[0] if cache_u == "auto" else None
+            if free is None or need + (8 << 30) < free:
+                k.build_ublk(self.x4, self.ctrl4, self.beta)
+                self.cached_u = True
         self.jitter = 0.0
         self.jitter_first = 1e-15 if dtype == "float64" else 1e-12
         self.jitter_max = 1e-3

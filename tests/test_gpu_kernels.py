@@ -174,6 +174,32 @@ def test_gram_vs_oracle(st, dtype, tol, n, m):
     assert torch.equal(G, G2) and torch.equal(R, R2)
 
 
+@pytest.mark.parametrize("n,m", [(3000, 300), (700, 130), (5000, 40), (256, 128)])
+def test_gram_cached_u_is_bit_identical_to_recompute(st, n, m):
+    """The cached-U Gram kernel streams materialised float32 kernel values; they are the same kernel_value() bits the
+    recompute kernel generates, accumulated in the same order -> identical G and R."""
+    rng, X, ctrl = _cloud(n + m, n, m)
+    beta = 0.003
+    Y = rng.standard_normal((n, 3))
+    P = torch.from_numpy(rng.uniform(1e-5, 1.0, n).astype(np.float32)).to("cuda:0")
+    k = _k("float32")
+    center = ctrl.mean(0)
+    x4, c4, y4 = k.to_x4(X, center), k.to_x4(ctrl, center), k.to_x4(Y)
+    G0 = torch.empty(m, m, dtype=torch.float64, device="cuda:0")
+    R0 = torch.empty(m, 3, dtype=torch.float64, device="cuda:0")
+    k.gram(x4, P, y4, c4, beta, G0, R0)
+    k.build_ublk(x4, c4, beta)
+    G1, R1 = torch.empty_like(G0), torch.empty_like(R0)
+    k.gram(x4, P, y4, c4, beta, G1, R1)
+    assert k._ublk is not None
+    assert torch.equal(R0, R1)
+    assert torch.equal(G0, G1)
+    # and against the oracle
+    U = svo.con_K(X, ctrl, beta)
+    Gr = (U.T * P.double().cpu().numpy()[None, :]) @ U
+    assert _relmax(G1.cpu().numpy(), Gr) < 3e-6
+
+
 def test_gram_f32_mfma_fast_mode(st):
     """The optional all-float32 MFMA Gram kernel (mvf_set_gram_mode): 256-cell float32 chains folded into float64."""
     n, m = 4000, 260
