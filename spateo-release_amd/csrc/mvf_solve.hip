@@ -58,36 +58,34 @@ __global__ __launch_bounds__(256) void chol_prepare_kernel(const double* __restr
 }
 
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ W, int64_t mp, int k, int* __restrict__ info) {
+    // Right-looking Cholesky of one 64x64 block in LDS with ONE barrier per column: step j applies the rank-1 update
+    // a[i][c] -= a[i][j] a[c][j] / a[j][j] to the trailing lower triangle from the still UNSCALED column j (nobody
+    // writes column j during step j, and later steps never read it), and the columns are scaled once at the end.
     __shared__ double a[NB][NB + 1];
-    __shared__ double dsh;
     double* blk = W + ((int64_t)k * NB) * mp + (int64_t)k * NB;
     for (int e = threadIdx.x; e < NB * NB; e += 256) a[e / NB][e % NB] = blk[(int64_t)(e / NB) * mp + (e % NB)];
     __syncthreads();
-    for (int j = 0; j < NB; ++j) {
-        if (threadIdx.x == 0) {
-            double d = a[j][j];
-            if (!(d > 0.0)) {  // also catches NaN
-                atomicCAS(info, 0, 1 + k * NB + j);
-                d = 1.0;
-            }
-            dsh = sqrt(d);
-            a[j][j] = dsh;
+    for (int j = 0; j < NB - 1; ++j) {
+        double d = a[j][j];
+        if (!(d > 0.0)) {  // also catches NaN; keep going with a harmless pivot so the kernel chain completes
+            if (threadIdx.x == 0) atomicCAS(info, 0, 1 + k * NB + j);
+            d = 1.0;
         }
-        __syncthreads();
-        const double inv = 1.0 / dsh;
-        if (threadIdx.x > j && threadIdx.x < NB) a[threadIdx.x][j] *= inv;
-        __syncthreads();
-        // trailing update of the lower triangle: a[i][c] -= a[i][j] a[c][j],  j < c <= i < NB
+        const double inv = 1.0 / d;
         const int rem = NB - 1 - j;
         for (int e = threadIdx.x; e < rem * rem; e += 256) {
             const int i = j + 1 + e / rem, c = j + 1 + e % rem;
-            if (c <= i) a[i][c] -= a[i][j] * a[c][j];
+            if (c <= i) a[i][c] -= a[i][j] * a[c][j] * inv;
         }
         __syncthreads();
     }
+    if (threadIdx.x == 0 && !(a[NB - 1][NB - 1] > 0.0)) atomicCAS(info, 0, 1 + k * NB + NB - 1);
     for (int e = threadIdx.x; e < NB * NB; e += 256) {
         const int i = e / NB, c = e % NB;
-        blk[(int64_t)i * mp + c] = (c <= i) ? a[i][c] : 0.0;
+        double djj = a[c][c];
+        if (!(djj > 0.0)) djj = 1.0;
+        const double l = sqrt(djj);
+        blk[(int64_t)i * mp + c] = (c < i) ? a[i][c] / l : (c == i ? l : 0.0);
     }
 }
 
@@ -171,47 +169,54 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ W
             }
 }
 
-// back substitution for block column k:  C_k = L_kk^{-T} (Y_k - sum_{rows r >= (k+1) NB} L[r, kblock]^T C[r, :])
+// back substitution L^T C = Y, one launch per block column k (descending), k + 1 workgroups:
+//   every workgroup redundantly solves the 64 x 64 triangular system  L_kk^T C_k = Y_k  (Y_k is final: all later block
+//   columns have already been eliminated from it), then workgroup j < k eliminates C_k from block j,
+//   Y_j -= L[k-block rows, j-block cols]^T C_k, and workgroup k stores C_k.  Yw (mp x MAXR) is the working rhs.
 template <int MAXR>
-__global__ __launch_bounds__(256) void bsub_kernel(const double* __restrict__ W, int64_t mp, int k, int nrhs,
-                                                   double* __restrict__ Cp /* mp x nrhs */) {
-    __shared__ double part[4][NB][MAXR];
+__global__ __launch_bounds__(64) void bsub_step_kernel(const double* __restrict__ W, int64_t mp, int k, int nrhs,
+                                                       double* __restrict__ Yw, double* __restrict__ Cp) {
     __shared__ double L[NB][NB + 1];
     __shared__ double t[NB][MAXR];
-    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
-    double acc[MAXR];
-#pragma unroll
-    for (int d = 0; d < MAXR; ++d) acc[d] = 0.0;
-    for (int64_t r = (int64_t)(k + 1) * NB + q; r < mp; r += 4) {
-        const double l = W[r * mp + (int64_t)k * NB + c];
-#pragma unroll
-        for (int d = 0; d < MAXR; ++d)
-            if (d < nrhs) acc[d] = fma(l, Cp[r * nrhs + d], acc[d]);
-    }
-#pragma unroll
-    for (int d = 0; d < MAXR; ++d) part[q][c][d] = acc[d];
+    const int tid = threadIdx.x;
     const double* blk = W + ((int64_t)k * NB) * mp + (int64_t)k * NB;
-    for (int e = threadIdx.x; e < NB * NB; e += 256) L[e / NB][e % NB] = blk[(int64_t)(e / NB) * mp + (e % NB)];
+    for (int e = tid; e < NB * NB; e += 64) L[e / NB][e % NB] = blk[(int64_t)(e / NB) * mp + (e % NB)];
+    for (int d = 0; d < nrhs; ++d) t[tid][d] = Yw[((int64_t)k * NB + tid) * MAXR + d];
     __syncthreads();
-    if (threadIdx.x < NB) {
-        for (int d = 0; d < nrhs; ++d) {
-            const double y = W[(mp + d) * mp + (int64_t)k * NB + threadIdx.x];  // forward-substituted rhs (row mp+d)
-            t[threadIdx.x][d] = y - (part[0][threadIdx.x][d] + part[1][threadIdx.x][d] + part[2][threadIdx.x][d] +
-                                     part[3][threadIdx.x][d]);
-        }
-    }
-    __syncthreads();
-    // solve L^T z = t  (upper triangular, backwards); lane d handles rhs column d
-    if (threadIdx.x < nrhs) {
-        const int d = threadIdx.x;
+    if (tid < nrhs) {
+        const int d = tid;
         for (int cc = NB - 1; cc >= 0; --cc) {
             double z = t[cc][d];
             for (int j = cc + 1; j < NB; ++j) z -= L[j][cc] * t[j][d];
-            z /= L[cc][cc];
-            t[cc][d] = z;
+            t[cc][d] = z / L[cc][cc];
         }
-        for (int cc = 0; cc < NB; ++cc) Cp[((int64_t)k * NB + cc) * nrhs + d] = t[cc][d];
     }
+    __syncthreads();
+    const int j = blockIdx.x;
+    if (j == k) {
+        for (int d = 0; d < nrhs; ++d) Cp[((int64_t)k * NB + tid) * nrhs + d] = t[tid][d];
+        return;
+    }
+    double acc[MAXR];
+#pragma unroll
+    for (int d = 0; d < MAXR; ++d) acc[d] = 0.0;
+    const double* lp = W + ((int64_t)k * NB) * mp + (int64_t)j * NB + tid;  // column tid of block (k, j)
+    for (int r = 0; r < NB; ++r) {
+        const double l = lp[(int64_t)r * mp];
+#pragma unroll
+        for (int d = 0; d < MAXR; ++d)
+            if (d < nrhs) acc[d] = fma(l, t[r][d], acc[d]);
+    }
+    for (int d = 0; d < nrhs; ++d) Yw[((int64_t)j * NB + tid) * MAXR + d] -= acc[d];
+}
+
+// working rhs for the back substitution: Yw[c][d] = W[mp + d][c]  (the forward-substituted rhs rows)
+template <int MAXR>
+__global__ __launch_bounds__(256) void bsub_init_kernel(const double* __restrict__ W, int64_t mp, int nrhs,
+                                                        double* __restrict__ Yw) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= mp) return;
+    for (int d = 0; d < MAXR; ++d) Yw[c * MAXR + d] = d < nrhs ? W[(mp + d) * mp + c] : 0.0;
 }
 
 __global__ __launch_bounds__(256) void copy_rows_kernel(const double* __restrict__ src, int64_t count,
@@ -229,7 +234,8 @@ static inline int64_t solve_mp(int64_t m) { return cdiv(m, NB) * NB; }
 extern "C" size_t mvf_solve_workspace_bytes(int64_t m, int nrhs) {
     if (m <= 0) return 0;
     const int64_t mp = solve_mp(m), mr = mp + NB;
-    return align_up((size_t)mr * mp * sizeof(double), 256) + align_up((size_t)mp * std::max(nrhs, 1) * sizeof(double), 256) + 256;
+    return align_up((size_t)mr * mp * sizeof(double), 256) + align_up((size_t)mp * std::max(nrhs, 1) * sizeof(double), 256) +
+           align_up((size_t)mp * 8 * sizeof(double), 256) + 256;
 }
 
 extern "C" int mvf_solve(const double* G, const double* K, double lambda_sigma2, double jitter, const double* R,
@@ -249,7 +255,8 @@ extern "C" int mvf_solve(const double* G, const double* K, double lambda_sigma2,
     const int nb = (int)(mp / NB), nbr = nb + 1;
     double* W = (double*)workspace;
     double* Cp = (double*)((char*)workspace + align_up((size_t)mr * mp * sizeof(double), 256));
-    double* scal = (double*)((char*)Cp + align_up((size_t)mp * nrhs * sizeof(double), 256));
+    double* Yw = (double*)((char*)Cp + align_up((size_t)mp * nrhs * sizeof(double), 256));
+    double* scal = (double*)((char*)Yw + align_up((size_t)mp * 8 * sizeof(double), 256));
 
     hipLaunchKernelGGL(diag_mean_kernel, dim3(1), dim3(256), 0, st, G, K, lambda_sigma2, jitter, m, scal);
     MVF_LAUNCH_CHECK();
@@ -268,8 +275,9 @@ extern "C" int mvf_solve(const double* G, const double* K, double lambda_sigma2,
             hipLaunchKernelGGL(syrk_update_kernel, dim3((unsigned)ntiles), dim3(256), 0, st, W, mp, k, nb, nbr);
     }
     MVF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bsub_init_kernel<8>, dim3((unsigned)cdiv(mp, 256)), dim3(256), 0, st, W, mp, nrhs, Yw);
     for (int k = nb - 1; k >= 0; --k)
-        hipLaunchKernelGGL(bsub_kernel<8>, dim3(1), dim3(256), 0, st, W, mp, k, nrhs, Cp);
+        hipLaunchKernelGGL(bsub_step_kernel<8>, dim3((unsigned)(k + 1)), dim3(64), 0, st, W, mp, k, nrhs, Yw, Cp);
     MVF_LAUNCH_CHECK();
     hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)cdiv(m * nrhs, 256)), dim3(256), 0, st, Cp, m * nrhs, C);
     MVF_LAUNCH_CHECK();
