@@ -63,7 +63,14 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ W,
     // writes column j during step j, and later steps never read it), and the columns are scaled once at the end.
     __shared__ double a[NB][NB + 1];
     double* blk = W + ((int64_t)k * NB) * mp + (int64_t)k * NB;
-    for (int e = threadIdx.x; e < NB * NB; e += 256) a[e / NB][e % NB] = blk[(int64_t)(e / NB) * mp + (e % NB)];
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = blk[(int64_t)(wave * 16 + q) * mp + lane];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[wave * 16 + q][lane] = v[q];
+    }
     __syncthreads();
     for (int j = 0; j < NB - 1; ++j) {
         double d = a[j][j];
@@ -72,10 +79,11 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ W,
             d = 1.0;
         }
         const double inv = 1.0 / d;
-        const int rem = NB - 1 - j;
-        for (int e = threadIdx.x; e < rem * rem; e += 256) {
-            const int i = j + 1 + e / rem, c = j + 1 + e % rem;
-            if (c <= i) a[i][c] -= a[i][j] * a[c][j] * inv;
+        // 16 x 16 thread grid over the trailing block (no integer divisions; c is the fast index -> conflict-free LDS)
+        const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+        for (int i = j + 1 + ty; i < NB; i += 16) {
+            const double aij = a[i][j] * inv;
+            for (int c = j + 1 + tx; c <= i; c += 16) a[i][c] -= aij * a[c][j];
         }
         __syncthreads();
     }
@@ -174,40 +182,72 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ W
 //   columns have already been eliminated from it), then workgroup j < k eliminates C_k from block j,
 //   Y_j -= L[k-block rows, j-block cols]^T C_k, and workgroup k stores C_k.  Yw (mp x MAXR) is the working rhs.
 template <int MAXR>
-__global__ __launch_bounds__(64) void bsub_step_kernel(const double* __restrict__ W, int64_t mp, int k, int nrhs,
-                                                       double* __restrict__ Yw, double* __restrict__ Cp) {
+__global__ __launch_bounds__(256) void bsub_step_kernel(const double* __restrict__ W, int64_t mp, int k, int nrhs,
+                                                        double* __restrict__ Yw, double* __restrict__ Cp) {
     __shared__ double L[NB][NB + 1];
     __shared__ double t[NB][MAXR];
-    const int tid = threadIdx.x;
+    __shared__ double part[4][NB][MAXR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* blk = W + ((int64_t)k * NB) * mp + (int64_t)k * NB;
-    for (int e = tid; e < NB * NB; e += 64) L[e / NB][e % NB] = blk[(int64_t)(e / NB) * mp + (e % NB)];
-    for (int d = 0; d < nrhs; ++d) t[tid][d] = Yw[((int64_t)k * NB + tid) * MAXR + d];
-    __syncthreads();
-    if (tid < nrhs) {
-        const int d = tid;
-        for (int cc = NB - 1; cc >= 0; --cc) {
-            double z = t[cc][d];
-            for (int j = cc + 1; j < NB; ++j) z -= L[j][cc] * t[j][d];
-            t[cc][d] = z / L[cc][cc];
-        }
+    {
+        double v[16];  // 16 independent loads in flight per lane
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = blk[(int64_t)(wave * 16 + q) * mp + lane];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) L[wave * 16 + q][lane] = v[q];
+    }
+    if (tid < NB)
+        for (int d = 0; d < nrhs; ++d) t[tid][d] = Yw[((int64_t)k * NB + tid) * MAXR + d];
+    // issue this workgroup's elimination-panel loads early (block (k, j), rows wave*16 .. +15, column `lane`)
+    const int j = blockIdx.x;
+    double lcol[16];
+    if (j < k) {
+        const double* lp = W + ((int64_t)k * NB + wave * 16) * mp + (int64_t)j * NB + lane;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) lcol[q] = lp[(int64_t)q * mp];
     }
     __syncthreads();
-    const int j = blockIdx.x;
+    if (wave == 0) {
+        // column-oriented back substitution across the wave: lane r owns row r of the right-hand sides; once c_cc is
+        // known every lane r < cc eliminates it: y_r -= L[cc][r] c_cc  ((L^T)[r][cc] = L[cc][r], contiguous over lanes)
+        double y[MAXR];
+#pragma unroll
+        for (int d = 0; d < MAXR; ++d) y[d] = d < nrhs ? t[lane][d] : 0.0;
+        for (int cc = NB - 1; cc >= 0; --cc) {
+            const double inv = 1.0 / L[cc][cc];
+            const double l = L[cc][lane];
+#pragma unroll
+            for (int d = 0; d < MAXR; ++d) {
+                if (d < nrhs) {
+                    const double c = __shfl(y[d], cc, 64) * inv;
+                    if (lane == cc) y[d] = c;
+                    if (lane < cc) y[d] = fma(-l, c, y[d]);
+                }
+            }
+        }
+        for (int d = 0; d < nrhs; ++d) t[lane][d] = y[d];
+    }
+    __syncthreads();
     if (j == k) {
-        for (int d = 0; d < nrhs; ++d) Cp[((int64_t)k * NB + tid) * nrhs + d] = t[tid][d];
+        if (tid < NB)
+            for (int d = 0; d < nrhs; ++d) Cp[((int64_t)k * NB + tid) * nrhs + d] = t[tid][d];
         return;
     }
     double acc[MAXR];
 #pragma unroll
     for (int d = 0; d < MAXR; ++d) acc[d] = 0.0;
-    const double* lp = W + ((int64_t)k * NB) * mp + (int64_t)j * NB + tid;  // column tid of block (k, j)
-    for (int r = 0; r < NB; ++r) {
-        const double l = lp[(int64_t)r * mp];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
 #pragma unroll
         for (int d = 0; d < MAXR; ++d)
-            if (d < nrhs) acc[d] = fma(l, t[r][d], acc[d]);
+            if (d < nrhs) acc[d] = fma(lcol[q], t[wave * 16 + q][d], acc[d]);
     }
-    for (int d = 0; d < nrhs; ++d) Yw[((int64_t)j * NB + tid) * MAXR + d] -= acc[d];
+#pragma unroll
+    for (int d = 0; d < MAXR; ++d) part[wave][lane][d] = acc[d];
+    __syncthreads();
+    if (tid < NB)
+        for (int d = 0; d < nrhs; ++d)
+            Yw[((int64_t)j * NB + tid) * MAXR + d] -= part[0][tid][d] + part[1][tid][d] + part[2][tid][d] + part[3][tid][d];
 }
 
 // working rhs for the back substitution: Yw[c][d] = W[mp + d][c]  (the forward-substituted rhs rows)
@@ -277,7 +317,7 @@ extern "C" int mvf_solve(const double* G, const double* K, double lambda_sigma2,
     MVF_LAUNCH_CHECK();
     hipLaunchKernelGGL(bsub_init_kernel<8>, dim3((unsigned)cdiv(mp, 256)), dim3(256), 0, st, W, mp, nrhs, Yw);
     for (int k = nb - 1; k >= 0; --k)
-        hipLaunchKernelGGL(bsub_step_kernel<8>, dim3((unsigned)(k + 1)), dim3(64), 0, st, W, mp, k, nrhs, Yw, Cp);
+        hipLaunchKernelGGL(bsub_step_kernel<8>, dim3((unsigned)(k + 1)), dim3(256), 0, st, W, mp, k, nrhs, Yw, Cp);
     MVF_LAUNCH_CHECK();
     hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)cdiv(m * nrhs, 256)), dim3(256), 0, st, Cp, m * nrhs, C);
     MVF_LAUNCH_CHECK();
