@@ -29,7 +29,9 @@ for _p in (ROOT, os.path.join(ROOT, "spateo-release_amd")):
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (spec; 155 measured)
 PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X datasheet: FP64 matrix (v_mfma_f64_16x16x4_f64) dense peak
-PEAK_HBM_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
+PEAK_HBM_GBPS = 8000.0
+# (dtype, gram_mode, cached_u, gpus, cells, ctrl) -> corrected FETCH+WRITE bytes per launch of the dominant kernel
+PMC_TRAFFIC_BYTES = {("float32", "f64acc", True, 1, 8_000_000, 3000): 2.19e12 + 1.14e9}        # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 
 
 def log(*a):
@@ -184,7 +186,9 @@ def main():
         "peak": peak,
         "unit": "TFLOP/s",
         "frac": achieved / peak,
-        "traffic": None,
+        # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected per the gfx950
+        # notes of MI355X_MICROARCH.md; profiles/r01_hbm_traffic_pmc.md).  Only measured for the default workload.
+        "traffic": PMC_TRAFFIC_BYTES.get((args.dtype, args.gram_mode, bool(eng.cached_u), world, N, Mc)),
         "avg_kernel_ms": gram_avg_ms,
         "launches": len(gram_ms),
         "algorithmic_flops_per_launch": alg_flops,
