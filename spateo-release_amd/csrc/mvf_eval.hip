@@ -14,9 +14,18 @@ namespace mvf {
 
 constexpr int EVAL_CHUNK = 512;
 
+// v_out = alpha * (K @ C) + A q + b  (q = the UNSCALED, centred query point as passed in x4);  J_out = jmul * J.
+// Identity for the sparsevfc field; the affine part carries the GP variant's norm_dict scaling and rigid transform
+// (spateo/tdr/morphometrics/morphofield/gaussian_process.py:102-127, GPVectorField.py:158-159,190).
+struct EvalAffine {
+    double alpha, jmul;
+    double A[9];
+    double b[3];
+};
+
 template <typename T, int CPT>
 __global__ __launch_bounds__(256) void eval_kernel(const T* __restrict__ x4, int64_t n, const T* __restrict__ ctrl4,
-                                                   int64_t m, T s, double jscale /* -2 beta / s */,
+                                                   int64_t m, T s, double jscale /* -2 beta / s */, EvalAffine af,
                                                    const double* __restrict__ C, int flags, double* __restrict__ v_out,
                                                    double* __restrict__ jac, double* __restrict__ div,
                                                    double* __restrict__ curl, double* __restrict__ acc_out,
@@ -29,11 +38,13 @@ __global__ __launch_bounds__(256) void eval_kernel(const T* __restrict__ x4, int
 
     const int64_t base = ((int64_t)blockIdx.x * 256) * CPT + threadIdx.x;
     T px[CPT], py[CPT], pz[CPT];
+    double q0[CPT], q1[CPT], q2[CPT];
     double v[CPT][3], J[CPT][3][3];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
         const int64_t i = base + (int64_t)c * 256;
         V4T xv = (i < n) ? reinterpret_cast<const V4T*>(x4)[i] : V4T{0, 0, 0, 0};
+        q0[c] = (double)xv.x, q1[c] = (double)xv.y, q2[c] = (double)xv.z;
         px[c] = xv.x * s, py[c] = xv.y * s, pz[c] = xv.z * s;
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
@@ -85,8 +96,10 @@ __global__ __launch_bounds__(256) void eval_kernel(const T* __restrict__ x4, int
 #pragma unroll
         for (int f = 0; f < 3; ++f)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) Jm[f][i] = J[c][f][i] * jscale;
-        const double v0 = v[c][0], v1 = v[c][1], v2 = v[c][2];
+            for (int i = 0; i < 3; ++i) Jm[f][i] = J[c][f][i] * jscale * af.jmul;
+        const double v0 = af.alpha * v[c][0] + af.A[0] * q0[c] + af.A[1] * q1[c] + af.A[2] * q2[c] + af.b[0];
+        const double v1 = af.alpha * v[c][1] + af.A[3] * q0[c] + af.A[4] * q1[c] + af.A[5] * q2[c] + af.b[1];
+        const double v2 = af.alpha * v[c][2] + af.A[6] * q0[c] + af.A[7] * q1[c] + af.A[8] * q2[c] + af.b[2];
         if (flags & MVF_EVAL_V) {
             v_out[q * 3 + 0] = v0, v_out[q * 3 + 1] = v1, v_out[q * 3 + 2] = v2;
         }
@@ -141,9 +154,10 @@ __global__ __launch_bounds__(256) void eval_kernel(const T* __restrict__ x4, int
 
 using namespace mvf;
 
-extern "C" int mvf_eval(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, const double* C,
-                        int flags, double* v, double* jac, double* div, double* curl, double* acc, double* curv,
-                        double* tors, double* jdet, mvf_dtype dtype, void* stream) {
+extern "C" int mvf_eval_affine(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, const double* C,
+                               const double* affine /* host: alpha, jmul, A[9] row-major, b[3]; NULL = identity */,
+                               int flags, double* v, double* jac, double* div, double* curl, double* acc, double* curv,
+                               double* tors, double* jdet, mvf_dtype dtype, void* stream) {
     MVF_REQUIRE(n >= 0 && m >= 0, "mvf_eval: bad shape");
     MVF_REQUIRE(beta > 0.0 && std::isfinite(beta), "mvf_eval: beta must be finite and > 0");
     if (n == 0) return 0;
@@ -156,6 +170,15 @@ extern "C" int mvf_eval(const void* x4, int64_t n, const void* ctrl4, int64_t m,
     MVF_REQUIRE(!(flags & MVF_EVAL_CURV) || curv, "mvf_eval: curv requested but null");
     MVF_REQUIRE(!(flags & MVF_EVAL_TORS) || tors, "mvf_eval: tors requested but null");
     MVF_REQUIRE(!(flags & MVF_EVAL_JDET) || jdet, "mvf_eval: jdet requested but null");
+    EvalAffine af;
+    af.alpha = 1.0, af.jmul = 1.0;
+    for (int i = 0; i < 9; ++i) af.A[i] = 0.0;
+    for (int i = 0; i < 3; ++i) af.b[i] = 0.0;
+    if (affine) {
+        af.alpha = affine[0], af.jmul = affine[1];
+        for (int i = 0; i < 9; ++i) af.A[i] = affine[2 + i];
+        for (int i = 0; i < 3; ++i) af.b[i] = affine[11 + i];
+    }
     hipStream_t st = (hipStream_t)stream;
     const double s = std::sqrt(beta * LOG2E);
     // (x - c) = (scaled difference) / s, with s as the kernel rounds it
@@ -164,12 +187,19 @@ extern "C" int mvf_eval(const void* x4, int64_t n, const void* ctrl4, int64_t m,
     dim3 grid((unsigned)cdiv(n, 256 * CPT));
     if (dtype == MVF_F32)
         hipLaunchKernelGGL((eval_kernel<float, CPT>), grid, dim3(256), 0, st, (const float*)x4, n, (const float*)ctrl4,
-                           m, (float)s, jscale, C, flags, v, jac, div, curl, acc, curv, tors, jdet);
+                           m, (float)s, jscale, af, C, flags, v, jac, div, curl, acc, curv, tors, jdet);
     else if (dtype == MVF_F64)
         hipLaunchKernelGGL((eval_kernel<double, CPT>), grid, dim3(256), 0, st, (const double*)x4, n,
-                           (const double*)ctrl4, m, s, jscale, C, flags, v, jac, div, curl, acc, curv, tors, jdet);
+                           (const double*)ctrl4, m, s, jscale, af, C, flags, v, jac, div, curl, acc, curv, tors, jdet);
     else
         return set_error("mvf_eval: bad dtype %d", (int)dtype);
     MVF_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int mvf_eval(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, const double* C,
+                        int flags, double* v, double* jac, double* div, double* curl, double* acc, double* curv,
+                        double* tors, double* jdet, mvf_dtype dtype, void* stream) {
+    return mvf_eval_affine(x4, n, ctrl4, m, beta, C, nullptr, flags, v, jac, div, curl, acc, curv, tors, jdet, dtype,
+                           stream);
 }

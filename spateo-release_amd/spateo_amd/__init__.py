@@ -9,8 +9,8 @@ Only this hot path is implemented; the compute runs in han
 """
 from . import tdr, vectorfield
 from ._anndata_lite import AnnDataLite
-from .vectorfield import SparseVFC, SvcVectorField, con_K, set_default_dtype, vector_field_function
+from .vectorfield import GPVectorField, SparseVFC, SvcVectorField, con_K, set_default_dtype, vector_field_function
 
 __version__ = "0.1.0"
-__all__ = ["tdr", "vectorfield", "AnnDataLite", "SparseVFC", "SvcVectorField", "con_K", "vector_field_function",
+__all__ = ["tdr", "vectorfield", "AnnDataLite", "SparseVFC", "SvcVectorField", "GPVectorField", "con_K", "vector_field_function",
            "set_default_dtype"]

@@ -1,1 +1,2 @@
+from .gaussian_process import morphofield_gp
 from .sparsevfc import _morphofield_sparsevfc, morphofield_sparsevfc

@@ -7,7 +7,7 @@ from typing import Optional
 
 import numpy as np
 
-from ....vectorfield import SvcVectorField
+from ....vectorfield import GPVectorField, SvcVectorField
 
 
 def _generate_vf_class(adata, vf_key: str, method: str = "gaussian_process", nonrigid_only: bool = False):
@@ -18,9 +18,9 @@ def _generate_vf_class(adata, vf_key: str, method: str = "gaussian_process", non
             vf.from_adata(adata, basis=None, vf_key=vf_key)
             return vf
         elif method == "gaussian_process":
-            raise NotImplementedError(
-                "the gaussian_process morphofield (GPVectorField) is a 'next' row of this engine (SURVEY.md 8f rank 2)"
-            )
+            vf = GPVectorField()
+            vf.from_adata(adata, vf_key=vf_key, nonrigid_only=nonrigid_only)
+            return vf
         raise Exception(
             f"The {method} is not in ``anndata.uns[{vf_key}]``."
             f"Please re-run ``st.tdr.morphofield_gp`` or ``st.tdr.morphofield_sparsevfc`` before running this function."

@@ -23,6 +23,8 @@ from . import _lib
 from ._kernels import HipKernels
 
 __all__ = [
+    "GPVectorField",
+    "gp_velocity",
     "con_K",
     "vector_field_function",
     "SparseVFC",
@@ -543,3 +545,82 @@ class SvcVectorField:
         self._check_method(method)
         X = self.data["X"] if X is None else X
         return self._eval(X, _lib.EVAL_DIV)[_lib.EVAL_DIV]
+
+
+# =====================================================================================================================
+# Gaussian-process morphofield variant: same kernels + norm_dict scaling + rigid part
+# =====================================================================================================================
+def _gp_scalars(vf_dict):
+    nd = vf_dict["norm_dict"]
+    sf, stt = np.asarray(nd["scale_fixed"], dtype=float), np.asarray(nd["scale_transformed"], dtype=float)
+    if sf.size != 1 or stt.size != 1:
+        raise NotImplementedError("per-axis norm_dict scales are not supported by the HIP path")
+    if vf_dict["kernel_type"] == "geodist":
+        raise NotImplementedError("geodist is not implemented yet")  # as the reference (gaussian_process.py:112-113)
+    if vf_dict["kernel_type"] != "euc":
+        raise ValueError("current only support cdist and geodist")
+    return float(sf), float(stt), np.asarray(nd["mean_fixed"], dtype=float), np.asarray(nd["mean_transformed"], dtype=float)
+
+
+def _gp_eval(X, vf_dict, flags, nonrigid_only=False, dtype=None, device=None):
+    """Fused evaluator on the GP field: v = _gp_velocity(X) (``gaussian_process.py:102-127``), J = the reference's
+    ``Jacobian_GP_gaussian_kernel`` (non-rigid part x scale_fixed/scale_transformed, ``GPVectorField.py:143-190``)."""
+    dtype = dtype or _DEFAULT_DTYPE
+    X = np.asarray(X, dtype=np.float64)
+    sf, stt, mean_f, mean_t = _gp_scalars(vf_dict)
+    ind = np.asarray(vf_dict["inducing_variables"], dtype=np.float64)
+    Coff = np.asarray(vf_dict["Coff"], dtype=np.float64)
+    d = ind.shape[1]
+    if d != 3 or X.shape[1] != 3:
+        raise NotImplementedError("the GP variant of the HIP path is 3-D")
+    xn = (X - mean_t) / stt
+    center = ind.mean(0)
+    if nonrigid_only:
+        A = (sf - stt) / 10000.0 * np.eye(3)
+        b = np.zeros(3)
+    else:
+        R, t = np.asarray(vf_dict["R"], dtype=float), np.asarray(vf_dict["t"], dtype=float).reshape(3)
+        A = (sf * R - stt * np.eye(3)) / 10000.0
+        b = (sf * t + mean_f - mean_t) / 10000.0
+    b = b + A @ center  # the kernel sees q = xn - center
+    k = _make_kernels(device, dtype)
+    x4, c4 = k.to_x4(xn, center), k.to_x4(ind, center)
+    Cd = torch.from_numpy(np.ascontiguousarray(Coff[:, :3])).to(k.device)
+    out = k.eval(x4, c4, float(vf_dict["beta"]), Cd, flags, affine=(sf / 10000.0, sf / stt, A, b))
+    return {f: tt.cpu().numpy() for f, tt in out.items()}
+
+
+def gp_velocity(X, vf_dict, nonrigid_only=False, *, dtype=None, device=None):
+    """GPU ``_gp_velocity`` (``gaussian_process.py:102-127``)."""
+    X = np.asarray(X, dtype=np.float64)
+    one = X.ndim == 1
+    v = _gp_eval(X[None, :] if one else X, vf_dict, _lib.EVAL_V, nonrigid_only, dtype, device)[_lib.EVAL_V]
+    return v[0] if one else v
+
+
+class GPVectorField(SvcVectorField):
+    """Counterpart of the in-tree ``GPVectorField`` (``morphofield_dg/GPVectorField.py:193-266``): same methods as
+    :class:`SvcVectorField`, evaluated on the GP field (norm_dict scaling, rigid part unless ``nonrigid_only``)."""
+
+    def from_adata(self, adata, vf_key="VecFld", nonrigid_only=False):
+        if vf_key in adata.uns.keys():
+            vf_dict = adata.uns[vf_key]
+        else:
+            raise Exception(
+                f"The {vf_key} that corresponds to the reconstructed vector field is not in ``anndata.uns``."
+                f"Please run ``st.align.morpho_align(adata, vecfld_key_added='{vf_key}')`` before running this function."
+            )
+        self.vf_dict = vf_dict
+        self.nonrigid_only = nonrigid_only
+        self.func = lambda x: gp_velocity(x, vf_dict, nonrigid_only=nonrigid_only, dtype=self._dtype,
+                                          device=self._device)
+        self.data["X"] = vf_dict["X"]
+        self.data["V"] = vf_dict["V"]
+        return self
+
+    def compute_velocity(self, X):
+        return self.func(X)
+
+    def _eval(self, X, flags):
+        return _gp_eval(np.asarray(X, dtype=np.float64), self.vf_dict, flags, getattr(self, "nonrigid_only", False),
+                        self._dtype, self._device)

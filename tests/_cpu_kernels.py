@@ -102,13 +102,17 @@ class CpuKernels:
         c = _np(C)
         out[0] = float(np.trace(c.T @ _np(K) @ c))
 
-    def eval(self, x4, ctrl4, beta, C, flags):
+    def eval(self, x4, ctrl4, beta, C, flags, affine=None):
         X, ctrl, Cn = _np(x4)[:, :3], _np(ctrl4)[:, :3], _np(C)
         vfd = {"X_ctrl": ctrl, "C": Cn, "beta": beta}
         n = len(X)
         out = {}
         v = svo.con_K(X, ctrl, beta).reshape(n, len(ctrl)) @ Cn
         J = dgo.Jacobian_rkhs_gaussian(X, vfd, vectorize=True)
+        if affine is not None:
+            alpha, jmul, A, b = affine
+            v = alpha * v + X @ np.asarray(A).T + np.asarray(b)[None, :]
+            J = jmul * J
         a = np.einsum("fin,ni->nf", J, v)
         if flags & EVAL_V:
             out[EVAL_V] = v

@@ -268,6 +268,29 @@ def main():
     out["a_divergence_obs"] = ad.obs["divergence"]
     out["a_jacobian_obs"], out["a_jacobian_uns"] = ad.obs["jacobian"], ad.uns["jacobian"]
 
+    # ---- GP variant through the REAL reference wrappers: morphofield_gp + the seven morphofield_* with
+    #      method == "gaussian_process", rigid part included and nonrigid_only
+    Xgp = rng.standard_normal((40, 3)) * np.array([30.0, 22.0, 15.0]) + np.array([3.0, -2.0, 0.5])
+    out["gpw_X"] = Xgp
+    for tag, nro in (("full", False), ("nr", True)):
+        adg = AnnDataLite(obsm={"align_spatial": Xgp})
+        adg.uns["VecFld_morpho"] = {k: (dict(v) if isinstance(v, dict) else v) for k, v in gpd.items()}
+        gp.morphofield_gp(adg, NX=Xgp[:6] + 1.5, nonrigid_only=nro)
+        vfg = adg.uns["VecFld_morpho"]
+        assert vfg["method"] == "gaussian_process"
+        out[f"gpw_{tag}_V"], out[f"gpw_{tag}_grid"], out[f"gpw_{tag}_grid_V"] = vfg["V"], vfg["grid"], vfg["grid_V"]
+        for fn in (dg.morphofield_velocity, dg.morphofield_acceleration, dg.morphofield_curvature, dg.morphofield_curl,
+                   dg.morphofield_torsion, dg.morphofield_divergence, dg.morphofield_jacobian):
+            fn(adg, nonrigid_only=nro)
+        out[f"gpw_{tag}_velocity"] = adg.obsm["velocity"]
+        out[f"gpw_{tag}_acc_obs"], out[f"gpw_{tag}_acc_obsm"] = adg.obs["acceleration"], adg.obsm["acceleration"]
+        out[f"gpw_{tag}_curv_obs"], out[f"gpw_{tag}_curv_obsm"] = adg.obs["curvature"], adg.obsm["curvature"]
+        out[f"gpw_{tag}_curl_obs"], out[f"gpw_{tag}_curl_obsm"] = adg.obs["curl"], adg.obsm["curl"]
+        out[f"gpw_{tag}_tor_obs"], out[f"gpw_{tag}_tor_uns"] = adg.obs["torsion"], adg.uns["torsion"]
+        out[f"gpw_{tag}_div_obs"] = adg.obs["divergence"]
+        out[f"gpw_{tag}_jac_obs"], out[f"gpw_{tag}_jac_uns"] = adg.obs["jacobian"], adg.uns["jacobian"]
+    out["gp_beta"] = gpd["beta"]
+
     path = os.path.join(HERE, "ref_twins.npz")
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in out.items()})
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path)/1024:.1f} KiB")

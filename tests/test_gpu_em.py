@@ -228,6 +228,25 @@ def test_morphofield_restart_loop_golden(st, golden):
     assert _rel(res2["V"], g["w2_V"]) < 1e-5 and _rel(res2["grid_V"], g["w2_grid_V"]) < 1e-5
 
 
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 2e-4)])
+def test_gp_variant_against_reference_goldens(st, golden, dtype, tol):
+    """Gaussian-process morphofield variant on the GPU (fused evaluator with the affine epilogue) against the outputs
+    of the real reference wrappers (morphofield_gp, GPVectorField, differential_geometry)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _gp_case import gp_dict, run_and_check
+
+    st.set_default_dtype(dtype)
+    try:
+        g = golden
+        v = st.vectorfield.gp_velocity(g["gp_Xq"], gp_dict(g))
+        assert _rel(v, g["gp_vel"]) < tol
+        assert _rel(st.vectorfield.gp_velocity(g["gp_Xq"], gp_dict(g), nonrigid_only=True), g["gp_vel_nonrigid"]) < tol
+        run_and_check(st, g, tol)
+    finally:
+        st.set_default_dtype("float64")
+
+
 def test_morphofield_missing_key_errors(st):
     ad = st.AnnDataLite(obsm={"align_spatial": np.zeros((3, 3))})
     ad.uns["bad"] = {"method": "nope"}

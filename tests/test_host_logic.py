@@ -214,16 +214,37 @@ def test_anndata_wrappers_match_reference_wrappers(golden, cpu_kernels):
     assert "div2" in ad3.obs and "div2" not in ad.obs
 
 
-def test_wrapper_error_conventions():
+def test_wrapper_error_conventions(cpu_kernels, golden):
+    from _gp_case import gp_dict
+
     ad = st.AnnDataLite(obsm={"align_spatial": np.zeros((3, 3))})
     ad.uns["bad"] = {"method": "nope"}
-    ad.uns["gp"] = {"method": "gaussian_process"}
     with pytest.raises(Exception, match="is not in ``anndata.uns"):
         st.tdr.morphofield_velocity(ad, vf_key="bad")
-    with pytest.raises(NotImplementedError):
-        st.tdr.morphofield_velocity(ad, vf_key="gp")
     with pytest.raises(KeyError):
         st.tdr.morphofield_jacobian(ad, vf_key="absent")
+    with pytest.raises(Exception, match="morpho_align"):
+        st.tdr.morphofield_gp(ad, vf_key="absent")
+    geo = dict(gp_dict(golden), kernel_type="geodist")
+    with pytest.raises(NotImplementedError, match="geodist"):
+        st.vectorfield.gp_velocity(np.zeros((2, 3)), geo)
+    with pytest.raises(ValueError):
+        st.vectorfield.gp_velocity(np.zeros((2, 3)), dict(geo, kernel_type="other"))
+
+
+def test_gp_variant_matches_reference_wrappers(cpu_kernels, golden):
+    """morphofield_gp + the seven evaluators on a gaussian_process field (norm_dict scaling, rigid part,
+    nonrigid_only) against the outputs of the REAL reference wrappers / GPVectorField twins."""
+    from _gp_case import gp_dict, run_and_check
+
+    g = golden
+    np.testing.assert_allclose(st.vectorfield.gp_velocity(g["gp_Xq"], gp_dict(g)), g["gp_vel"], rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(st.vectorfield.gp_velocity(g["gp_Xq"], gp_dict(g), nonrigid_only=True),
+                               g["gp_vel_nonrigid"], rtol=1e-9, atol=1e-14)
+    vf = st.GPVectorField()
+    vf.vf_dict, vf.nonrigid_only = gp_dict(g), False
+    np.testing.assert_allclose(vf.get_Jacobian()(g["gp_Xq"]), g["gp_J"], rtol=1e-9, atol=1e-16)
+    run_and_check(st, g, 1e-8)
 
 
 def test_svcvectorfield_shapes_and_errors(cpu_kernels):
