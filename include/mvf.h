@@ -99,9 +99,10 @@ int mvf_set_gram_mode(int mode);
 int mvf_gram(const void* x4, const void* P, const void* y4, int64_t n, const void* ctrl4, int64_t m, double beta,
              double* G, double* R, void* workspace, size_t workspace_bytes, mvf_dtype dtype, void* stream);
 /* Same, one stage at a time (mask of MVF_GRAM_STAGE_*): TILES = the MFMA kernel writing per-slice partial tiles into
- * the workspace, RHS = the U^T P Y kernel, REDUCE = fixed-order sums of the partials into G and R.  mvf_gram ==
- * all three.  Lets a caller bracket the dominant kernel with HIP events on `stream` (bench.py's roofline). */
-enum { MVF_GRAM_STAGE_TILES = 1, MVF_GRAM_STAGE_RHS = 2, MVF_GRAM_STAGE_REDUCE = 4 };
+ * the workspace, RHS = the U^T P Y kernel (partials), REDUCE / REDUCE_RHS = fixed-order sums of the partials into G /
+ * into R.  mvf_gram == all four.  Lets a caller bracket the dominant kernel with HIP events on `stream` (bench.py's
+ * roofline) and lets a wide Y (Dy > 3, kernel_interpolation) reuse one G for several 3-column rhs groups. */
+enum { MVF_GRAM_STAGE_TILES = 1, MVF_GRAM_STAGE_RHS = 2, MVF_GRAM_STAGE_REDUCE = 4, MVF_GRAM_STAGE_REDUCE_RHS = 8 };
 int mvf_gram_stages(int stages, const void* x4, const void* P, const void* y4, int64_t n, const void* ctrl4,
                     int64_t m, double beta, double* G, double* R, void* workspace, size_t workspace_bytes,
                     mvf_dtype dtype, void* stream);

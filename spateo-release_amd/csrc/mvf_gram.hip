@@ -600,18 +600,18 @@ extern "C" int mvf_gram_stages(int stages, const void* x4, const void* P, const 
     MVF_REQUIRE(n >= 0 && m >= 0, "mvf_gram: bad shape");
     MVF_REQUIRE(beta >= 0.0 && std::isfinite(beta), "mvf_gram: beta must be finite and >= 0");
     MVF_REQUIRE(dtype == MVF_F32 || dtype == MVF_F64, "mvf_gram: bad dtype %d", (int)dtype);
-    MVF_REQUIRE(stages > 0 && stages <= 7, "mvf_gram: bad stage mask %d", stages);
+    MVF_REQUIRE(stages > 0 && stages <= 15, "mvf_gram: bad stage mask %d", stages);
     if (m == 0) return 0;
-    MVF_REQUIRE(G && R, "mvf_gram: null output");
+    MVF_REQUIRE(!(stages & MVF_GRAM_STAGE_REDUCE) || G, "mvf_gram: null G");
+    MVF_REQUIRE(!(stages & MVF_GRAM_STAGE_REDUCE_RHS) || R, "mvf_gram: null R");
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
-        if (stages & MVF_GRAM_STAGE_REDUCE) {
-            MVF_CHECK_HIP(hipMemsetAsync(G, 0, sizeof(double) * m * m, st));
-            MVF_CHECK_HIP(hipMemsetAsync(R, 0, sizeof(double) * m * 3, st));
-        }
+        if (stages & MVF_GRAM_STAGE_REDUCE) MVF_CHECK_HIP(hipMemsetAsync(G, 0, sizeof(double) * m * m, st));
+        if (stages & MVF_GRAM_STAGE_REDUCE_RHS) MVF_CHECK_HIP(hipMemsetAsync(R, 0, sizeof(double) * m * 3, st));
         return 0;
     }
-    MVF_REQUIRE(x4 && P && y4 && ctrl4, "mvf_gram: null input");
+    MVF_REQUIRE(x4 && P && ctrl4, "mvf_gram: null input");
+    MVF_REQUIRE(!(stages & MVF_GRAM_STAGE_RHS) || y4, "mvf_gram: null y4");
     const GramPlan p = make_plan(n, m);
     const size_t need = align_up(p.gram_bytes, 256) + align_up(p.rhs_bytes, 256);
     MVF_REQUIRE(workspace && workspace_bytes >= need, "mvf_gram: workspace too small (%zu < %zu)", workspace_bytes, need);
@@ -648,6 +648,8 @@ extern "C" int mvf_gram_stages(int stages, const void* x4, const void* P, const 
         hipLaunchKernelGGL(gram_reduce_kernel, dim3(GT * GT / 256, (unsigned)p.npairs), dim3(256), 0, st, gpart,
                            p.nslices, p.nt, p.npairs, m, G);
         MVF_LAUNCH_CHECK();
+    }
+    if (stages & MVF_GRAM_STAGE_REDUCE_RHS) {
         hipLaunchKernelGGL(rhs_reduce_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, rpart, p.rslices, m, R);
         MVF_LAUNCH_CHECK();
     }
@@ -685,8 +687,8 @@ extern "C" int mvf_gram_cached(int stages, const void* ublk, const void* x4, con
                                const void* ctrl4, int64_t m, double beta, double* G, double* R, void* workspace,
                                size_t workspace_bytes, void* stream) {
     MVF_REQUIRE(n > 0 && m > 0, "mvf_gram_cached: need n > 0 and m > 0");
-    MVF_REQUIRE(stages > 0 && stages <= 7, "mvf_gram_cached: bad stage mask %d", stages);
-    MVF_REQUIRE(ublk && P && G && R, "mvf_gram_cached: null pointer");
+    MVF_REQUIRE(stages > 0 && stages <= 15, "mvf_gram_cached: bad stage mask %d", stages);
+    MVF_REQUIRE(ublk && P, "mvf_gram_cached: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (stages & MVF_GRAM_STAGE_TILES) {
         const GramPlan p = make_plan(n, m);
@@ -699,7 +701,7 @@ extern "C" int mvf_gram_cached(int stages, const void* ublk, const void* x4, con
                            ublk_npad(n), p.nt, p.npairs, p.slice_len, (double*)workspace);
         MVF_LAUNCH_CHECK();
     }
-    const int rest = stages & (MVF_GRAM_STAGE_RHS | MVF_GRAM_STAGE_REDUCE);
+    const int rest = stages & (MVF_GRAM_STAGE_RHS | MVF_GRAM_STAGE_REDUCE | MVF_GRAM_STAGE_REDUCE_RHS);
     if (rest)
         return mvf_gram_stages(rest, x4, P, y4, n, ctrl4, m, beta, G, R, workspace, workspace_bytes, MVF_F32, stream);
     return 0;
@@ -708,6 +710,7 @@ extern "C" int mvf_gram_cached(int stages, const void* ublk, const void* x4, con
 extern "C" int mvf_gram(const void* x4, const void* P, const void* y4, int64_t n, const void* ctrl4, int64_t m,
                         double beta, double* G, double* R, void* workspace, size_t workspace_bytes, mvf_dtype dtype,
                         void* stream) {
-    return mvf_gram_stages(MVF_GRAM_STAGE_TILES | MVF_GRAM_STAGE_RHS | MVF_GRAM_STAGE_REDUCE, x4, P, y4, n, ctrl4, m,
+    return mvf_gram_stages(MVF_GRAM_STAGE_TILES | MVF_GRAM_STAGE_RHS | MVF_GRAM_STAGE_REDUCE | MVF_GRAM_STAGE_REDUCE_RHS, x4,
+                           P, y4, n, ctrl4, m,
                            beta, G, R, workspace, workspace_bytes, dtype, stream);
 }

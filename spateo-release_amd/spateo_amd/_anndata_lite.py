@@ -20,14 +20,18 @@ class _ObsFrame(dict):
 
 
 class AnnDataLite:
-    def __init__(self, obsm=None, obs=None, uns=None, n_obs=None):
+    def __init__(self, obsm=None, obs=None, uns=None, n_obs=None, X=None, var_names=None, layers=None):
+        self.X = None if X is None else np.asarray(X)
+        self.var_names = list(var_names) if var_names is not None else (
+            [str(i) for i in range(self.X.shape[1])] if self.X is not None else [])
+        self.layers = dict(layers or {})
         self.obsm = dict(obsm or {})
         self.obs = _ObsFrame()
         for k, v in (obs or {}).items():
             self.obs[k] = v
         self.uns = dict(uns or {})
         if n_obs is None:
-            n_obs = len(next(iter(self.obsm.values()))) if self.obsm else 0
+            n_obs = len(self.X) if self.X is not None else (len(next(iter(self.obsm.values()))) if self.obsm else 0)
         self.n_obs = int(n_obs)
 
     def copy(self):

@@ -128,7 +128,8 @@ class HipKernels:
         self._ublk = None
         self._ublk_key = None
 
-    def gram(self, x4, P, y4, ctrl4, beta, G, R):
+    def gram(self, x4, P, y4, ctrl4, beta, G, R, rhs_only=False):
+        """G = U^T P U (m x m), R = U^T P Y (m x 3).  rhs_only: only R for this y4 (G unchanged) - for Y wider than 3."""
         n, m = x4.shape[0], ctrl4.shape[0]
         need = self.lib.mvf_gram_workspace_bytes(n, m, self.cdtype)
         if self._gram_ws is None or self._gram_ws.numel() < need:
@@ -143,15 +144,18 @@ class HipKernels:
         else:
             def run(stages):
                 _lib.check(self.lib.mvf_gram_stages(stages, *args, self.cdtype, self._stream()), "mvf_gram_stages")
+        if rhs_only:
+            run(_lib.GRAM_RHS | _lib.GRAM_REDUCE_RHS)
+            return
         if self.gram_events is None:
-            run(_lib.GRAM_TILES | _lib.GRAM_RHS | _lib.GRAM_REDUCE)
+            run(_lib.GRAM_TILES | _lib.GRAM_RHS | _lib.GRAM_REDUCE | _lib.GRAM_REDUCE_RHS)
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         run(_lib.GRAM_TILES)
         e1.record()
         self.gram_events.append((e0, e1))
-        run(_lib.GRAM_RHS | _lib.GRAM_REDUCE)
+        run(_lib.GRAM_RHS | _lib.GRAM_REDUCE | _lib.GRAM_REDUCE_RHS)
 
     def solve(self, G, K, lambda_sigma2, jitter, R, C_out, info):
         m, nrhs = R.shape

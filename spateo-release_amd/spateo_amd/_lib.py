@@ -15,7 +15,7 @@ MVF_F32, MVF_F64 = 0, 1
 MVF_ESTEP_MIN_DOUBLES = 4098
 
 GRAM_MODE_F64_ACC, GRAM_MODE_F32_MFMA = 0, 1
-GRAM_TILES, GRAM_RHS, GRAM_REDUCE = 1, 2, 4
+GRAM_TILES, GRAM_RHS, GRAM_REDUCE, GRAM_REDUCE_RHS = 1, 2, 4, 8
 EVAL_V, EVAL_JAC, EVAL_DIV, EVAL_CURL, EVAL_ACC, EVAL_CURV, EVAL_TORS, EVAL_JDET = 1, 2, 4, 8, 16, 32, 64, 128
 
 _p, _i64, _i, _d, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_size_t

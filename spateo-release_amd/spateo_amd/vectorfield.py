@@ -135,11 +135,11 @@ class SparseVFCEngine:
         self.D, self.Dy = X.shape[1], Y.shape[1]
         if not (1 <= self.D <= 3):
             raise NotImplementedError(f"the HIP path supports 1-3 spatial dimensions, got {self.D}")
-        if not (1 <= self.Dy <= 3):
-            raise NotImplementedError(
-                f"the HIP path supports 1-3 output dimensions, got Dy={self.Dy} (kernel_interpolation's wide Dy is a "
-                f"'next' row, SURVEY.md 8f)"
-            )
+        if self.Dy < 1:
+            raise ValueError("Y must have at least one column")
+        # The kernels are 3 columns wide; a wider Y (kernel_interpolation: Dy = #keys) is processed as column groups
+        # that share ONE Gram matrix per EM step (G does not depend on Y) and get their own rhs / solve / apply.
+        self.ng = (self.Dy + 2) // 3
         self.k = kernels if kernels is not None else _make_kernels(device, dtype)
         self.distributed = bool(distributed)
         self.group = group
@@ -154,7 +154,7 @@ class SparseVFCEngine:
 
         k = self.k
         self.x4 = k.to_x4(X, self.center)
-        self.y4 = k.to_x4(Y)
+        self.y4 = [k.to_x4(Y[:, 3 * g : 3 * g + 3]) for g in range(self.ng)]
         self.ctrl4 = k.to_x4(ctrl, self.center)
         f64 = torch.float64
         M = self.M
@@ -163,18 +163,19 @@ class SparseVFCEngine:
         cc[:, : self.D] = ctrl - self.center[None, :]
         ctrl64 = torch.from_numpy(cc).to(k.device)
         self.K = k.con_k(ctrl64, ctrl64, self.beta, dtype="float64")
-        # one contiguous float64 buffer for the all-reduce: [G (M*M) | R (M*3) | stats (4)]
-        self.red = k.zeros(M * M + 3 * M + 4, dtype=f64)
+        # one contiguous float64 buffer for the all-reduce: [G (M*M) | R_g (M*3) per column group | stats (4)]
+        ng = self.ng
+        self.red = k.zeros(M * M + 3 * M * ng + 4, dtype=f64)
         self.G = self.red[: M * M].view(M, M)
-        self.R = self.red[M * M : M * M + 3 * M].view(M, 3)
-        self.st = self.red[M * M + 3 * M :]
-        self.C = k.zeros(M, 3, dtype=f64)
-        self.C_new = k.zeros(M, 3, dtype=f64)
-        self.quad = k.zeros(1, dtype=f64)
+        self.R = [self.red[M * M + 3 * M * g : M * M + 3 * M * (g + 1)].view(M, 3) for g in range(ng)]
+        self.st = self.red[M * M + 3 * M * ng :]
+        self.C = [k.zeros(M, 3, dtype=f64) for _ in range(ng)]
+        self.C_new = [k.zeros(M, 3, dtype=f64) for _ in range(ng)]
+        self.quad = k.zeros(ng, dtype=f64)
         self.spr = k.zeros(1, dtype=f64)
         self.info = k.zeros(1, dtype=torch.int32)
         self.P = torch.ones(self.n_local, dtype=k.tdtype, device=k.device)
-        self.V4 = k.zeros(self.n_local, 4)
+        self.V4 = [k.zeros(self.n_local, 4) for _ in range(ng)]
         self.r = None
         # Cholesky jitter (relative to the mean diagonal): start with none - then the solve equals the reference's
         # lstsq wherever the system has full numerical rank - and escalate only when a pivot fails (sticky afterwards)
@@ -207,15 +208,26 @@ class SparseVFCEngine:
     def init_state(self, gamma=0.9):
         """V = 0, C = 0, sigma^2 = sum ||Y||^2 / (N Dy)  (Appendix A step 4)."""
         k = self.k
-        self.C.zero_()
         self.spr.zero_()
         empty_ctrl = self.ctrl4[:0]
-        self.V4, self.r = k.apply(self.x4, empty_ctrl, self.beta, self.C, self.y4, self.P, self.spr)
+        for g in range(self.ng):
+            self.C[g].zero_()
+        self._apply_all(empty_ctrl)
         self._all_reduce(self.spr)
         s2 = float(self.spr.cpu()[0]) / (self.n_total * self.Dy)
         self.sigma2 = 1e-7 if s2 < 1e-8 else s2
         self.gamma = float(gamma)
         self.E, self.tecr, self.iteration = 1.0, 1.0, 0
+
+    def _apply_all(self, ctrl4):
+        """V_g = U C_g for every column group; r = sum_g ||Y_g - V_g||^2; spr += sum P r."""
+        k = self.k
+        for g in range(self.ng):
+            self.V4[g], rg = k.apply(self.x4, ctrl4, self.beta, self.C[g], self.y4[g], self.P, self.spr)
+            if g == 0:
+                self.r = rg
+            else:
+                self.r += rg
 
     def em_step(self, *, a=5.0, lambda_=3.0, minP=1e-5, theta=0.75):
         """One EM iteration (Appendix A step 5 a-e).  Returns (E, tecr)."""
@@ -229,14 +241,22 @@ class SparseVFCEngine:
         self.st.zero_()
         k.estep_p(self.r, self.sigma2, self.gamma, a, self.Dy, minP, theta, zero_fill, self.P, self.st)
         # ---- M-step assembly (MFMA) + energy regulariser with the OLD coefficients
-        k.gram(self.x4, self.P, self.y4, self.ctrl4, self.beta, self.G, self.R)
-        k.quadform(self.K, self.C, self.quad)
+        k.gram(self.x4, self.P, self.y4[0], self.ctrl4, self.beta, self.G, self.R[0])
+        for g in range(1, self.ng):
+            k.gram(self.x4, self.P, self.y4[g], self.ctrl4, self.beta, self.G, self.R[g], rhs_only=True)
+        for g in range(self.ng):
+            k.quadform(self.K, self.C[g], self.quad[g : g + 1])
         self._all_reduce(self.red)  # the one big collective per EM step: [G | R | stats]
         # ---- coefficient solve (jitter escalates only if a pivot fails; it is sticky afterwards)
         ls2 = lambda_ * self.sigma2
         while True:
-            k.solve(self.G, self.K, ls2, self.jitter, self.R, self.C_new, self.info)
-            host = torch.cat([self.st, self.quad, self.info.to(torch.float64)]).cpu()
+            fail = 0
+            for g in range(self.ng):
+                k.solve(self.G, self.K, ls2, self.jitter, self.R[g], self.C_new[g], self.info)
+                if g + 1 < self.ng:
+                    fail = max(fail, int(self.info.cpu()[0]))
+            host = torch.cat([self.st, self.quad.sum().reshape(1), self.info.to(torch.float64)]).cpu()
+            host[5] = max(float(host[5]), float(fail))
             if int(host[5]) == 0:
                 break
             self.solve_retries += 1
@@ -254,7 +274,7 @@ class SparseVFCEngine:
         self.C, self.C_new = self.C_new, self.C
         # ---- field + sigma^2 + gamma
         self.spr.zero_()
-        self.V4, self.r = k.apply(self.x4, self.ctrl4, self.beta, self.C, self.y4, self.P, self.spr)
+        self._apply_all(self.ctrl4)
         self._all_reduce(self.spr)
         self.sigma2 = float(self.spr.cpu()[0]) / (s_pf * self.Dy)
         g = s_cnt / self.n_total
@@ -276,8 +296,8 @@ class SparseVFCEngine:
         """v(pts) = con_K(pts, ctrl, beta) @ C on the device -> host float64 (n, Dy)."""
         pts = np.asarray(pts, dtype=np.float64)
         p4 = self.k.to_x4(pts, self.center)
-        V4, _ = self.k.apply(p4, self.ctrl4, self.beta, self.C)
-        return V4[:, : self.Dy].to(torch.float64).cpu().numpy()
+        cols = [self.k.apply(p4, self.ctrl4, self.beta, self.C[g])[0][:, :3] for g in range(self.ng)]
+        return torch.cat(cols, dim=1)[:, : self.Dy].to(torch.float64).cpu().numpy()
 
     def _gather_rows(self, t):
         """Concatenate per-rank row blocks (sizes from shard_bounds) on every rank."""
@@ -295,9 +315,10 @@ class SparseVFCEngine:
 
     def results(self):
         """(V (N, Dy), P (N, 1), C (M, Dy)) as host float64, gathered over ranks."""
-        V = self._gather_rows(self.V4[:, : self.Dy].contiguous()).to(torch.float64).cpu().numpy()
+        Vloc = torch.cat([v[:, :3] for v in self.V4], dim=1)[:, : self.Dy].contiguous()
+        V = self._gather_rows(Vloc).to(torch.float64).cpu().numpy()
         P = self._gather_rows(self.P[:, None].contiguous()).to(torch.float64).cpu().numpy()
-        C = self.C[:, : self.Dy].cpu().numpy().copy()
+        C = torch.cat(self.C, dim=1)[:, : self.Dy].cpu().numpy().copy()
         return V, P, C
 
 

@@ -81,11 +81,12 @@ class CpuKernels:
         P_out.copy_(torch.from_numpy(pf))
         stats += torch.tensor([p @ rr, p.sum(), pf.sum(), float((pf > theta).sum())], dtype=torch.float64)
 
-    def gram(self, x4, P, y4, ctrl4, beta, G, R):
+    def gram(self, x4, P, y4, ctrl4, beta, G, R, rhs_only=False):
         X, ctrl = _np(x4)[:, :3], _np(ctrl4)[:, :3]
         U = svo.con_K(X, ctrl, beta).reshape(len(X), len(ctrl))
         UP = U.T * _np(P)[None, :]
-        G.copy_(torch.from_numpy(UP @ U))
+        if not rhs_only:
+            G.copy_(torch.from_numpy(UP @ U))
         R.copy_(torch.from_numpy(UP @ _np(y4)[:, :3]))
 
     def solve(self, G, K, lambda_sigma2, jitter, R, C_out, info):
@@ -101,6 +102,7 @@ class CpuKernels:
     def quadform(self, K, C, out):
         c = _np(C)
         out[0] = float(np.trace(c.T @ _np(K) @ c))
+        return out
 
     def eval(self, x4, ctrl4, beta, C, flags, affine=None):
         X, ctrl, Cn = _np(x4)[:, :3], _np(ctrl4)[:, :3], _np(C)

@@ -156,6 +156,23 @@ def test_sparsevfc_non_finite_rows_and_duplicates(st):
     assert _rel(got["V"], ref["V"]) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("dy", [1, 5])
+def test_sparsevfc_wide_and_narrow_outputs(st, dtype, dy):
+    """Dy != D (kernel_interpolation's call shape): 3-column groups sharing one Gram matrix per EM step."""
+    rng = np.random.default_rng(dy)
+    X, _ = _c2(5000)
+    Y = np.column_stack([np.sin(X[:, 0] / 80 + j) + 0.3 * np.cos(X[:, 1] / 60 * (j + 1)) for j in range(dy)])
+    Y += 0.02 * rng.standard_normal(Y.shape)
+    kw = dict(M=150, lambda_=3.0, lstsq_method="scipy", MaxIter=10, seed=0)
+    ref = svo.SparseVFC(X, Y, X[::50], **kw)
+    got = st.SparseVFC(X, Y, X[::50], dtype=dtype, device="cuda:0", **kw)
+    assert got["V"].shape == (5000, dy) and got["C"].shape == (150, dy) and got["grid_V"].shape == (100, dy)
+    assert got["iteration"] == ref["iteration"]
+    assert _rel(got["V"], ref["V"]) < TOL[dtype] and _rel(got["grid_V"], ref["grid_V"]) < TOL[dtype]
+    np.testing.assert_allclose(got["sigma2"], ref["sigma2"], rtol=TOL[dtype])
+
+
 def test_sparsevfc_errors(st):
     X, V = _c2(100)
     with pytest.raises(NotImplementedError):

@@ -78,6 +78,23 @@ def test_em_driver_reproduces_oracle_sparsevfc(cpu_kernels):
     assert got["P"].shape == (700, 1) and got["C"].shape == (40, 3)
 
 
+@pytest.mark.parametrize("dy", [1, 2, 4, 7])
+def test_em_driver_wide_and_narrow_outputs(cpu_kernels, dy):
+    """Dy != D (kernel_interpolation's use of SparseVFC): Y is processed in 3-column groups sharing one Gram matrix."""
+    rng = np.random.default_rng(dy)
+    X, V = _data(500)
+    Y = np.column_stack([np.sin(X[:, 0] / 80 + j) + 0.3 * np.cos(X[:, 1] / 60 * (j + 1)) for j in range(dy)])
+    Y += 0.02 * rng.standard_normal(Y.shape)
+    kw = dict(M=30, lambda_=3.0, lstsq_method="scipy", MaxIter=12, seed=0)
+    ref = svo.SparseVFC(X, Y, X[::20], **kw)
+    got = st.SparseVFC(X, Y, X[::20], _kernels=cpu_kernels, **kw)
+    assert got["V"].shape == (500, dy) and got["C"].shape == (30, dy) and got["grid_V"].shape == (25, dy)
+    assert got["iteration"] == ref["iteration"]
+    assert _rel(got["V"], ref["V"]) < 1e-8 and _rel(got["grid_V"], ref["grid_V"]) < 1e-8
+    np.testing.assert_allclose(got["E_traj"], ref["E_traj"], rtol=1e-8)
+    np.testing.assert_allclose(got["P"], ref["P"], rtol=1e-6, atol=1e-12)
+
+
 def test_em_driver_stops_like_the_reference(cpu_kernels):
     X, V = _data(300)
     for kw in (dict(MaxIter=3), dict(MaxIter=50, ecr=1e-2), dict(MaxIter=1)):
@@ -131,8 +148,6 @@ def test_engine_rejects_unsupported_shapes(cpu_kernels):
     X = np.zeros((10, 4))
     with pytest.raises(NotImplementedError, match="spatial dimensions"):
         SparseVFCEngine(X, X[:, :3], X[:3], 0.1, kernels=cpu_kernels)
-    with pytest.raises(NotImplementedError, match="kernel_interpolation"):
-        SparseVFCEngine(X[:, :3], np.zeros((10, 7)), X[:3, :3], 0.1, kernels=cpu_kernels)
     with pytest.raises(ValueError):
         SparseVFCEngine(X[:, :3], X[:5, :3], X[:3, :3], 0.1, kernels=cpu_kernels)
     with pytest.raises(NotImplementedError):
@@ -275,3 +290,34 @@ def test_anndata_lite_copy_is_deep():
     c.obsm["a"][0, 0] = 5
     c.uns["k"] = 1
     assert ad.obsm["a"][0, 0] == 0 and "k" not in ad.uns
+
+
+def test_kernel_interpolation_matches_reference_call_shape(cpu_kernels):
+    """kernel_interpolation == SparseVFC(spatial, [obs cols | gene cols], target_points)["grid_V"] split back into
+    obs / X (interpolation_sparseVFC.py:44-83)."""
+    rng = np.random.default_rng(3)
+    n = 400
+    S = rng.uniform(-1, 1, (n, 3)) * 50
+    genes = np.column_stack([np.sin(S[:, 0] / 20), np.cos(S[:, 1] / 15), S[:, 2] / 50, np.sin(S[:, 0] / 9) ** 2])
+    genes += 0.01 * rng.standard_normal(genes.shape)
+    score = np.cos(S[:, 2] / 25)
+    ad = st.AnnDataLite(X=genes, var_names=["g0", "g1", "g2", "g3"], obs={"score": score}, obsm={"spatial": S})
+    tgt = rng.uniform(-1, 1, (30, 3)) * 45
+    kw = dict(M=40, MaxIter=10, seed=0)
+    out = st.tdr.kernel_interpolation(ad, target_points=tgt, keys=["g2", "score", "g0", "g3"], lambda_=3.0, **kw)
+    info = np.column_stack([score, genes[:, [2, 0, 3]]])  # obs keys first, then genes, each in `keys` order
+    ref = svo.SparseVFC(S, info, tgt, lambda_=3.0, lstsq_method="scipy", **kw)["grid_V"]
+    got_obs = np.asarray(out.obs["score"], dtype=float)
+    got_X = np.asarray(out.X)
+    assert got_X.shape == (30, 3) and list(out.var_names) == ["g2", "g0", "g3"]
+    np.testing.assert_allclose(got_obs, ref[:, 0], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(got_X, ref[:, 1:], rtol=1e-7, atol=1e-9)
+    np.testing.assert_array_equal(np.asarray(out.obsm["spatial"]), tgt)
+    # single key as a string; layer selection; error conventions
+    ad.layers["alt"] = genes * 2
+    one = st.tdr.kernel_interpolation(ad, target_points=tgt, keys="g1", layer="alt", lambda_=3.0, **kw)
+    assert np.asarray(one.X).shape == (30, 1)
+    with pytest.raises(AssertionError, match="keys"):
+        st.tdr.kernel_interpolation(ad, target_points=tgt)
+    with pytest.raises(ValueError, match="none of the keys"):
+        st.tdr.kernel_interpolation(ad, target_points=tgt, keys=["nope"])
