@@ -153,6 +153,16 @@ int mvf_eval_affine(const void* x4, int64_t n, const void* ctrl4, int64_t m, dou
                     const double* affine, int flags, double* v, double* jac, double* div, double* curl, double* acc,
                     double* curv, double* tors, double* jdet, mvf_dtype dtype, void* stream);
 
+/* ---- trajectory integration (morphopath) ------------------------------------------------------------------------
+ * Integrates dx/dt = v(x), v as in mvf_eval_affine, from the n start points x4 with classical RK4: n_out samples per
+ * trajectory, `dt` apart, `substeps` RK4 steps between samples; traj (float64) = [n][n_out][3], traj[:, 0] = start.
+ * One launch, one lane per trajectory, control points staged in LDS.  A negative dt integrates backwards.
+ * Replaces the field evaluations inside dynamo `fate` as driven by `morphopath`
+ * (spateo/tdr/morphometrics/morphofield/trajectory.py:61-109).  The integrator itself is this repo's (fixed-step RK4,
+ * uniform time sampling): dynamo's adaptive RK45 + arc-length resampling lives outside the reference tree. */
+int mvf_integrate(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, const double* C,
+                  const double* affine, double dt, int substeps, int n_out, double* traj, mvf_dtype dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

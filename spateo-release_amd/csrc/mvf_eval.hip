@@ -150,6 +150,94 @@ __global__ __launch_bounds__(256) void eval_kernel(const T* __restrict__ x4, int
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Trajectory integration  dx/dt = v(x)  (morphopath; reference: spateo/tdr/morphometrics/morphofield/trajectory.py:11-117,
+// which hands the field to dynamo's `fate`).  One launch integrates every start point through ALL time steps with
+// classical RK4: a lane owns one trajectory (position in float64 registers), the control points and coefficients are
+// staged in LDS once (or per evaluation in chunks when they do not fit), and the n_out sampled positions are written
+// as traj[cell][t][3].  No host round trip and no intermediate tensor per step.
+// ----------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void integrate_kernel(const T* __restrict__ x4, int64_t n, const T* __restrict__ ctrl4,
+                                                        int64_t m, T s, EvalAffine af, const double* __restrict__ C,
+                                                        double dt, int substeps, int n_out, int chunk,
+                                                        double* __restrict__ traj) {
+    using V4T = typename Vec4<T>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    V4T* sc = reinterpret_cast<V4T*>(smem_dyn);
+    double4* sC = reinterpret_cast<double4*>(smem_dyn + (size_t)chunk * sizeof(V4T));
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n;
+    const int nchunks = (int)((m + chunk - 1) / chunk);
+
+    auto stage = [&](int64_t m0) {
+        const int mc = (int)min((int64_t)chunk, m - m0);
+        for (int j = threadIdx.x; j < chunk; j += 256) {
+            if (j < mc) {
+                const V4T cv = reinterpret_cast<const V4T*>(ctrl4)[m0 + j];
+                sc[j] = V4T{cv.x * s, cv.y * s, cv.z * s, 0};
+                const double* cp = C + (m0 + j) * 3;
+                sC[j] = double4{cp[0], cp[1], cp[2], 0.0};
+            } else {
+                sc[j] = V4T{0, 0, 0, 0};
+                sC[j] = double4{0.0, 0.0, 0.0, 0.0};
+            }
+        }
+    };
+    // v(q) for this lane's position q (block-synchronous: every lane takes the same path through the barriers)
+    auto field = [&](double q0, double q1, double q2, double& v0, double& v1, double& v2) {
+        const T px = (T)q0 * s, py = (T)q1 * s, pz = (T)q2 * s;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int cidx = 0; cidx < nchunks; ++cidx) {
+            if (nchunks > 1) {
+                __syncthreads();
+                stage((int64_t)cidx * chunk);
+                __syncthreads();
+            }
+            const int mc = (int)min((int64_t)chunk, m - (int64_t)cidx * chunk);
+#pragma unroll 4
+            for (int j = 0; j < mc; ++j) {
+                const V4T cv = sc[j];
+                const double4 cc = sC[j];
+                const double k = (double)kernel_value(px, py, pz, cv.x, cv.y, cv.z);
+                a0 = fma(k, cc.x, a0), a1 = fma(k, cc.y, a1), a2 = fma(k, cc.z, a2);
+            }
+        }
+        v0 = af.alpha * a0 + af.A[0] * q0 + af.A[1] * q1 + af.A[2] * q2 + af.b[0];
+        v1 = af.alpha * a1 + af.A[3] * q0 + af.A[4] * q1 + af.A[5] * q2 + af.b[1];
+        v2 = af.alpha * a2 + af.A[6] * q0 + af.A[7] * q1 + af.A[8] * q2 + af.b[2];
+    };
+
+    if (nchunks == 1) {
+        stage(0);
+        __syncthreads();
+    }
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+    if (live) {
+        const V4T xv = reinterpret_cast<const V4T*>(x4)[i];
+        x0 = (double)xv.x, x1 = (double)xv.y, x2 = (double)xv.z;
+        double* o = traj + (size_t)i * n_out * 3;
+        o[0] = x0, o[1] = x1, o[2] = x2;
+    }
+    const double h = dt / substeps;
+    for (int t = 1; t < n_out; ++t) {
+        for (int ss = 0; ss < substeps; ++ss) {
+            double k1x, k1y, k1z, k2x, k2y, k2z, k3x, k3y, k3z, k4x, k4y, k4z;
+            field(x0, x1, x2, k1x, k1y, k1z);
+            field(x0 + 0.5 * h * k1x, x1 + 0.5 * h * k1y, x2 + 0.5 * h * k1z, k2x, k2y, k2z);
+            field(x0 + 0.5 * h * k2x, x1 + 0.5 * h * k2y, x2 + 0.5 * h * k2z, k3x, k3y, k3z);
+            field(x0 + h * k3x, x1 + h * k3y, x2 + h * k3z, k4x, k4y, k4z);
+            x0 += h / 6.0 * (k1x + 2.0 * k2x + 2.0 * k3x + k4x);
+            x1 += h / 6.0 * (k1y + 2.0 * k2y + 2.0 * k3y + k4y);
+            x2 += h / 6.0 * (k1z + 2.0 * k2z + 2.0 * k3z + k4z);
+        }
+        if (live) {
+            double* o = traj + ((size_t)i * n_out + t) * 3;
+            o[0] = x0, o[1] = x1, o[2] = x2;
+        }
+    }
+}
+
 }  // namespace mvf
 
 using namespace mvf;
@@ -202,4 +290,44 @@ extern "C" int mvf_eval(const void* x4, int64_t n, const void* ctrl4, int64_t m,
                         double* tors, double* jdet, mvf_dtype dtype, void* stream) {
     return mvf_eval_affine(x4, n, ctrl4, m, beta, C, nullptr, flags, v, jac, div, curl, acc, curv, tors, jdet, dtype,
                            stream);
+}
+
+extern "C" int mvf_integrate(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, const double* C,
+                             const double* affine, double dt, int substeps, int n_out, double* traj, mvf_dtype dtype,
+                             void* stream) {
+    MVF_REQUIRE(n >= 0 && m >= 0 && n_out >= 1 && substeps >= 1, "mvf_integrate: bad shape");
+    MVF_REQUIRE(beta > 0.0 && std::isfinite(beta) && std::isfinite(dt), "mvf_integrate: bad beta / dt");
+    if (n == 0) return 0;
+    MVF_REQUIRE(x4 && traj && (m == 0 || (ctrl4 && C)), "mvf_integrate: null pointer");
+    EvalAffine af;
+    af.alpha = 1.0, af.jmul = 1.0;
+    for (int i = 0; i < 9; ++i) af.A[i] = 0.0;
+    for (int i = 0; i < 3; ++i) af.b[i] = 0.0;
+    if (affine) {
+        af.alpha = affine[0], af.jmul = affine[1];
+        for (int i = 0; i < 9; ++i) af.A[i] = affine[2 + i];
+        for (int i = 0; i < 3; ++i) af.b[i] = affine[11 + i];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const double s = std::sqrt(beta * LOG2E);
+    const size_t per = (dtype == MVF_F32 ? 16 : 32) + 32;  // bytes of LDS per staged control point
+    const int cap = (int)((144 * 1024) / per);               // leave headroom below the 160 KiB of a CU
+    const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(m, cap));
+    const size_t lds = (size_t)chunk * per;
+    dim3 grid((unsigned)cdiv(n, 256));
+    if (dtype == MVF_F32) {
+        MVF_CHECK_HIP(hipFuncSetAttribute((const void*)integrate_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds));
+        hipLaunchKernelGGL(integrate_kernel<float>, grid, dim3(256), lds, st, (const float*)x4, n, (const float*)ctrl4, m,
+                           (float)s, af, C, dt, substeps, n_out, chunk, traj);
+    } else if (dtype == MVF_F64) {
+        MVF_CHECK_HIP(hipFuncSetAttribute((const void*)integrate_kernel<double>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(integrate_kernel<double>, grid, dim3(256), lds, st, (const double*)x4, n,
+                           (const double*)ctrl4, m, s, af, C, dt, substeps, n_out, chunk, traj);
+    } else {
+        return set_error("mvf_integrate: bad dtype %d", (int)dtype);
+    }
+    MVF_LAUNCH_CHECK();
+    return 0;
 }

@@ -170,6 +170,26 @@ class HipKernels:
         _lib.check(self.lib.mvf_quadform(_ptr(K), _ptr(C), K.shape[0], C.shape[1], _ptr(out), self._stream()),
                    "mvf_quadform")
 
+    @staticmethod
+    def _affine_buf(affine):
+        if affine is None:
+            return None
+        import ctypes
+
+        alpha, jmul, A, b = affine
+        vals = [float(alpha), float(jmul)] + [float(x) for x in np.asarray(A, dtype=np.float64).reshape(9)] + \
+               [float(x) for x in np.asarray(b, dtype=np.float64).reshape(3)]
+        return (ctypes.c_double * 14)(*vals)
+
+    def integrate(self, x4, ctrl4, beta, C, dt, substeps, n_out, affine=None):
+        """RK4 trajectories of dx/dt = v(x): returns a float64 device tensor (n, n_out, 3)."""
+        n, m = x4.shape[0], ctrl4.shape[0]
+        traj = torch.empty(n, n_out, 3, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mvf_integrate(_ptr(x4), n, _ptr(ctrl4), m, float(beta), _ptr(C), self._affine_buf(affine),
+                                          float(dt), int(substeps), int(n_out), _ptr(traj), self.cdtype,
+                                          self._stream()), "mvf_integrate")
+        return traj
+
     def eval(self, x4, ctrl4, beta, C, flags, affine=None):
         """Fused evaluator.  Returns a dict of float64 device tensors for the requested MVF_EVAL_* flags.
         `affine` = (alpha, jmul, A (3x3), b (3)) applies v = alpha K@C + A q + b, J = jmul J (GP variant)."""
@@ -192,14 +212,7 @@ class HipKernels:
         curv = buf(_lib.EVAL_CURV, n, 3)
         tors = buf(_lib.EVAL_TORS, n, 3)
         jdet = buf(_lib.EVAL_JDET, n)
-        aff = None
-        if affine is not None:
-            import ctypes
-
-            alpha, jmul, A, b = affine
-            vals = [float(alpha), float(jmul)] + [float(x) for x in np.asarray(A, dtype=np.float64).reshape(9)] + \
-                   [float(x) for x in np.asarray(b, dtype=np.float64).reshape(3)]
-            aff = (ctypes.c_double * 14)(*vals)
+        aff = self._affine_buf(affine)
         _lib.check(self.lib.mvf_eval_affine(_ptr(x4), n, _ptr(ctrl4), m, float(beta), _ptr(C), aff, int(flags), _ptr(v),
                                             _ptr(jac), _ptr(div), _ptr(curl), _ptr(acc), _ptr(curv), _ptr(tors),
                                             _ptr(jdet), self.cdtype, self._stream()), "mvf_eval_affine")

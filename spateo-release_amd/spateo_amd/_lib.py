@@ -43,6 +43,7 @@ SIGNATURES = {
     "mvf_eval": (_i, [_p, _i64, _p, _i64, _d, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "mvf_eval_affine": (_i, [_p, _i64, _p, _i64, _d, _p, C.POINTER(C.c_double), _i, _p, _p, _p, _p, _p, _p, _p, _p, _i,
                              _p]),
+    "mvf_integrate": (_i, [_p, _i64, _p, _i64, _d, _p, C.POINTER(C.c_double), _d, _i, _i, _p, _i, _p]),
 }
 
 _lib = None

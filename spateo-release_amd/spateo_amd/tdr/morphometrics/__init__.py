@@ -1,4 +1,4 @@
-from .morphofield import _morphofield_sparsevfc, morphofield_gp, morphofield_sparsevfc
+from .morphofield import _morphofield_sparsevfc, morphofield_gp, morphofield_sparsevfc, morphopath
 from .morphofield_dg import (
     morphofield_acceleration,
     morphofield_curl,

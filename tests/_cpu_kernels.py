@@ -104,6 +104,28 @@ class CpuKernels:
         out[0] = float(np.trace(c.T @ _np(K) @ c))
         return out
 
+    def integrate(self, x4, ctrl4, beta, C, dt, substeps, n_out, affine=None):
+        """Same fixed-step RK4 as the device kernel, in NumPy (host-logic double; accuracy is checked on the GPU)."""
+        X, ctrl, Cn = _np(x4)[:, :3].astype(np.float64), _np(ctrl4)[:, :3], _np(C)
+
+        def f(q):
+            v = svo.con_K(q, ctrl, beta).reshape(len(q), len(ctrl)) @ Cn
+            if affine is not None:
+                alpha, _, A, b = affine
+                v = alpha * v + q @ np.asarray(A).T + np.asarray(b)[None, :]
+            return v
+
+        traj = np.empty((len(X), n_out, 3))
+        x = X.copy()
+        traj[:, 0] = x
+        h = dt / substeps
+        for t in range(1, n_out):
+            for _ in range(substeps):
+                k1 = f(x); k2 = f(x + 0.5 * h * k1); k3 = f(x + 0.5 * h * k2); k4 = f(x + h * k3)
+                x = x + h / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+            traj[:, t] = x
+        return torch.from_numpy(traj)
+
     def eval(self, x4, ctrl4, beta, C, flags, affine=None):
         X, ctrl, Cn = _np(x4)[:, :3], _np(ctrl4)[:, :3], _np(C)
         vfd = {"X_ctrl": ctrl, "C": Cn, "beta": beta}

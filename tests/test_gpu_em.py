@@ -264,6 +264,42 @@ def test_gp_variant_against_reference_goldens(st, golden, dtype, tol):
         st.set_default_dtype("float64")
 
 
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-6), ("float32", 2e-4)])  # RK4 truncation at 4 substeps ~3e-7
+def test_morphopath_fused_rk4_vs_dop853(st, golden, dtype, tol):
+    """The fused RK4 integration kernel against SciPy DOP853 on the float64 oracle field (sparsevfc and GP fields)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _gp_case import gp_dict
+    from oracle import trajectory_oracle as tro
+    from spateo_amd.vectorfield import integrate_field
+
+    g = golden
+    vf = {k: g[f"a_vf_{k}"] for k in ["X_ctrl", "C", "V"]}
+    vf.update(X=g["a_X"], beta=float(g["a_vf_beta"]), method="sparsevfc")
+    x0 = g["a_X"][:40]
+    tq = np.linspace(0, 30, 16)
+    t, pred = integrate_field(vf, x0, t_end=30.0, interpolation_num=16, dtype=dtype, device="cuda:0")
+    ref = tro.integrate(vf, x0, tq)
+    assert np.abs(np.stack(pred) - ref).max() / np.abs(ref).max() < tol
+    np.testing.assert_allclose(t[0], tq)
+    # GP field (norm_dict scaling + rigid part): the oracle field is the reference twin's formula
+    gd = gp_dict(g)
+    gd.update(X=g["gpw_X"], V=g["gpw_full_V"], method="gaussian_process")
+
+    def gp_field(x):
+        nd = gd["norm_dict"]
+        xn = (np.atleast_2d(x) - nd["mean_transformed"]) / nd["scale_transformed"]
+        vel = svo.con_K(xn, gd["inducing_variables"], gd["beta"]).reshape(len(xn), -1) @ gd["Coff"]
+        q = (vel + xn @ gd["R"].T + gd["t"]) * nd["scale_fixed"] + nd["mean_fixed"]
+        return (q - np.atleast_2d(x)) / 10000
+
+    np.testing.assert_allclose(gp_field(g["gp_Xq"]), g["gp_vel"], rtol=1e-10)  # the restated field == the twin
+    tq2 = np.linspace(0, 2000.0, 11)
+    t2, pred2 = integrate_field(gd, g["gpw_X"][:10], t_end=2000.0, interpolation_num=11, dtype=dtype, device="cuda:0")
+    ref2 = tro.integrate(gd, g["gpw_X"][:10], tq2, field=gp_field)
+    assert np.abs(np.stack(pred2) - ref2).max() / np.abs(ref2).max() < tol
+
+
 def test_morphofield_missing_key_errors(st):
     ad = st.AnnDataLite(obsm={"align_spatial": np.zeros((3, 3))})
     ad.uns["bad"] = {"method": "nope"}

@@ -321,3 +321,37 @@ def test_kernel_interpolation_matches_reference_call_shape(cpu_kernels):
         st.tdr.kernel_interpolation(ad, target_points=tgt)
     with pytest.raises(ValueError, match="none of the keys"):
         st.tdr.kernel_interpolation(ad, target_points=tgt, keys=["nope"])
+
+
+def test_morphopath_slots_and_accuracy(cpu_kernels, golden):
+    """morphopath's AnnData slots (trajectory.py:111-115) and the RK4 solution against SciPy DOP853 on the oracle field."""
+    from oracle import trajectory_oracle as tro
+
+    g = golden
+    ad = st.AnnDataLite(obsm={"align_spatial": g["a_X"], "V_mapping": g["a_V"]})
+    vf = {k: g[f"a_vf_{k}"] for k in ["X_ctrl", "C", "beta", "V"]}
+    vf.update(X=g["a_X"][:6], Y=g["a_V"][:6], method="sparsevfc", beta=float(g["a_vf_beta"]))
+    vf["V"] = vf["V"][:6]
+    ad.uns["VecFld_morpho"] = vf
+    assert st.tdr.morphopath(ad, interpolation_num=21, t_end=40.0, direction="both") is None
+    fate = ad.uns["fate_morpho"]
+    assert set(fate["t"].keys()) == set(range(6)) and fate["prediction"][0].shape == (3, 41)
+    np.testing.assert_allclose(fate["t"][0], np.linspace(-40, 40, 41))
+    np.testing.assert_allclose(fate["prediction"][2][:, 20], g["a_X"][2])  # t = 0 is the start point
+    tq = np.linspace(0, 40, 21)
+    ref = tro.integrate(vf, g["a_X"][:6], tq)
+    got = np.stack([fate["prediction"][i].T[20:] for i in range(6)])
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-7
+    refb = tro.integrate(vf, g["a_X"][:6], -tq)
+    gotb = np.stack([fate["prediction"][i].T[20::-1] for i in range(6)])
+    assert np.abs(gotb - refb).max() / np.abs(refb).max() < 1e-7
+    # default t_end (dynamo getTend), averaging modes, copies, errors
+    ad2 = st.tdr.morphopath(ad, interpolation_num=5, average="origin", inplace=False, key_added="f2")
+    assert "f2" in ad2.uns and "f2" not in ad.uns and len(ad2.uns["f2"]["prediction"]) == 1
+    st.tdr.morphopath(ad, interpolation_num=5, t_end=3.0, average="trajectory", key_added="f3")
+    assert ad.uns["f3"]["prediction"][0].shape == (3, 5)
+    ad.uns["bad"] = {"method": "other", "X": g["a_X"][:2]}
+    with pytest.raises(Exception, match="not in avaliable"):
+        st.tdr.morphopath(ad, vf_key="bad")
+    with pytest.raises(Exception, match="not in ``anndata.uns``"):
+        st.tdr.morphopath(ad, vf_key="absent")
