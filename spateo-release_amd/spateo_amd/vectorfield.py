@@ -23,6 +23,7 @@ from . import _lib
 from ._kernels import HipKernels
 
 __all__ = [
+    "SparseVFC_many",
     "integrate_field",
     "GPVectorField",
     "gp_velocity",
@@ -74,8 +75,16 @@ def sample_by_velocity(V: np.ndarray, n: int, seed: int = 19491001) -> np.ndarra
     return np.random.choice(np.arange(len(V)), size=n, p=p, replace=False)
 
 
+_PREPROCESS_LOCK = __import__("threading").Lock()  # the sampling re-seeds NumPy's GLOBAL RNG (as dynamo does)
+
+
 def sparsevfc_preprocess(X, Y, M=100, beta=None, velocity_based_sampling=True, seed=0):
     """valid rows, unique rows, control points and beta exactly as dynamo's SparseVFC picks them."""
+    with _PREPROCESS_LOCK:
+        return _sparsevfc_preprocess(X, Y, M, beta, velocity_based_sampling, seed)
+
+
+def _sparsevfc_preprocess(X, Y, M, beta, velocity_based_sampling, seed):
     valid_ind = np.where(np.isfinite(Y.sum(1)))[0]
     Xv, Yv = X[valid_ind], Y[valid_ind]
     if len(Xv) == 0:
@@ -732,3 +741,56 @@ def integrate_field(vf_dict, init_states, t_end=None, interpolation_num=250, dir
     if average in ("trajectory", True):
         traj = traj.mean(0, keepdims=True)
     return [times.copy() for _ in range(len(traj))], [traj[i] for i in range(len(traj))]
+
+
+# =====================================================================================================================
+# batched independent fits (BASELINE config 5: 32 organs x ~250 k cells, M = 500) - replicas only, no collective
+# =====================================================================================================================
+def SparseVFC_many(datasets, n_streams=4, device=None, distributed=False, group=None, **kwargs):
+    """Fit several independent vector fields concurrently: ``datasets`` = list of ``(X, Y, Grid)``.
+
+    Within a process the fits run on ``n_streams`` HIP streams (one host thread per stream; every libmvf call is
+    asynchronous on the calling thread's current stream and host syncs are per stream), so small fits overlap on the
+    GPU.  With ``distributed=True`` organ ``i`` is fitted by rank ``i % world`` and the result dicts are exchanged with
+    ``all_gather_object`` - there is no data-path collective ("replicas only").
+    Returns the list of result dicts in input order."""
+    import threading
+
+    rank, world = _dist_info(distributed, group)
+    mine = [i for i in range(len(datasets)) if i % world == rank]
+    results = {}
+    errors = []
+    if torch.cuda.is_available():
+        dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, min(n_streams, len(mine))))]
+    else:
+        dev, streams = None, [None]
+
+    def worker(slot):
+        try:
+            for pos in range(slot, len(mine), len(streams)):
+                i = mine[pos]
+                X, Y, Grid = datasets[i]
+                if streams[slot] is None:
+                    results[i] = SparseVFC(X, Y, Grid, device=device, **kwargs)
+                else:
+                    with torch.cuda.stream(streams[slot]):
+                        results[i] = SparseVFC(X, Y, Grid, device=dev, **kwargs)
+                        streams[slot].synchronize()
+        except Exception as exc:  # surfaced in the caller's thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(s_,)) for s_ in range(len(streams))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    if errors:
+        raise errors[0]
+    if world > 1:
+        import torch.distributed as dist
+
+        gathered = [None] * world
+        dist.all_gather_object(gathered, results, group=group)
+        results = {k_: v for part in gathered for k_, v in part.items()}
+    return [results[i] for i in range(len(datasets))]

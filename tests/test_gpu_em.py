@@ -300,6 +300,28 @@ def test_morphopath_fused_rk4_vs_dop853(st, golden, dtype, tol):
     assert np.abs(np.stack(pred2) - ref2).max() / np.abs(ref2).max() < tol
 
 
+def test_many_independent_fits_on_streams(st):
+    """BASELINE config 5 shape (independent organs, one per HIP stream): concurrent fits == sequential fits."""
+    from spateo_amd.vectorfield import SparseVFC_many
+    from spateo_amd._synthetic import ellipsoid_cloud, displacement_field
+
+    data = []
+    for k in range(6):
+        rng = np.random.default_rng(100 + k)
+        X = ellipsoid_cloud(rng, 3000 + 200 * k, rng.uniform(100, 400, 3))
+        V = displacement_field(X)
+        V = V / np.sqrt(np.mean(V**2)) + 0.05 * rng.standard_normal(X.shape)
+        data.append((X, V, X[:20]))
+    kw = dict(M=100, lambda_=3.0, MaxIter=8, dtype="float64")
+    seq = [st.SparseVFC(X, V, G, device="cuda:0", **kw) for X, V, G in data]
+    par = SparseVFC_many(data, n_streams=3, device="cuda:0", **kw)
+    assert len(par) == 6
+    for a, b in zip(seq, par):
+        np.testing.assert_array_equal(a["X_ctrl"], b["X_ctrl"])
+        assert _rel(b["V"], a["V"]) < 1e-10 and _rel(b["grid_V"], a["grid_V"]) < 1e-10
+        assert a["iteration"] == b["iteration"]
+
+
 def test_morphofield_missing_key_errors(st):
     ad = st.AnnDataLite(obsm={"align_spatial": np.zeros((3, 3))})
     ad.uns["bad"] = {"method": "nope"}

@@ -355,3 +355,18 @@ def test_morphopath_slots_and_accuracy(cpu_kernels, golden):
         st.tdr.morphopath(ad, vf_key="bad")
     with pytest.raises(Exception, match="not in ``anndata.uns``"):
         st.tdr.morphopath(ad, vf_key="absent")
+
+
+def test_sparsevfc_many_matches_sequential(cpu_kernels):
+    from spateo_amd.vectorfield import SparseVFC_many
+
+    data = []
+    for k in range(3):
+        X, V = _data(300 + 50 * k, seed=k)
+        data.append((X, V, X[:5]))
+    kw = dict(M=15, lambda_=3.0, MaxIter=5)
+    seq = [st.SparseVFC(X, V, G, **kw) for X, V, G in data]
+    par = SparseVFC_many(data, n_streams=2, **kw)
+    for a, b in zip(seq, par):
+        np.testing.assert_array_equal(a["V"], b["V"])
+        np.testing.assert_array_equal(a["grid_V"], b["grid_V"])
