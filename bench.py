@@ -113,13 +113,21 @@ def main():
                 f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus {args.gpus} ...`")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    # developer override: exercise the multi-rank code path on a ONE-GPU box (all ranks on cuda:0, gloo collectives,
+    # because RCCL refuses two ranks on one device).  Never set by the driver; numbers from it are meaningless.
+    one_dev = os.environ.get("MVF_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        if one_dev:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     from spateo_amd._kernels import HipKernels
     from spateo_amd._synthetic import make_config
