@@ -427,3 +427,51 @@ def test_two_ranks_sharing_one_gpu_match_the_oracle(st, tmp_path):
     assert int(r0["iteration"]) == ref["iteration"]
     assert _rel(r0["V"], ref["V"]) < 1e-5 and _rel(r0["grid_V"], ref["grid_V"]) < 1e-5
     np.testing.assert_allclose(r0["E"], ref["E_traj"], rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------- BASELINE full size
+def test_full_size_c4_invariants_float32(st):
+    """BASELINE config 4 at FULL size on one GPU (8 M cells x 3000 control points, float32 cells) - where the oracle
+    cannot run - through size-independent properties: the cached-U and the recompute Gram kernels agree bit for bit,
+    G is symmetric PSD (up to round-off), the EM statistics are consistent, and V == con_K(X, ctrl) @ C on sampled rows
+    (materialised kernel rows x float64 coefficients)."""
+    from spateo_amd._kernels import HipKernels
+    from spateo_amd._synthetic import make_config
+    from spateo_amd.vectorfield import SparseVFCEngine, sparsevfc_preprocess
+
+    X, V, M = make_config("C4")
+    valid, Xv, Yv, idx, ctrl, beta = sparsevfc_preprocess(X, V, M=M, seed=0)
+    N = len(Xv)
+    assert N == 8_000_000 and len(ctrl) == 3000
+    kern = HipKernels("cuda:0", "float32")
+    eng = SparseVFCEngine(Xv, Yv, ctrl, beta, dtype="float32", device="cuda:0", kernels=kern, cache_u=True)
+    assert eng.cached_u
+    eng.init_state(0.9)
+    np.testing.assert_allclose(eng.sigma2, np.sum(Yv**2) / (N * 3), rtol=1e-5)
+    E, tecr = eng.em_step(lambda_=0.02)
+    assert np.isfinite(E) and eng.sigma2 > 0 and 0.05 <= eng.gamma <= 0.95
+    st_ = eng.st.cpu().numpy()
+    assert 1e-5 * N * 0.999 <= st_[2] <= N and st_[3] <= N  # sum of floored P, #inliers
+    G_cached = eng.G.clone()
+    # the same Gram through the recompute kernel (cache dropped): identical bits
+    kern.drop_ublk()
+    G2 = torch.empty_like(eng.G)
+    R2 = torch.empty_like(eng.R[0])
+    kern.gram(eng.x4, eng.P, eng.y4[0], eng.ctrl4, eng.beta, G2, R2)
+    assert torch.equal(G2, G_cached)
+    assert torch.equal(R2, eng.R[0])
+    assert torch.equal(G2, G2.T)
+    ev = torch.linalg.eigvalsh(G2)
+    assert float(ev.min()) > -1e-10 * float(ev.max())
+    # V == U C on a sample of rows
+    rng = np.random.default_rng(0)
+    sel = torch.from_numpy(np.sort(rng.choice(N, 4096, replace=False))).to("cuda:0")
+    xs = eng.x4[sel][:, :3].contiguous()
+    cs = eng.ctrl4[:, :3].contiguous()
+    U = kern.con_k(xs, cs, eng.beta).double()
+    Vs = U @ eng.C[0]
+    got = eng.V4[0][sel][:, :3].double()
+    assert float((got - Vs).abs().max() / Vs.abs().max()) < 2e-4  # float32 storage of V + per-kernel K rounding
+    # residuals and sigma^2 are consistent with V
+    r_s = ((eng.y4[0][sel][:, :3].double() - got) ** 2).sum(1)
+    assert float((eng.r[sel].double() - r_s).abs().max() / r_s.abs().max()) < 1e-5
