@@ -187,7 +187,8 @@ def main():
     peak = PEAK_F32_MFMA_TFLOPS if f32mfma else PEAK_F64_MFMA_TFLOPS
     roofline = {
         "kernel": "gram_f32_kernel (v_mfma_f32_32x32x2_f32)" if f32mfma else
-                  ("gram_cached_kernel (v_mfma_f64_16x16x4_f64, float32 U streamed from HBM)" if eng.cached_u else
+                  (f"gram_cached_kernel<{'float' if args.dtype == 'float32' else 'double'}> (v_mfma_f64_16x16x4_f64, "
+                   f"cached {args.dtype} U streamed from HBM)" if eng.cached_u else
                    f"gram_f64acc_kernel<{'float' if args.dtype == 'float32' else 'double'}> (v_mfma_f64_16x16x4_f64)"),
         "bound": "mfma",
         "achieved": achieved,

@@ -107,17 +107,18 @@ int mvf_gram_stages(int stages, const void* x4, const void* P, const void* y4, i
                     int64_t m, double beta, double* G, double* R, void* workspace, size_t workspace_bytes,
                     mvf_dtype dtype, void* stream);
 
-/* Cached-U variant of the float32 Gram (MVF_F32 only).  U = con_K(x, ctrl) is constant across EM iterations (only P
- * changes), so when HBM has room (mvf_ublk_bytes = 4 * roundup(n,256) * roundup(m,128) bytes; 96 GB at 8 M x 3000) the
- * float32 kernel values are materialised once per fit in the MFMA-operand-shaped layout Ublk[m/16][n][16] and the
- * Gram kernel streams them (9 coalesced dword loads per 16 MFMAs) instead of regenerating them.  Same values, same
- * float64 accumulation, same outputs as mvf_gram; `stages` as in mvf_gram_stages. */
-size_t mvf_ublk_bytes(int64_t n, int64_t m);
+/* Cached-U variant of the Gram kernel.  U = con_K(x, ctrl) is constant across EM iterations (only P changes), so when
+ * HBM has room (mvf_ublk_bytes = sizeof(dtype) * roundup(n,256) * roundup(m,128) bytes; 98 GB at 8 M x 3000 float32)
+ * the kernel values are materialised once per fit in the MFMA-operand-shaped layout Ublk[m/16][n][16] and the Gram
+ * kernel streams them (9 coalesced loads per 16 MFMAs) instead of regenerating them - VALU work is additive to f64
+ * MFMA time on gfx950, and in float64 mode the regenerated exp alone makes the kernel VALU-bound.  Same values, same
+ * float64 accumulation, bit-identical outputs to mvf_gram; `stages` as in mvf_gram_stages. */
+size_t mvf_ublk_bytes(int64_t n, int64_t m, mvf_dtype dtype);
 int mvf_ublk_build(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, void* ublk, size_t ublk_bytes,
-                   void* stream);
+                   mvf_dtype dtype, void* stream);
 int mvf_gram_cached(int stages, const void* ublk, const void* x4, const void* P, const void* y4, int64_t n,
                     const void* ctrl4, int64_t m, double beta, double* G, double* R, void* workspace,
-                    size_t workspace_bytes, void* stream);
+                    size_t workspace_bytes, mvf_dtype dtype, void* stream);
 
 /* ---- coefficient solve:  (G + lambda_sigma2 * K + jitter * mean(diag) * I) C = R  ------------------------------
  * Replaces: dynamo `lstsq_solver(lhs, rhs, "scipy")` as Spateo calls it (sparsevfc.py:110,194,250).  Blocked

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void gram_f64acc_kernel(const typename Vec4
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// Cached-U variant (float32 mode).  U = con_K(x, ctrl) does not change across EM iterations - only P does - so when
+// Cached-U variant (both cell dtypes).  U = con_K(x, ctrl) does not change across EM iterations - only P does - so when
 // HBM has room (4 n M bytes: 96 GB at 8 M x 3000) the float32 kernel values are materialised ONCE per fit, in the
 // blocked layout  Ublk[cb][cell][16]  (cb = control point / 16), which is exactly the v_mfma_f64_16x16x4 operand
 // shape: for one MFMA block and one k-step the 64 lanes read 4 cells x 16 control points = 256 contiguous bytes.
@@ -326,42 +326,47 @@ __global__ __launch_bounds__(256, 1) void gram_f64acc_kernel(const typename Vec4
 // ----------------------------------------------------------------------------------------------------------------
 constexpr int UB = 16;  // control points per cached block
 
-__global__ __launch_bounds__(256) void ublk_build_kernel(const float4* __restrict__ x4, int64_t n, int64_t n_pad,
-                                                         const float4* __restrict__ ctrl4, int64_t m, int64_t m_pad,
-                                                         float s, int cb_per_block, float* __restrict__ ublk) {
-    extern __shared__ __attribute__((aligned(16))) float4 sctrl[];  // cb_per_block * 16 scaled control points
+template <typename T>
+__global__ __launch_bounds__(256) void ublk_build_kernel(const typename Vec4<T>::type* __restrict__ x4, int64_t n,
+                                                         int64_t n_pad, const typename Vec4<T>::type* __restrict__ ctrl4,
+                                                         int64_t m, int64_t m_pad, T s, int cb_per_block,
+                                                         T* __restrict__ ublk) {
+    using V4 = typename Vec4<T>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ublk_smem[];
+    V4* sctrl = reinterpret_cast<V4*>(ublk_smem);  // cb_per_block * 16 scaled control points
     const int64_t cb0 = (int64_t)blockIdx.y * cb_per_block;
     const int ncb = (int)min((int64_t)cb_per_block, m_pad / UB - cb0);
     for (int j = threadIdx.x; j < ncb * UB; j += 256) {
         const int64_t c = cb0 * UB + j;
         if (c < m) {
-            const float4 cv = ctrl4[c];
-            sctrl[j] = float4{cv.x * s, cv.y * s, cv.z * s, 1.f};
+            const V4 cv = ctrl4[c];
+            sctrl[j] = V4{cv.x * s, cv.y * s, cv.z * s, 1};
         } else {
-            sctrl[j] = float4{0.f, 0.f, 0.f, 0.f};  // w = 0 marks a padded control point
+            sctrl[j] = V4{0, 0, 0, 0};  // w = 0 marks a padded control point
         }
     }
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pad) return;
     const bool live = i < n;
-    float px = 0.f, py = 0.f, pz = 0.f;
+    T px = 0, py = 0, pz = 0;
     if (live) {
-        const float4 xv = x4[i];
+        const V4 xv = x4[i];
         px = xv.x * s, py = xv.y * s, pz = xv.z * s;
     }
+    constexpr int PER = 16 / sizeof(T);  // elements per 16-byte store
+    typedef T vec_t __attribute__((ext_vector_type(PER)));
     for (int b = 0; b < ncb; ++b) {
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        f4 o[4];
+        vec_t o[UB / PER];
 #pragma unroll
         for (int j = 0; j < UB; ++j) {
-            const float4 cv = sctrl[b * UB + j];
-            const float k = kernel_value(px, py, pz, cv.x, cv.y, cv.z);
-            o[j >> 2][j & 3] = (live && cv.w != 0.f) ? k : 0.f;
+            const V4 cv = sctrl[b * UB + j];
+            const T k = kernel_value(px, py, pz, cv.x, cv.y, cv.z);
+            o[j / PER][j % PER] = (live && cv.w != 0) ? k : T(0);
         }
-        f4* dst = reinterpret_cast<f4*>(ublk + ((cb0 + b) * n_pad + i) * UB);
+        vec_t* dst = reinterpret_cast<vec_t*>(ublk + ((cb0 + b) * n_pad + i) * UB);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) __builtin_nontemporal_store(o[q], dst + q);
+        for (int q = 0; q < UB / PER; ++q) __builtin_nontemporal_store(o[q], dst + q);
     }
 }
 
@@ -373,7 +378,8 @@ constexpr int UG = MVF_UG;  // k-steps (of 4 cells) per software-pipeline group
 #ifndef MVF_CACHED_WPS
 #define MVF_CACHED_WPS 2
 #endif
-__global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const float* __restrict__ ublk, const float* __restrict__ P,
+template <typename T>
+__global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const T* __restrict__ ublk, const T* __restrict__ P,
                                                              int64_t n, int64_t n_pad, int nt, int npairs,
                                                              int64_t slice_len, double* __restrict__ partial) {
     const int pair = blockIdx.x % npairs;
@@ -386,8 +392,8 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
     const int wi = wave >> 1, wj = wave & 1;
     const int li = lane & 15, lk = lane >> 4;
 
-    const float* pa[4];
-    const float* pb[4];
+    const T* pa[4];
+    const T* pb[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int64_t cba = ((int64_t)ti * GT + wi * 64) / UB + a;
@@ -402,18 +408,18 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-    float ua[2][UG][4], ub[2][UG][4], pp[2][UG];
+    T ua[2][UG][4], ub[2][UG][4], pp[2][UG];
     const int ngroups = (int)((n1 - n0) / (4 * UG));  // slices are multiples of 256 cells: ngroups is even
 
-    auto load_group = [&](int g, float(&A)[UG][4], float(&B)[UG][4], float(&Pq)[UG]) {
+    auto load_group = [&](int g, T(&A)[UG][4], T(&B)[UG][4], T(&Pq)[UG]) {
 #pragma unroll
         for (int q = 0; q < UG; ++q) {
             const int64_t off = ((int64_t)g * UG + q) * (4 * UB);
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
 #ifdef MVF_PROBE_NO_LOAD
-                A[q][a] = 0.5f + (float)lane * 1e-3f + (float)off * 1e-9f;
-                B[q][a] = 0.25f + (float)lane * 1e-3f;
+                A[q][a] = (T)(0.5 + lane * 1e-3 + off * 1e-9);
+                B[q][a] = (T)(0.25 + lane * 1e-3);
 #else
                 A[q][a] = pa[a][off];
                 B[q][a] = pb[a][off];
@@ -421,13 +427,13 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
             }
             const int64_t cell = n0 + ((int64_t)g * UG + q) * 4 + lk;
 #if defined(MVF_PROBE_NO_LOAD) || defined(MVF_PROBE_NO_P)
-            Pq[q] = 1.0f;
+            Pq[q] = T(1);
 #else
-            Pq[q] = cell < n ? P[cell] : 0.f;
+            Pq[q] = cell < n ? P[cell] : T(0);
 #endif
         }
     };
-    auto compute_group = [&](const float(&A)[UG][4], const float(&B)[UG][4], const float(&Pq)[UG]) {
+    auto compute_group = [&](const T(&A)[UG][4], const T(&B)[UG][4], const T(&Pq)[UG]) {
 #pragma unroll
         for (int q = 0; q < UG; ++q) {
             double fa[4], fb[4];
@@ -659,34 +665,42 @@ extern "C" int mvf_gram_stages(int stages, const void* x4, const void* P, const 
 static inline int64_t ublk_npad(int64_t n) { return cdiv(n, GCHUNK) * GCHUNK; }
 static inline int64_t ublk_mpad(int64_t m) { return cdiv(m, GT) * GT; }
 
-extern "C" size_t mvf_ublk_bytes(int64_t n, int64_t m) {
+extern "C" size_t mvf_ublk_bytes(int64_t n, int64_t m, mvf_dtype dtype) {
     if (n <= 0 || m <= 0) return 0;
-    return (size_t)ublk_npad(n) * (size_t)ublk_mpad(m) * sizeof(float);
+    return (size_t)ublk_npad(n) * (size_t)ublk_mpad(m) * (dtype == MVF_F64 ? sizeof(double) : sizeof(float));
 }
 
 extern "C" int mvf_ublk_build(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, void* ublk,
-                              size_t ublk_bytes, void* stream) {
+                              size_t ublk_bytes, mvf_dtype dtype, void* stream) {
     MVF_REQUIRE(n > 0 && m > 0, "mvf_ublk_build: need n > 0 and m > 0");
+    MVF_REQUIRE(dtype == MVF_F32 || dtype == MVF_F64, "mvf_ublk_build: bad dtype %d", (int)dtype);
     MVF_REQUIRE(beta >= 0.0 && std::isfinite(beta), "mvf_ublk_build: beta must be finite and >= 0");
     MVF_REQUIRE(x4 && ctrl4 && ublk, "mvf_ublk_build: null pointer");
-    MVF_REQUIRE(ublk_bytes >= mvf_ublk_bytes(n, m), "mvf_ublk_build: buffer too small (%zu < %zu)", ublk_bytes,
-                mvf_ublk_bytes(n, m));
+    MVF_REQUIRE(ublk_bytes >= mvf_ublk_bytes(n, m, dtype), "mvf_ublk_build: buffer too small (%zu < %zu)", ublk_bytes,
+                mvf_ublk_bytes(n, m, dtype));
     hipStream_t st = (hipStream_t)stream;
     const int64_t n_pad = ublk_npad(n), m_pad = ublk_mpad(m);
     const int cb_per_block = 32;  // 512 control points (8 KiB of LDS) per workgroup column
     dim3 grid((unsigned)(n_pad / 256), (unsigned)cdiv(m_pad / UB, cb_per_block));
     MVF_REQUIRE(grid.y <= 65535, "mvf_ublk_build: m too large");
-    const float s = (float)std::sqrt(beta * LOG2E);
-    hipLaunchKernelGGL(ublk_build_kernel, grid, dim3(256), cb_per_block * UB * sizeof(float4), st, (const float4*)x4, n,
-                       n_pad, (const float4*)ctrl4, m, m_pad, s, cb_per_block, (float*)ublk);
+    const double s = std::sqrt(beta * LOG2E);
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(ublk_build_kernel<float>, grid, dim3(256), cb_per_block * UB * sizeof(float4), st,
+                           (const float4*)x4, n, n_pad, (const float4*)ctrl4, m, m_pad, (float)s, cb_per_block,
+                           (float*)ublk);
+    else
+        hipLaunchKernelGGL(ublk_build_kernel<double>, grid, dim3(256), cb_per_block * UB * sizeof(double4), st,
+                           (const double4*)x4, n, n_pad, (const double4*)ctrl4, m, m_pad, s, cb_per_block,
+                           (double*)ublk);
     MVF_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int mvf_gram_cached(int stages, const void* ublk, const void* x4, const void* P, const void* y4, int64_t n,
                                const void* ctrl4, int64_t m, double beta, double* G, double* R, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               size_t workspace_bytes, mvf_dtype dtype, void* stream) {
     MVF_REQUIRE(n > 0 && m > 0, "mvf_gram_cached: need n > 0 and m > 0");
+    MVF_REQUIRE(dtype == MVF_F32 || dtype == MVF_F64, "mvf_gram_cached: bad dtype %d", (int)dtype);
     MVF_REQUIRE(stages > 0 && stages <= 15, "mvf_gram_cached: bad stage mask %d", stages);
     MVF_REQUIRE(ublk && P, "mvf_gram_cached: null pointer");
     hipStream_t st = (hipStream_t)stream;
@@ -697,13 +711,17 @@ extern "C" int mvf_gram_cached(int stages, const void* ublk, const void* x4, con
                     workspace_bytes, need);
         MVF_REQUIRE((int64_t)p.nslices * p.npairs < (1LL << 31), "mvf_gram_cached: too many jobs");
         const unsigned njobs = (unsigned)(p.nslices * p.npairs);
-        hipLaunchKernelGGL(gram_cached_kernel, dim3(njobs), dim3(256), 0, st, (const float*)ublk, (const float*)P, n,
-                           ublk_npad(n), p.nt, p.npairs, p.slice_len, (double*)workspace);
+        if (dtype == MVF_F32)
+            hipLaunchKernelGGL(gram_cached_kernel<float>, dim3(njobs), dim3(256), 0, st, (const float*)ublk,
+                               (const float*)P, n, ublk_npad(n), p.nt, p.npairs, p.slice_len, (double*)workspace);
+        else
+            hipLaunchKernelGGL(gram_cached_kernel<double>, dim3(njobs), dim3(256), 0, st, (const double*)ublk,
+                               (const double*)P, n, ublk_npad(n), p.nt, p.npairs, p.slice_len, (double*)workspace);
         MVF_LAUNCH_CHECK();
     }
     const int rest = stages & (MVF_GRAM_STAGE_RHS | MVF_GRAM_STAGE_REDUCE | MVF_GRAM_STAGE_REDUCE_RHS);
     if (rest)
-        return mvf_gram_stages(rest, x4, P, y4, n, ctrl4, m, beta, G, R, workspace, workspace_bytes, MVF_F32, stream);
+        return mvf_gram_stages(rest, x4, P, y4, n, ctrl4, m, beta, G, R, workspace, workspace_bytes, dtype, stream);
     return 0;
 }
 

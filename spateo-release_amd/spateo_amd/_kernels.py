@@ -109,20 +109,21 @@ class HipKernels:
                                         self.cdtype, self._stream()), "mvf_estep_p")
 
     def ublk_bytes(self, n, m):
-        return int(self.lib.mvf_ublk_bytes(n, m))
+        return int(self.lib.mvf_ublk_bytes(n, m, self.cdtype))
 
     def build_ublk(self, x4, ctrl4, beta):
         """Materialise the float32 kernel values once per fit (U is constant across EM iterations); later `gram`
         calls with the same (x4, ctrl4, beta) stream them instead of regenerating them."""
-        if self.tdtype != torch.float32:
-            raise TypeError("the cached-U Gram path is float32 only")
         n, m = x4.shape[0], ctrl4.shape[0]
         need = self.ublk_bytes(n, m)
         self._ublk = None
-        self._ublk = torch.empty(need // 4, dtype=torch.float32, device=self.device)
+        self._ublk = torch.empty(need // self._ublk_itemsize(), dtype=self.tdtype, device=self.device)
         _lib.check(self.lib.mvf_ublk_build(_ptr(x4), n, _ptr(ctrl4), m, float(beta), _ptr(self._ublk), need,
-                                           self._stream()), "mvf_ublk_build")
+                                           self.cdtype, self._stream()), "mvf_ublk_build")
         self._ublk_key = (x4.data_ptr(), ctrl4.data_ptr(), n, m, float(beta))
+
+    def _ublk_itemsize(self):
+        return 4 if self.tdtype == torch.float32 else 8
 
     def drop_ublk(self):
         self._ublk = None
@@ -140,7 +141,8 @@ class HipKernels:
         cached = self._ublk is not None and self._ublk_key == (x4.data_ptr(), ctrl4.data_ptr(), n, m, float(beta))
         if cached:
             def run(stages):
-                _lib.check(self.lib.mvf_gram_cached(stages, _ptr(self._ublk), *args, self._stream()), "mvf_gram_cached")
+                _lib.check(self.lib.mvf_gram_cached(stages, _ptr(self._ublk), *args, self.cdtype, self._stream()),
+                           "mvf_gram_cached")
         else:
             def run(stages):
                 _lib.check(self.lib.mvf_gram_stages(stages, *args, self.cdtype, self._stream()), "mvf_gram_stages")

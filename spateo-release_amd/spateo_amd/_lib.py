@@ -34,9 +34,9 @@ SIGNATURES = {
     "mvf_gram_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "mvf_gram": (_i, [_p, _p, _p, _i64, _p, _i64, _d, _p, _p, _p, _sz, _i, _p]),
     "mvf_gram_stages": (_i, [_i, _p, _p, _p, _i64, _p, _i64, _d, _p, _p, _p, _sz, _i, _p]),
-    "mvf_ublk_bytes": (_sz, [_i64, _i64]),
-    "mvf_ublk_build": (_i, [_p, _i64, _p, _i64, _d, _p, _sz, _p]),
-    "mvf_gram_cached": (_i, [_i, _p, _p, _p, _p, _i64, _p, _i64, _d, _p, _p, _p, _sz, _p]),
+    "mvf_ublk_bytes": (_sz, [_i64, _i64, _i]),
+    "mvf_ublk_build": (_i, [_p, _i64, _p, _i64, _d, _p, _sz, _i, _p]),
+    "mvf_gram_cached": (_i, [_i, _p, _p, _p, _p, _i64, _p, _i64, _d, _p, _p, _p, _sz, _i, _p]),
     "mvf_solve_workspace_bytes": (_sz, [_i64, _i]),
     "mvf_solve": (_i, [_p, _p, _d, _d, _p, _i64, _i, _p, _p, _p, _sz, _p]),
     "mvf_quadform": (_i, [_p, _p, _i64, _i, _p, _p]),

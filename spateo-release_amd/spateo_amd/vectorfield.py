@@ -189,10 +189,10 @@ class SparseVFCEngine:
         self.r = None
         # Cholesky jitter (relative to the mean diagonal): start with none - then the solve equals the reference's
         # lstsq wherever the system has full numerical rank - and escalate only when a pivot fails (sticky afterwards)
-        # U = con_K(X, ctrl) is constant across EM iterations: cache its float32 values for the Gram kernel when HBM
-        # has room ("auto": needs 4 n M bytes plus headroom), else the Gram kernel regenerates them every iteration
+        # U = con_K(X, ctrl) is constant across EM iterations: cache its values (cell dtype) for the Gram kernel when HBM
+        # has room ("auto": sizeof(dtype) n M bytes plus headroom), else the Gram kernel regenerates them every iteration
         self.cached_u = False
-        if dtype == "float32" and cache_u and hasattr(k, "build_ublk") and self.n_local and M:
+        if cache_u and hasattr(k, "build_ublk") and self.n_local and M:
             need = k.ublk_bytes(self.n_local, M)
             free = torch.cuda.mem_get_info(k.device)[0] if cache_u == "auto" else None
             if free is None or need + (8 << 30) < free:

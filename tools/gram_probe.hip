@@ -18,9 +18,9 @@ int main(int argc, char** argv) {
     hipMemcpy(p, hp.data(), n*4, hipMemcpyHostToDevice); hipMemcpy(y, hy.data(), n*16, hipMemcpyHostToDevice);
     hipMalloc(&G, m*m*8); hipMalloc(&R, m*3*8);
     size_t wsb = mvf_gram_workspace_bytes(n, m, MVF_F32); hipMalloc(&ws, wsb);
-    size_t ubb = mvf_ublk_bytes(n, m); hipMalloc(&ub, ubb);
+    size_t ubb = mvf_ublk_bytes(n, m, MVF_F32); hipMalloc(&ub, ubb);
     const double beta = 2.7e-6;
-    if (mvf_ublk_build(x, n, c, m, beta, ub, ubb, nullptr)) { printf("build failed: %s\n", mvf_last_error()); return 1; }
+    if (mvf_ublk_build(x, n, c, m, beta, ub, ubb, MVF_F32, nullptr)) { printf("build failed: %s\n", mvf_last_error()); return 1; }
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const double flops = (double)n * m * (m + 1);
@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
         printf("%-28s %8.2f ms  %6.1f TF(alg)\n", name, ms, flops / ms / 1e9);
     };
     timeit("recompute f64acc<float>", [&] { mvf_gram_stages(1, x, p, y, n, c, m, beta, G, R, ws, wsb, MVF_F32, nullptr); });
-    timeit("cached-U", [&] { mvf_gram_cached(1, ub, x, p, y, n, c, m, beta, G, R, ws, wsb, nullptr); });
-    timeit("ublk_build", [&] { mvf_ublk_build(x, n, c, m, beta, ub, ubb, nullptr); });
+    timeit("cached-U", [&] { mvf_gram_cached(1, ub, x, p, y, n, c, m, beta, G, R, ws, wsb, MVF_F32, nullptr); });
+    timeit("ublk_build", [&] { mvf_ublk_build(x, n, c, m, beta, ub, ubb, MVF_F32, nullptr); });
     return 0;
 }
