@@ -382,6 +382,10 @@ template <typename T>
 __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const T* __restrict__ ublk, const T* __restrict__ P,
                                                              int64_t n, int64_t n_pad, int nt, int npairs,
                                                              int64_t slice_len, double* __restrict__ partial) {
+    // Wave tile 32 x 128 (NA = 2 row blocks x NB = 8 column blocks of 16): the four waves of the workgroup stack in
+    // the row direction and all read the same 8 column panels (L1 hits).  Per k-step a lane does 10 loads and only
+    // TWO v_mul_f64 (P K, kept exact) for 16 MFMAs - the f64 VALU work is what steals MFMA time on gfx950.
+    constexpr int NA = 2, NB = 8;
     const int pair = blockIdx.x % npairs;
     const int64_t slice = blockIdx.x / npairs;
     int ti, tj;
@@ -389,42 +393,45 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
     const int64_t n0 = slice * slice_len;
     const int64_t n1 = min(n_pad, n0 + slice_len);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave >> 1, wj = wave & 1;
     const int li = lane & 15, lk = lane >> 4;
 
-    const T* pa[4];
-    const T* pb[4];
+    const T* pa[NA];
+    const T* pb[NB];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int64_t cba = ((int64_t)ti * GT + wi * 64) / UB + a;
-        const int64_t cbb = ((int64_t)tj * GT + wj * 64) / UB + a;
+    for (int a = 0; a < NA; ++a) {
+        const int64_t cba = ((int64_t)ti * GT + wave * 32) / UB + a;
         pa[a] = ublk + (cba * n_pad + n0 + lk) * UB + li;
-        pb[a] = ublk + (cbb * n_pad + n0 + lk) * UB + li;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int64_t cbb = ((int64_t)tj * GT) / UB + b;
+        pb[b] = ublk + (cbb * n_pad + n0 + lk) * UB + li;
     }
 
-    f64x4 acc[4][4];
+    f64x4 acc[NA][NB];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < NB; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-    T ua[2][UG][4], ub[2][UG][4], pp[2][UG];
+    T ua[2][UG][NA], ub[2][UG][NB], pp[2][UG];
     const int ngroups = (int)((n1 - n0) / (4 * UG));  // slices are multiples of 256 cells: ngroups is even
 
-    auto load_group = [&](int g, T(&A)[UG][4], T(&B)[UG][4], T(&Pq)[UG]) {
+    auto load_group = [&](int g, T(&A)[UG][NA], T(&B)[UG][NB], T(&Pq)[UG]) {
 #pragma unroll
         for (int q = 0; q < UG; ++q) {
             const int64_t off = ((int64_t)g * UG + q) * (4 * UB);
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
 #ifdef MVF_PROBE_NO_LOAD
-                A[q][a] = (T)(0.5 + lane * 1e-3 + off * 1e-9);
-                B[q][a] = (T)(0.25 + lane * 1e-3);
+#pragma unroll
+            for (int a = 0; a < NA; ++a) A[q][a] = (T)(0.5 + lane * 1e-3 + off * 1e-9);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) B[q][b] = (T)(0.25 + lane * 1e-3);
 #else
-                A[q][a] = pa[a][off];
-                B[q][a] = pb[a][off];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) A[q][a] = pa[a][off];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) B[q][b] = pb[b][off];
 #endif
-            }
             const int64_t cell = n0 + ((int64_t)g * UG + q) * 4 + lk;
 #if defined(MVF_PROBE_NO_LOAD) || defined(MVF_PROBE_NO_P)
             Pq[q] = T(1);
@@ -433,28 +440,29 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
 #endif
         }
     };
-    auto compute_group = [&](const T(&A)[UG][4], const T(&B)[UG][4], const T(&Pq)[UG]) {
+    auto compute_group = [&](const T(&A)[UG][NA], const T(&B)[UG][NB], const T(&Pq)[UG]) {
 #pragma unroll
         for (int q = 0; q < UG; ++q) {
-            double fa[4], fb[4];
+            double fa[NA], fb[NB];
             const double pd = (double)Pq[q];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
+            for (int a = 0; a < NA; ++a) {
 #ifdef MVF_PROBE_NO_P
                 fa[a] = (double)A[q][a];
 #else
                 fa[a] = (double)A[q][a] * pd;  // exact in float64
 #endif
-                fb[a] = (double)B[q][a];
             }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) fb[b] = (double)B[q][b];
 #ifdef MVF_PROBE_NO_MFMA
 #pragma unroll
-            for (int a = 0; a < 4; ++a) acc[a][a][0] += fa[a] + fb[a];
+            for (int a = 0; a < NA; ++a) acc[a][a][0] += fa[a] + fb[a];
 #else
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < NA; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < NB; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
 #endif
         }
@@ -470,13 +478,13 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
 
     double* out = partial + ((size_t)slice * npairs + pair) * (size_t)(GT * GT);
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = wi * 64 + a * 16 + lk + 4 * r;
-                const int col = wj * 64 + b * 16 + li;
+                const int row = wave * 32 + a * 16 + lk + 4 * r;
+                const int col = b * 16 + li;
                 out[row * GT + col] = acc[a][b][r];
             }
 }
