@@ -199,7 +199,7 @@ class SparseVFCEngine:
                 k.build_ublk(self.x4, self.ctrl4, self.beta)
                 self.cached_u = True
         self.jitter = 0.0
-        self.jitter_first = 1e-15 if dtype == "float64" else 1e-12
+        self.jitter_first = 1e-15  # both modes: G is accumulated in float64 (exact for the float32 kernel values)
         self.jitter_max = 1e-3
         self.solve_retries = 0
         self.E = 1.0

@@ -1,0 +1,27 @@
+"""Developer probe (GPU): float32 mode vs float64 mode at scale (1 M cells x 3000 control points, lambda 0.02 and 3),
+where the CPU oracle cannot run: max relative difference of the learned field after a fixed number of EM iterations."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "spateo-release_amd"))
+import numpy as np, torch
+from spateo_amd._synthetic import make_config
+from spateo_amd.vectorfield import SparseVFCEngine, sparsevfc_preprocess
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+X, V, M = make_config("C4", N=N)
+valid, Xv, Yv, idx, ctrl, beta = sparsevfc_preprocess(X, V, M=M, seed=0)
+for lam in (0.02, 3.0):
+    res = {}
+    for dt in ("float64", "float32"):
+        eng = SparseVFCEngine(Xv, Yv, ctrl, beta, dtype=dt, device="cuda:0")
+        eng.init_state(0.9)
+        for it in range(10):
+            eng.em_step(lambda_=lam)
+        Vg, Pg, Cg = eng.results()
+        res[dt] = (Vg, eng.sigma2, eng.jitter, eng.solve_retries, eng.E)
+        del eng; torch.cuda.empty_cache()
+    a, b = res["float64"], res["float32"]
+    rel = np.abs(a[0] - b[0]).max() / np.abs(a[0]).max()
+    rms = np.sqrt(np.mean((a[0] - b[0]) ** 2)) / np.sqrt(np.mean(a[0] ** 2))
+    print(f"N={N} M={M} lambda={lam}: V max-rel diff f32 vs f64 = {rel:.2e} (rms {rms:.2e}); sigma2 {a[1]:.6g} vs {b[1]:.6g}; "
+          f"jitter f64 {a[2]:g} ({a[3]} retries) f32 {b[2]:g} ({b[3]} retries); E {a[4]:.8g} vs {b[4]:.8g}")
