@@ -292,11 +292,17 @@ __global__ __launch_bounds__(256, 1) void gram_f64acc_kernel(const typename Vec4
                 fa[a] = (double)kernel_value(cell.x, cell.y, cell.z, ax[a], ay[a], az[a]) * (double)cell.w;
                 fb[a] = (double)kernel_value(cell.x, cell.y, cell.z, bx[a], by[a], bz[a]);
             }
+#ifdef MVF_PROBE_SETPRIO_RECOMPUTE
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+#ifdef MVF_PROBE_SETPRIO_RECOMPUTE
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         if (c + 1 < nchunks) cells[(c + 1) & 1][tid] = stage;
     }
@@ -459,11 +465,19 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
 #pragma unroll
             for (int a = 0; a < NA; ++a) acc[a][a][0] += fa[a] + fb[a];
 #else
+            // the two waves of a SIMD run out of phase (one converting / multiplying the next operands, one issuing
+            // MFMAs): raising the priority of the MFMA cluster keeps the matrix pipe fed (+2.5 % measured)
+#ifndef MVF_PROBE_NO_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+#ifndef MVF_PROBE_NO_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
 #endif
         }
     };
