@@ -62,6 +62,8 @@ def bandwidth_selector(X: np.ndarray) -> float:
 
     n = X.shape[0]
     k = max(2, int(0.2 * n))
+    if k > n:  # same condition and exception type as the sklearn kNN the reference goes through (a single control point)
+        raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {k}, n_samples_fit = {n}")
     distances, _ = cKDTree(X).query(X, k=k)
     d = np.mean(distances[:, 1:]) / 1.5
     return float(np.sqrt(2) * d)
@@ -443,6 +445,10 @@ def SparseVFC(
         X, Y, M=M, beta=beta, velocity_based_sampling=velocity_based_sampling, seed=seed
     )
     N = len(Xv)
+    if len(ctrl_pts) < 2:
+        # reference behaviour: con_K(ctrl, ctrl) of a single control point is flattened to 1-D (gaussian_process.py:23-24)
+        # and the energy term C.T.dot(K).dot(C) then fails with a ValueError
+        raise ValueError("SparseVFC needs at least 2 control points (shapes (3,) and (1,3) not aligned in the reference)")
     rank, world = _dist_info(distributed, group)
     lo, hi = shard_bounds(N, rank, world)
     eng = SparseVFCEngine(Xv[lo:hi], Yv[lo:hi], ctrl_pts, beta, dtype=dtype, device=device, distributed=distributed,

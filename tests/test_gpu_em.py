@@ -173,6 +173,20 @@ def test_sparsevfc_wide_and_narrow_outputs(st, dtype, dy):
     np.testing.assert_allclose(got["sigma2"], ref["sigma2"], rtol=TOL[dtype])
 
 
+def test_sparsevfc_tiny_inputs(st):
+    """Fewer cells than one 128-wide tile / one 256-cell stage; M clipped to the unique rows; explicit beta."""
+    rng = np.random.default_rng(0)
+    X, Y = rng.standard_normal((5, 3)), rng.standard_normal((5, 3)) * 0.1
+    kw = dict(lambda_=3.0, lstsq_method="scipy", MaxIter=3)
+    for Xi, Yi, M, extra in ((X, Y, 3, {}), (X[:2], Y[:2], 5, {}), (X, Y, 2, {"beta": 0.3})):
+        ref = svo.SparseVFC(Xi, Yi, Xi, M=M, **kw, **extra)
+        for dtype, tol in (("float64", 1e-6), ("float32", 1e-3)):
+            got = st.SparseVFC(Xi, Yi, Xi, M=M, dtype=dtype, device="cuda:0", **kw, **extra)
+            assert got["iteration"] == ref["iteration"] and got["V"].shape == ref["V"].shape
+            np.testing.assert_allclose(got["V"], ref["V"], rtol=tol, atol=tol * np.abs(ref["V"]).max())
+            np.testing.assert_allclose(got["grid_V"], ref["grid_V"], rtol=tol, atol=tol * np.abs(ref["V"]).max())
+
+
 def test_sparsevfc_errors(st):
     X, V = _c2(100)
     with pytest.raises(NotImplementedError):

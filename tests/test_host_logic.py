@@ -370,3 +370,33 @@ def test_sparsevfc_many_matches_sequential(cpu_kernels):
     for a, b in zip(seq, par):
         np.testing.assert_array_equal(a["V"], b["V"])
         np.testing.assert_array_equal(a["grid_V"], b["grid_V"])
+
+
+def test_degenerate_inputs_behave_like_the_reference(cpu_kernels):
+    """Tiny / degenerate inputs: same results or the same exception type as the oracle (= dynamo through sklearn/NumPy)."""
+    rng = np.random.default_rng(0)
+    X, Y = rng.standard_normal((5, 3)), rng.standard_normal((5, 3)) * 0.1
+    kw = dict(lambda_=3.0, lstsq_method="scipy", MaxIter=3)
+    for Xi, Yi, M in ((X, Y, 3), (X[:2], Y[:2], 5)):  # fewer cells than a tile; M clipped to the 2 unique rows
+        ref = svo.SparseVFC(Xi, Yi, None, M=M, **kw)
+        got = st.SparseVFC(Xi, Yi, None, M=M, _kernels=cpu_kernels, **kw)
+        assert got["X_ctrl"].shape == ref["X_ctrl"].shape and got["iteration"] == ref["iteration"]
+        np.testing.assert_allclose(got["V"], ref["V"], rtol=1e-7, atol=1e-12)
+    cases = [
+        (X, Y, 1),                           # one control point: the kNN bandwidth rule needs >= 2
+        (X[:1], Y[:1], 5),                   # one cell
+        (np.zeros((6, 3)), Y[:1].repeat(6, 0), 5),  # all cells at one position -> one unique row
+        (X, np.zeros((5, 3)), 3),            # zero velocities: sampling probabilities are NaN
+        (np.zeros((0, 3)), np.zeros((0, 3)), 3),     # empty
+    ]
+    for Xi, Yi, M in cases:
+        with pytest.raises(ValueError):
+            svo.SparseVFC(Xi, Yi, None, M=M, **kw)
+        with pytest.raises(ValueError):
+            st.SparseVFC(Xi, Yi, None, M=M, _kernels=cpu_kernels, **kw)
+    # an explicit beta bypasses the bandwidth rule, but a single control point still fails in the reference (its
+    # 1 x 1 K is flattened to 1-D and the energy term cannot be formed): ValueError in both
+    with pytest.raises(ValueError):
+        svo.SparseVFC(X, Y, None, M=1, beta=0.3, **kw)
+    with pytest.raises(ValueError):
+        st.SparseVFC(X, Y, None, M=1, beta=0.3, _kernels=cpu_kernels, **kw)
