@@ -263,10 +263,19 @@ class SparseVFCEngine:
         ls2 = lambda_ * self.sigma2
         while True:
             fail = 0
-            for g in range(self.ng):
-                k.solve(self.G, self.K, ls2, self.jitter, self.R[g], self.C_new[g], self.info)
-                if g + 1 < self.ng:
-                    fail = max(fail, int(self.info.cpu()[0]))
+            if self.ng == 1:
+                k.solve(self.G, self.K, ls2, self.jitter, self.R[0], self.C_new[0], self.info)
+            else:
+                # wide Y: one factorisation serves two 3-column groups (mvf_solve takes up to 8 right-hand sides)
+                for g0 in range(0, self.ng, 2):
+                    gs = list(range(g0, min(g0 + 2, self.ng)))
+                    Rcat = torch.cat([self.R[g] for g in gs], dim=1).contiguous()
+                    Ccat = torch.empty_like(Rcat)
+                    k.solve(self.G, self.K, ls2, self.jitter, Rcat, Ccat, self.info)
+                    for j, g in enumerate(gs):
+                        self.C_new[g].copy_(Ccat[:, 3 * j : 3 * j + 3])
+                    if gs[-1] + 1 < self.ng:
+                        fail = max(fail, int(self.info.cpu()[0]))
             host = torch.cat([self.st, self.quad.sum().reshape(1), self.info.to(torch.float64)]).cpu()
             host[5] = max(float(host[5]), float(fail))
             if int(host[5]) == 0:

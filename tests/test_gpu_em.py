@@ -9,7 +9,6 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from oracle import dg_oracle as dgo  # noqa: E402
 from oracle import sparsevfc_oracle as svo  # noqa: E402
 
 TOL = {"float64": 1e-5, "float32": 1e-3}
@@ -98,8 +97,6 @@ def test_sparsevfc_default_lambda_within_reference_noise_floor(st):
     singular and the reference's own result moves by O(1e-3) when its LAPACK solver is swapped for a mathematically
     identical one (lstsq vs symmetric eigendecomposition with the same cut-off).  The GPU result must sit within a
     small multiple of that measured noise floor, and must reach the same objective value."""
-    import scipy.linalg as sl
-
     X, V = _c2(6000)
     kw = dict(M=300, lambda_=0.02, MaxIter=12, seed=0)
     ref = svo.SparseVFC(X, V, None, lstsq_method="scipy", **kw)
