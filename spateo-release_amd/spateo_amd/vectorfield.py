@@ -77,6 +77,33 @@ def sample_by_velocity(V: np.ndarray, n: int, seed: int = 19491001) -> np.ndarra
     return np.random.choice(np.arange(len(V)), size=n, p=p, replace=False)
 
 
+def unique_rows(X: np.ndarray):
+    """``np.unique(X, axis=0, return_index=True)`` (lexicographically sorted unique rows + index of the FIRST
+    occurrence of each) without NumPy's structured-view sort, which is the slowest host step at millions of cells
+    (12 s at 8 M): stable argsort on the first coordinate, then a stable lexsort only inside runs of equal first
+    coordinates.  Bit-identical to np.unique for finite input; anything else takes the NumPy route."""
+    X = np.ascontiguousarray(X)
+    n, d = X.shape if X.ndim == 2 else (0, 0)
+    if n < 2 or d < 1 or X.dtype.kind != "f" or not np.isfinite(X).all():
+        return np.unique(X, axis=0, return_index=True)
+    order = np.argsort(X[:, 0], kind="stable")
+    x0 = X[order, 0]
+    eq = x0[1:] == x0[:-1]
+    if d > 1 and eq.any():
+        tied = np.zeros(n, dtype=bool)  # positions (in sorted order) that belong to a run of equal first coordinates
+        tied[1:] |= eq
+        tied[:-1] |= eq
+        pos = np.flatnonzero(tied)
+        sub = order[pos]
+        # stable lexsort (last key is the primary one); the first coordinate keeps each run in its own slots
+        keys = tuple(X[sub, c] for c in range(d - 1, 0, -1)) + (X[sub, 0],)
+        order[pos] = sub[np.lexsort(keys)]
+    S = X[order]
+    keep = np.ones(n, dtype=bool)
+    keep[1:] = np.any(S[1:] != S[:-1], axis=1)
+    return S[keep], order[keep]
+
+
 _PREPROCESS_LOCK = __import__("threading").Lock()  # the sampling re-seeds NumPy's GLOBAL RNG (as dynamo does)
 
 
@@ -91,7 +118,7 @@ def _sparsevfc_preprocess(X, Y, M, beta, velocity_based_sampling, seed):
     Xv, Yv = X[valid_ind], Y[valid_ind]
     if len(Xv) == 0:
         raise ValueError("SparseVFC: no row of Y is finite - nothing to fit.")
-    tmp_X, uid = np.unique(Xv, axis=0, return_index=True)
+    tmp_X, uid = unique_rows(Xv)
     M = min(M, tmp_X.shape[0])
     if velocity_based_sampling:
         np.random.seed(seed)

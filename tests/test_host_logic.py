@@ -400,3 +400,24 @@ def test_degenerate_inputs_behave_like_the_reference(cpu_kernels):
         svo.SparseVFC(X, Y, None, M=1, beta=0.3, **kw)
     with pytest.raises(ValueError):
         st.SparseVFC(X, Y, None, M=1, beta=0.3, _kernels=cpu_kernels, **kw)
+
+
+def test_unique_rows_matches_numpy_unique():
+    """The host shortcut for dynamo's ``np.unique(X, axis=0, return_index=True)`` is bit-identical to it (rows, first
+    occurrence indices), including ties on the leading coordinate, duplicated rows, signed zeros and 1/2/3 columns."""
+    from spateo_amd.vectorfield import unique_rows
+
+    rng = np.random.default_rng(5)
+    for n, d, hi in [(1, 3, 5), (2, 3, 2), (1000, 3, 4), (1000, 2, 6), (5000, 3, 50), (3000, 1, 40), (50000, 3, 10**9)]:
+        X = rng.integers(0, hi, size=(n, d)).astype(np.float64)
+        if n > 10:
+            X[::7] = X[3]
+            X[5] = -0.0 * X[5]
+        a, ai = np.unique(X, axis=0, return_index=True)
+        b, bi = unique_rows(X)
+        assert a.tobytes() == b.tobytes() and np.array_equal(ai, bi), (n, d, hi)
+    Xn = rng.normal(size=(100, 3))
+    Xn[7, 1] = np.nan  # non-finite input takes the NumPy route (whatever it does, it is the same thing)
+    a, ai = np.unique(Xn, axis=0, return_index=True)
+    b, bi = unique_rows(Xn)
+    assert np.array_equal(ai, bi) and np.array_equal(a, b, equal_nan=True)
