@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void gram_f32_kernel(const float4* __restri
 // (DESIGN.md "Why the float32 mode accumulates in float64").
 // ----------------------------------------------------------------------------------------------------------------
 template <typename TIn>
-__global__ __launch_bounds__(256, 1) void gram_f64acc_kernel(const typename Vec4<TIn>::type* __restrict__ x4,
+__global__ __launch_bounds__(256, 2) void gram_f64acc_kernel(const typename Vec4<TIn>::type* __restrict__ x4,
                                                              const TIn* __restrict__ P, int64_t n,
                                                              const typename Vec4<TIn>::type* __restrict__ ctrl4,
                                                              int64_t m, TIn s, int nt, int npairs, int64_t slice_len,
@@ -384,6 +384,19 @@ constexpr int UG = MVF_UG;  // k-steps (of 4 cells) per software-pipeline group
 #ifndef MVF_CACHED_WPS
 #define MVF_CACHED_WPS 2
 #endif
+// Software pipeline of the cached kernel: a ring of NBUF operand groups of UGT k-steps each; the loads of group
+// g + NBUF - 1 are issued before the MFMAs of group g.  float: 2 groups x 2 k-steps (20 + 20 operand VGPRs next to
+// the 128 accumulator VGPRs).  double: operands are twice as wide, and 2 x 2 spills (256 VGPRs + scratch, 36 TF
+// measured): 3 groups x 1 k-step keeps the same prefetch distance (2 k-steps) in 66 instead of 88 VGPRs.
+#ifndef MVF_DBL_UG
+#define MVF_DBL_UG 1
+#endif
+#ifndef MVF_DBL_NBUF
+#define MVF_DBL_NBUF 2
+#endif
+template <typename T> struct CachedPipe { static constexpr int UGT = UG, NBUF = 2; };
+template <> struct CachedPipe<double> { static constexpr int UGT = MVF_DBL_UG, NBUF = MVF_DBL_NBUF; };
+
 template <typename T>
 __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const T* __restrict__ ublk, const T* __restrict__ P,
                                                              int64_t n, int64_t n_pad, int nt, int npairs,
@@ -392,6 +405,7 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
     // the row direction and all read the same 8 column panels (L1 hits).  Per k-step a lane does 10 loads and only
     // TWO v_mul_f64 (P K, kept exact) for 16 MFMAs - the f64 VALU work is what steals MFMA time on gfx950.
     constexpr int NA = 2, NB = 8;
+    constexpr int UGT = CachedPipe<T>::UGT, NBUF = CachedPipe<T>::NBUF;
     const int pair = blockIdx.x % npairs;
     const int64_t slice = blockIdx.x / npairs;
     int ti, tj;
@@ -420,13 +434,13 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-    T ua[2][UG][NA], ub[2][UG][NB], pp[2][UG];
-    const int ngroups = (int)((n1 - n0) / (4 * UG));  // slices are multiples of 256 cells: ngroups is even
+    T ua[NBUF][UGT][NA], ub[NBUF][UGT][NB], pp[NBUF][UGT];
+    const int ngroups = (int)((n1 - n0) / (4 * UGT));  // slices are multiples of 256 cells
 
-    auto load_group = [&](int g, T(&A)[UG][NA], T(&B)[UG][NB], T(&Pq)[UG]) {
+    auto load_group = [&](int g, T(&A)[UGT][NA], T(&B)[UGT][NB], T(&Pq)[UGT]) {
 #pragma unroll
-        for (int q = 0; q < UG; ++q) {
-            const int64_t off = ((int64_t)g * UG + q) * (4 * UB);
+        for (int q = 0; q < UGT; ++q) {
+            const int64_t off = ((int64_t)g * UGT + q) * (4 * UB);
 #ifdef MVF_PROBE_NO_LOAD
 #pragma unroll
             for (int a = 0; a < NA; ++a) A[q][a] = (T)(0.5 + lane * 1e-3 + off * 1e-9);
@@ -438,7 +452,7 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
 #pragma unroll
             for (int b = 0; b < NB; ++b) B[q][b] = pb[b][off];
 #endif
-            const int64_t cell = n0 + ((int64_t)g * UG + q) * 4 + lk;
+            const int64_t cell = n0 + ((int64_t)g * UGT + q) * 4 + lk;
 #if defined(MVF_PROBE_NO_LOAD) || defined(MVF_PROBE_NO_P)
             Pq[q] = T(1);
 #else
@@ -446,9 +460,9 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
 #endif
         }
     };
-    auto compute_group = [&](const T(&A)[UG][NA], const T(&B)[UG][NB], const T(&Pq)[UG]) {
+    auto compute_group = [&](const T(&A)[UGT][NA], const T(&B)[UGT][NB], const T(&Pq)[UGT]) {
 #pragma unroll
-        for (int q = 0; q < UG; ++q) {
+        for (int q = 0; q < UGT; ++q) {
             double fa[NA], fb[NB];
             const double pd = (double)Pq[q];
 #pragma unroll
@@ -482,12 +496,17 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
         }
     };
 
-    if (ngroups > 0) load_group(0, ua[0], ub[0], pp[0]);
-    for (int g = 0; g < ngroups; g += 2) {
-        if (g + 1 < ngroups) load_group(g + 1, ua[1], ub[1], pp[1]);
-        compute_group(ua[0], ub[0], pp[0]);
-        if (g + 2 < ngroups) load_group(g + 2, ua[0], ub[0], pp[0]);
-        if (g + 1 < ngroups) compute_group(ua[1], ub[1], pp[1]);
+#pragma unroll
+    for (int s = 0; s < NBUF - 1; ++s)
+        if (s < ngroups) load_group(s, ua[s], ub[s], pp[s]);
+    for (int g = 0; g < ngroups; g += NBUF) {
+#pragma unroll
+        for (int s = 0; s < NBUF; ++s) {
+            constexpr int AHEAD = NBUF - 1;
+            if (g + s + AHEAD < ngroups)
+                load_group(g + s + AHEAD, ua[(s + AHEAD) % NBUF], ub[(s + AHEAD) % NBUF], pp[(s + AHEAD) % NBUF]);
+            if (g + s < ngroups) compute_group(ua[s], ub[s], pp[s]);
+        }
     }
 
     double* out = partial + ((size_t)slice * npairs + pair) * (size_t)(GT * GT);

@@ -58,7 +58,7 @@ CONFIGS = {
 }
 
 
-def make_config(name, N=None, noise=0.05, outlier_frac=0.05, outlier_sd=2.0, dtype=np.float64):
+def make_config(name, N=None, noise=0.05, outlier_frac=0.05, outlier_sd=2.0, dtype=np.float64, seed=None):
     """Return (X, V, M) for a BASELINE config (optionally with N overridden, same generator).
 
     The displacement field is scaled to unit rms, noise and outliers are in those units.  (SURVEY.md 8d suggested
@@ -66,7 +66,7 @@ def make_config(name, N=None, noise=0.05, outlier_frac=0.05, outlier_sd=2.0, dty
     degenerate, so the generator keeps the geometry and the field shape but normalises the magnitudes.)"""
     cfg = CONFIGS[name]
     N = cfg["N"] if N is None else int(N)
-    rng = np.random.default_rng(cfg["seed"])
+    rng = np.random.default_rng(cfg["seed"] if seed is None else seed)
     if cfg["embryo"]:
         X = embryo_cloud(rng, N, cfg["axes"], dtype=dtype)
     else:
