@@ -58,26 +58,32 @@ static GramPlan make_plan(int64_t n, int64_t m) {
     GramPlan p;
     p.nt = (int)cdiv(m, GT);
     p.npairs = p.nt * (p.nt + 1) / 2;
-    // Jobs = tile pairs x cell slices.  All jobs cost the same, so the launch runs in ceil(jobs / slots) rounds: pick
-    // the slice count (within a memory budget of ~1.5 GB of float64 partial tiles) that wastes the least of the
-    // last round.  (At 1 M cells x 300 pairs the naive 4 slices = 1200 jobs on 512 slots lost 22 % to the tail.)
+    // Jobs = tile pairs x cell slices.  All jobs cost the same, so the launch runs in ceil(jobs / slots) rounds of
+    // (slice_len + OVERHEAD) cell-times, OVERHEAD = the 128 KB partial tile a job writes and the reduce kernel reads
+    // back, expressed in cells of MFMA work (measured ~150: at 50 k cells x 500 control points 1024-cell slices beat
+    // 256-cell ones by 15 % although both fill the chip).  Pick the slice count (within a memory budget of ~1.5 GB of
+    // float64 partial tiles) with the smallest modelled time.  (At 1 M cells x 300 pairs the naive 4 slices = 1200
+    // jobs on 512 slots lost 22 % to the tail.)
     const int64_t max_chunks = cdiv(n, GCHUNK);
     const int64_t budget_jobs = std::max<int64_t>(p.npairs, (int64_t)(1.5e9 / (GT * GT * sizeof(double))));
     const int64_t s_max = std::max<int64_t>(1, std::min<int64_t>(max_chunks, budget_jobs / p.npairs));
-    const int64_t s_min = std::max<int64_t>(1, std::min<int64_t>(s_max, cdiv(4 * (int64_t)gram_slots(), p.npairs)));
     const double slots = (double)gram_slots();
-    int64_t best_s = s_max;
-    double best_eff = -1.0;
-    for (int64_t s = s_min; s <= s_max; ++s) {
+    constexpr double OVERHEAD = 150.0;
+    auto model = [&](int64_t s, int64_t& ns) {
         const int64_t sl = cdiv(cdiv(n, s), GCHUNK) * GCHUNK;
-        const int64_t ns = cdiv(n, sl);
-        const double jobs = (double)ns * p.npairs;
-        const double eff = (jobs / slots) / std::ceil(jobs / slots) * ((double)n / ((double)ns * sl));
-        if (eff > best_eff + 1e-9) {
-            best_eff = eff;
+        ns = cdiv(n, sl);
+        return std::ceil((double)ns * p.npairs / slots) * ((double)sl + OVERHEAD);
+    };
+    int64_t best_s = s_max, ns = 0;
+    double best_t = 1e300;
+    for (int64_t s = 1; s <= s_max; ++s) best_t = std::min(best_t, model(s, ns));
+    // among plans within 0.5 % of the best modelled time take the one with the most rounds (many short rounds even
+    // out per-XCD speed differences better than a few long ones)
+    for (int64_t s = s_max; s >= 1; --s)
+        if (model(s, ns) <= best_t * 1.005) {
             best_s = ns;
+            break;
         }
-    }
     int64_t sl = cdiv(cdiv(n, best_s), GCHUNK) * GCHUNK;
     if (const char* e = getenv("MVF_SLICE_LEN")) sl = std::max<int64_t>(GCHUNK, atoll(e) / GCHUNK * GCHUNK);  // probes
     p.slice_len = sl;
@@ -610,16 +616,28 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restri
 
 __global__ __launch_bounds__(256) void rhs_reduce_kernel(const double* __restrict__ rpart, int64_t rslices, int64_t m,
                                                          double* __restrict__ R /* m x 3 */) {
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= m) return;
+    // 16 control points x 16 slice lanes per workgroup (a serial loop over ~1000 slices per output was latency bound:
+    // 78 us at M = 500); the combination order is fixed, so the result is deterministic.
+    __shared__ double sm[16][16][3];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t j = (int64_t)blockIdx.x * 16 + tx;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    for (int64_t s = 0; s < rslices; ++s) {
-        const double4 v = *reinterpret_cast<const double4*>(rpart + ((size_t)s * m + j) * 4);
-        a0 += v.x, a1 += v.y, a2 += v.z;
+    if (j < m) {
+        for (int64_t s = ty; s < rslices; s += 16) {
+            const double4 v = *reinterpret_cast<const double4*>(rpart + ((size_t)s * m + j) * 4);
+            a0 += v.x, a1 += v.y, a2 += v.z;
+        }
     }
-    R[j * 3 + 0] = a0;
-    R[j * 3 + 1] = a1;
-    R[j * 3 + 2] = a2;
+    sm[ty][tx][0] = a0, sm[ty][tx][1] = a1, sm[ty][tx][2] = a2;
+    __syncthreads();
+    if (threadIdx.x < 48) {
+        const int o = threadIdx.x / 3, comp = threadIdx.x % 3;
+        const int64_t jo = (int64_t)blockIdx.x * 16 + o;
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sm[q][o][comp];
+        if (jo < m) R[jo * 3 + comp] = t;
+    }
 }
 
 }  // namespace mvf
@@ -697,7 +715,7 @@ extern "C" int mvf_gram_stages(int stages, const void* x4, const void* P, const 
         MVF_LAUNCH_CHECK();
     }
     if (stages & MVF_GRAM_STAGE_REDUCE_RHS) {
-        hipLaunchKernelGGL(rhs_reduce_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, rpart, p.rslices, m, R);
+        hipLaunchKernelGGL(rhs_reduce_kernel, dim3((unsigned)cdiv(m, 16)), dim3(256), 0, st, rpart, p.rslices, m, R);
         MVF_LAUNCH_CHECK();
     }
     return 0;

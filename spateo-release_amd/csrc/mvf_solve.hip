@@ -7,8 +7,8 @@
 // parity quantity and shows the measured noise floor of the reference itself.
 //
 // Structure per block column k (all kernels on one stream, no host sync):
-//   potrf_diag : one workgroup factors the 64x64 diagonal block in LDS
-//   trsm_panel : one lane per row below solves  x L_kk^T = a  (right-looking inside the lane -> independent FMAs)
+//   potrf_diag : one workgroup factors the 64x64 diagonal block (register tiled, one barrier per column)
+//   trsm_panel : one DPP quad (4 lanes x 16 columns) per row below solves  x L_kk^T = a
 //   syrk_update: one workgroup per 64x64 trailing tile, v_mfma_f64_16x16x4_f64 on LDS-staged panels
 // The right-hand sides ride along as extra ROWS of the trapezoidal matrix, so the forward substitution L Y = R falls
 // out of trsm/syrk for free; the back substitution L^T C = Y is one small kernel per block column.
@@ -57,67 +57,137 @@ __global__ __launch_bounds__(256) void chol_prepare_kernel(const double* __restr
     W[i * mp + j] = v;
 }
 
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ W, int64_t mp, int k, int* __restrict__ info) {
-    // Right-looking Cholesky of one 64x64 block in LDS with ONE barrier per column: step j applies the rank-1 update
-    // a[i][c] -= a[i][j] a[c][j] / a[j][j] to the trailing lower triangle from the still UNSCALED column j (nobody
-    // writes column j during step j, and later steps never read it), and the columns are scaled once at the end.
-    __shared__ double a[NB][NB + 1];
+// Right-looking Cholesky of one 64x64 diagonal block, register tiled: thread (ty, tx) of a 16 x 16 grid keeps the 16
+// elements a[ty + 16 p][tx + 16 q] in registers.  Step j: the owners of column j publish it (still UNSCALED) to LDS,
+// ONE barrier, then every thread applies the rank-1 update a[i][c] -= (a[i][j] / a[j][j]) a[c][j] to its registers
+// (8 LDS reads + 16 multiply-subtracts per step instead of a latency-bound LDS read-modify-write per element).
+// Columns are scaled by 1 / sqrt(a[j][j]) once at the end; rdiag gets 1 / L[j][j] for the triangular solves (no
+// divisions in their dependent chains).  The column loop is ROLLED inside each 16-column group (the group index must
+// be static for the register tile): these one-workgroup kernels run once per launch, so straight-line unrolled code
+// is paid for in instruction-cache misses (measured: the fully unrolled version was no faster than the LDS one).
+template <int JQ>
+__device__ __forceinline__ void potrf_group(double (&r)[4][4], double (*col)[NB], double* dg, int tx, int ty, int k,
+                                            int* __restrict__ info) {
+#pragma unroll 1
+    for (int jx = 0; jx < 16; ++jx) {
+        const int j = 16 * JQ + jx;
+        if (tx == jx) {
+#pragma unroll
+            for (int p = JQ; p < 4; ++p) col[j & 1][ty + 16 * p] = r[p][JQ];
+        }
+        __syncthreads();
+        const double* cb = col[j & 1];
+        double d = cb[j];
+        if (!(d > 0.0)) {  // also catches NaN; keep going with a harmless pivot so the kernel chain completes
+            if (threadIdx.x == 0) atomicCAS(info, 0, 1 + k * NB + j);
+            d = 1.0;
+        }
+        if (threadIdx.x == 0) dg[j] = d;
+        const double inv = 1.0 / d;
+        double ci[4], cc[4];
+#pragma unroll
+        for (int p = JQ; p < 4; ++p) {
+            ci[p] = cb[ty + 16 * p] * inv;
+            cc[p] = cb[tx + 16 * p];
+        }
+#pragma unroll
+        for (int p = JQ; p < 4; ++p)
+#pragma unroll
+            for (int q = JQ; q < 4; ++q) {
+                const double u = r[p][q] - ci[p] * cc[q];
+                r[p][q] = (ty + 16 * p > j && tx + 16 * q > j) ? u : r[p][q];
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ W, int64_t mp, int k,
+                                                         double* __restrict__ rdiag, int* __restrict__ info) {
+    __shared__ double col[2][NB];
+    __shared__ double dg[NB];
     double* blk = W + ((int64_t)k * NB) * mp + (int64_t)k * NB;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    double r[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[p][q] = blk[(int64_t)(ty + 16 * p) * mp + tx + 16 * q];
+    potrf_group<0>(r, col, dg, tx, ty, k, info);
+    potrf_group<1>(r, col, dg, tx, ty, k, info);
+    potrf_group<2>(r, col, dg, tx, ty, k, info);
+    potrf_group<3>(r, col, dg, tx, ty, k, info);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = ty + 16 * p, c = tx + 16 * q;
+            const double l = sqrt(dg[c]);
+            blk[(int64_t)i * mp + c] = (c < i) ? r[p][q] / l : (c == i ? l : 0.0);
+            if (c == i) rdiag[(int64_t)k * NB + c] = 1.0 / l;
+        }
+}
+
+// rows below the diagonal block:  x L^T = a  ->  for c: x_c = a_c / L_cc ; a_j -= x_c L_jc (j > c).
+// FOUR lanes (one DPP quad) per row, each holding 16 of the row's 64 columns in registers: per column c the owning
+// lane scales by the precomputed 1 / L_cc, a quad_perm DPP move broadcasts x_c to the quad, and every lane updates its
+// 16 columns.  The diagonal block is stored with an explicitly ZERO upper triangle, so the update needs no predicate:
+// for j < c it subtracts x_c * 0.  (4x the lanes and a 4x shorter dependent chain than one lane per row; the column
+// loop is rolled - wave-uniform dynamic register index - to stay inside the instruction cache.)
+template <int O>
+__device__ __forceinline__ double quad_bcast(double v) {
+    constexpr int ctrl = O | (O << 2) | (O << 4) | (O << 6);  // quad_perm: every lane of the quad reads lane O
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), ctrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), ctrl, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+typedef double f64x16 __attribute__((ext_vector_type(16)));
+
+template <int O>
+__device__ __forceinline__ void trsm_quarter(f64x16& x, const double (*L)[NB + 1], const double* rd, int role) {
+#pragma unroll 1
+    for (int cl = 0; cl < 16; ++cl) {
+        const int c = 16 * O + cl;
+        const double xc = quad_bcast<O>(x[cl] * rd[c]);  // meaningful on the owning lane (role == O), read from it
+        const double* Lc = &L[16 * role][c];
+#pragma unroll
+        for (int jl = 0; jl < 16; ++jl) x[jl] = fma(-xc, Lc[jl * (NB + 1)], x[jl]);
+        const double keep = x[cl];
+        x[cl] = (role == O) ? xc : keep;
+    }
+}
+
+__global__ __launch_bounds__(256) void trsm_panel_kernel(double* __restrict__ W, int64_t mp, int64_t mr, int k,
+                                                         const double* __restrict__ rdiag) {
+    __shared__ double L[NB][NB + 1];
+    __shared__ double rd[NB];
+    const double* blk = W + ((int64_t)k * NB) * mp + (int64_t)k * NB;
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         double v[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = blk[(int64_t)(wave * 16 + q) * mp + lane];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) a[wave * 16 + q][lane] = v[q];
+        for (int q = 0; q < 16; ++q) L[wave * 16 + q][lane] = v[q];
+        if (threadIdx.x < NB) rd[threadIdx.x] = rdiag[(int64_t)k * NB + threadIdx.x];
     }
+    const int role = threadIdx.x & 3;
+    const int64_t row = (int64_t)(k + 1) * NB + (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool live = row < mr;  // whole quads are live or not (same row)
+    double* rp = W + (live ? row : (int64_t)(k + 1) * NB) * mp + (int64_t)k * NB + 16 * role;
+    f64x16 x;
+#pragma unroll
+    for (int jl = 0; jl < 16; ++jl) x[jl] = rp[jl];
     __syncthreads();
-    for (int j = 0; j < NB - 1; ++j) {
-        double d = a[j][j];
-        if (!(d > 0.0)) {  // also catches NaN; keep going with a harmless pivot so the kernel chain completes
-            if (threadIdx.x == 0) atomicCAS(info, 0, 1 + k * NB + j);
-            d = 1.0;
-        }
-        const double inv = 1.0 / d;
-        // 16 x 16 thread grid over the trailing block (no integer divisions; c is the fast index -> conflict-free LDS)
-        const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-        for (int i = j + 1 + ty; i < NB; i += 16) {
-            const double aij = a[i][j] * inv;
-            for (int c = j + 1 + tx; c <= i; c += 16) a[i][c] -= aij * a[c][j];
-        }
-        __syncthreads();
+    trsm_quarter<0>(x, L, rd, role);
+    trsm_quarter<1>(x, L, rd, role);
+    trsm_quarter<2>(x, L, rd, role);
+    trsm_quarter<3>(x, L, rd, role);
+    if (live) {
+#pragma unroll
+        for (int jl = 0; jl < 16; ++jl) rp[jl] = x[jl];
     }
-    if (threadIdx.x == 0 && !(a[NB - 1][NB - 1] > 0.0)) atomicCAS(info, 0, 1 + k * NB + NB - 1);
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {
-        const int i = e / NB, c = e % NB;
-        double djj = a[c][c];
-        if (!(djj > 0.0)) djj = 1.0;
-        const double l = sqrt(djj);
-        blk[(int64_t)i * mp + c] = (c < i) ? a[i][c] / l : (c == i ? l : 0.0);
-    }
-}
-
-// rows below the diagonal block: x L^T = a  ->  for c: x_c = a_c / L_cc ; a_j -= x_c L_jc (j > c)
-__global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ W, int64_t mp, int64_t mr, int k) {
-    __shared__ double L[NB][NB];
-    const double* blk = W + ((int64_t)k * NB) * mp + (int64_t)k * NB;
-    for (int e = threadIdx.x; e < NB * NB; e += 64) L[e / NB][e % NB] = blk[(int64_t)(e / NB) * mp + (e % NB)];
-    __syncthreads();
-    const int64_t row = (int64_t)(k + 1) * NB + (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (row >= mr) return;
-    double* rp = W + row * mp + (int64_t)k * NB;
-    double x[NB];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) x[c] = rp[c];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) {
-        const double xc = x[c] / L[c][c];
-        x[c] = xc;
-#pragma unroll
-        for (int j = c + 1; j < NB; ++j) x[j] = fma(-xc, L[j][c], x[j]);
-    }
-#pragma unroll
-    for (int c = 0; c < NB; ++c) rp[c] = x[c];
 }
 
 // W[i, j] -= W[i, k] W[j, k]^T  for block rows i > k (incl. the rhs block row) and block cols k < j <= min(i, nb-1)
@@ -183,9 +253,11 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ W
 //   Y_j -= L[k-block rows, j-block cols]^T C_k, and workgroup k stores C_k.  Yw (mp x MAXR) is the working rhs.
 template <int MAXR>
 __global__ __launch_bounds__(256) void bsub_step_kernel(const double* __restrict__ W, int64_t mp, int k, int nrhs,
-                                                        double* __restrict__ Yw, double* __restrict__ Cp) {
+                                                        const double* __restrict__ rdiag, double* __restrict__ Yw,
+                                                        double* __restrict__ Cp) {
     __shared__ double L[NB][NB + 1];
     __shared__ double t[NB][MAXR];
+    __shared__ double rd[NB];
     __shared__ double part[4][NB][MAXR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* blk = W + ((int64_t)k * NB) * mp + (int64_t)k * NB;
@@ -196,8 +268,10 @@ __global__ __launch_bounds__(256) void bsub_step_kernel(const double* __restrict
 #pragma unroll
         for (int q = 0; q < 16; ++q) L[wave * 16 + q][lane] = v[q];
     }
-    if (tid < NB)
+    if (tid < NB) {
         for (int d = 0; d < nrhs; ++d) t[tid][d] = Yw[((int64_t)k * NB + tid) * MAXR + d];
+        rd[tid] = rdiag[(int64_t)k * NB + tid];
+    }
     // issue this workgroup's elimination-panel loads early (block (k, j), rows wave*16 .. +15, column `lane`)
     const int j = blockIdx.x;
     double lcol[16];
@@ -214,7 +288,7 @@ __global__ __launch_bounds__(256) void bsub_step_kernel(const double* __restrict
 #pragma unroll
         for (int d = 0; d < MAXR; ++d) y[d] = d < nrhs ? t[lane][d] : 0.0;
         for (int cc = NB - 1; cc >= 0; --cc) {
-            const double inv = 1.0 / L[cc][cc];
+            const double inv = rd[cc];  // 1 / L[cc][cc] from potrf_diag
             const double l = L[cc][lane];
 #pragma unroll
             for (int d = 0; d < MAXR; ++d) {
@@ -275,7 +349,7 @@ extern "C" size_t mvf_solve_workspace_bytes(int64_t m, int nrhs) {
     if (m <= 0) return 0;
     const int64_t mp = solve_mp(m), mr = mp + NB;
     return align_up((size_t)mr * mp * sizeof(double), 256) + align_up((size_t)mp * std::max(nrhs, 1) * sizeof(double), 256) +
-           align_up((size_t)mp * 8 * sizeof(double), 256) + 256;
+           align_up((size_t)mp * 8 * sizeof(double), 256) + align_up((size_t)mp * sizeof(double), 256) + 256;
 }
 
 extern "C" int mvf_solve(const double* G, const double* K, double lambda_sigma2, double jitter, const double* R,
@@ -296,7 +370,8 @@ extern "C" int mvf_solve(const double* G, const double* K, double lambda_sigma2,
     double* W = (double*)workspace;
     double* Cp = (double*)((char*)workspace + align_up((size_t)mr * mp * sizeof(double), 256));
     double* Yw = (double*)((char*)Cp + align_up((size_t)mp * nrhs * sizeof(double), 256));
-    double* scal = (double*)((char*)Yw + align_up((size_t)mp * 8 * sizeof(double), 256));
+    double* rdiag = (double*)((char*)Yw + align_up((size_t)mp * 8 * sizeof(double), 256));
+    double* scal = (double*)((char*)rdiag + align_up((size_t)mp * sizeof(double), 256));
 
     hipLaunchKernelGGL(diag_mean_kernel, dim3(1), dim3(256), 0, st, G, K, lambda_sigma2, jitter, m, scal);
     MVF_LAUNCH_CHECK();
@@ -305,9 +380,9 @@ extern "C" int mvf_solve(const double* G, const double* K, double lambda_sigma2,
                        lambda_sigma2, scal, R, m, nrhs, mp, mr, W);
     MVF_LAUNCH_CHECK();
     for (int k = 0; k < nb; ++k) {
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, W, mp, k, info);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, W, mp, k, rdiag, info);
         const int64_t rows_below = mr - (int64_t)(k + 1) * NB;
-        hipLaunchKernelGGL(trsm_panel_kernel, dim3((unsigned)cdiv(rows_below, 64)), dim3(64), 0, st, W, mp, mr, k);
+        hipLaunchKernelGGL(trsm_panel_kernel, dim3((unsigned)cdiv(rows_below, 64)), dim3(256), 0, st, W, mp, mr, k, rdiag);
         // tiles: sum over i in (k, nbr) of (min(i, nb-1) - k)
         int64_t ntiles = 0;
         for (int i = k + 1; i < nbr; ++i) ntiles += std::min(i, nb - 1) - k;
@@ -317,7 +392,7 @@ extern "C" int mvf_solve(const double* G, const double* K, double lambda_sigma2,
     MVF_LAUNCH_CHECK();
     hipLaunchKernelGGL(bsub_init_kernel<8>, dim3((unsigned)cdiv(mp, 256)), dim3(256), 0, st, W, mp, nrhs, Yw);
     for (int k = nb - 1; k >= 0; --k)
-        hipLaunchKernelGGL(bsub_step_kernel<8>, dim3((unsigned)(k + 1)), dim3(256), 0, st, W, mp, k, nrhs, Yw, Cp);
+        hipLaunchKernelGGL(bsub_step_kernel<8>, dim3((unsigned)(k + 1)), dim3(256), 0, st, W, mp, k, nrhs, rdiag, Yw, Cp);
     MVF_LAUNCH_CHECK();
     hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)cdiv(m * nrhs, 256)), dim3(256), 0, st, Cp, m * nrhs, C);
     MVF_LAUNCH_CHECK();
