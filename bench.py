@@ -228,6 +228,9 @@ def main():
             "solve_retries": eng.solve_retries,
             "gram_mode": args.gram_mode,
             "cached_u": bool(eng.cached_u),
+            # whole-step rates over all ranks, U counted as materialised (2 s N M bytes, 2 N M^2 flop)
+            "step_effective_GBps": 2.0 * (4 if args.dtype == "float32" else 8) * N * Mc / (ms_per_step * 1e-3) / 1e9,
+            "step_TFLOPs_2NM2": 2.0 * N * Mc * Mc / (ms_per_step * 1e-3) / 1e12,
         },
         "roofline": roofline,
     }
