@@ -17,6 +17,7 @@
 //   * Work decomposition: job = (tile pair, cell slice); blockIdx = slice * npairs + pair so that concurrently
 //     resident workgroups stream the same cell slice (L2 / MALL hits on the only global input).
 #include "mvf_common.h"
+#include <type_traits>
 
 namespace mvf {
 
@@ -443,10 +444,18 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
     T ua[NBUF][UGT][NA], ub[NBUF][UGT][NB], pp[NBUF][UGT];
     const int ngroups = (int)((n1 - n0) / (4 * UGT));  // slices are multiples of 256 cells
 
-    auto load_group = [&](int g, T(&A)[UGT][NA], T(&B)[UGT][NB], T(&Pq)[UGT]) {
+    // Address arithmetic is VALU work too (64-bit adds) and VALU time is additive to f64 MFMA time: the ten operand
+    // pointers and the P pointer advance ONCE per superblock of SUPER groups (4 KB per pointer); inside it every load
+    // uses a compile-time immediate offset.  P is read branch-free: cached rows of padded cells are zero, so any finite
+    // P does; only the slice that crosses n clamps its index (tail == true).
+    constexpr int SUPER = 4096 / (UGT * 4 * UB * (int)sizeof(T));  // groups per 4 KB of one pointer's stream
+    const T* pP = P + n0 + lk;
+    const int pmax = (int)min((int64_t)0x3fffffff, n - 1 - n0 - lk);  // last valid index from pP (may be < 0: P[n-1])
+    auto load_group = [&](int64_t gbase, int s, bool in_tail, T(&A)[UGT][NA], T(&B)[UGT][NB], T(&Pq)[UGT]) {
+        // group gbase + s; `s` is a compile-time constant after unrolling, gbase advances once per superblock
 #pragma unroll
         for (int q = 0; q < UGT; ++q) {
-            const int64_t off = ((int64_t)g * UGT + q) * (4 * UB);
+            const int64_t off = (gbase * UGT) * (4 * UB) + (s * UGT + q) * (4 * UB);
 #ifdef MVF_PROBE_NO_LOAD
 #pragma unroll
             for (int a = 0; a < NA; ++a) A[q][a] = (T)(0.5 + lane * 1e-3 + off * 1e-9);
@@ -458,11 +467,11 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
 #pragma unroll
             for (int b = 0; b < NB; ++b) B[q][b] = pb[b][off];
 #endif
-            const int64_t cell = n0 + ((int64_t)g * UGT + q) * 4 + lk;
 #if defined(MVF_PROBE_NO_LOAD) || defined(MVF_PROBE_NO_P)
             Pq[q] = T(1);
 #else
-            Pq[q] = cell < n ? P[cell] : T(0);
+            const int64_t poff = (gbase * UGT) * 4 + (s * UGT + q) * 4;
+            Pq[q] = in_tail ? pP[min((int)poff, pmax)] : pP[poff];
 #endif
         }
     };
@@ -502,18 +511,30 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
         }
     };
 
+    static_assert(SUPER % NBUF == 0, "ring slots must be static inside a superblock");
+    constexpr int AHEAD = NBUF - 1;
+    // main part: whole superblocks whose cells all exist (no index clamp on P)
+    const int64_t live = max((int64_t)0, min(n1, n) - n0);
+    const int ng_main = (int)(min((int64_t)ngroups, live / (4 * UGT)) / SUPER) * SUPER;
 #pragma unroll
-    for (int s = 0; s < NBUF - 1; ++s)
-        if (s < ngroups) load_group(s, ua[s], ub[s], pp[s]);
-    for (int g = 0; g < ngroups; g += NBUF) {
+    for (int s = 0; s < AHEAD; ++s)
+        if (s < ng_main) load_group(0, s, false, ua[s], ub[s], pp[s]);
+    for (int g0 = 0; g0 < ng_main; g0 += SUPER) {
 #pragma unroll
-        for (int s = 0; s < NBUF; ++s) {
-            constexpr int AHEAD = NBUF - 1;
-            if (g + s + AHEAD < ngroups)
-                load_group(g + s + AHEAD, ua[(s + AHEAD) % NBUF], ub[(s + AHEAD) % NBUF], pp[(s + AHEAD) % NBUF]);
-            if (g + s < ngroups) compute_group(ua[s], ub[s], pp[s]);
+        for (int s = 0; s < SUPER; ++s) {
+            if (g0 + s + AHEAD < ng_main)
+                load_group(g0, s + AHEAD, false, ua[(s + AHEAD) % NBUF], ub[(s + AHEAD) % NBUF], pp[(s + AHEAD) % NBUF]);
+            compute_group(ua[s % NBUF], ub[s % NBUF], pp[s % NBUF]);
+            __builtin_amdgcn_sched_barrier(0);  // keep the unrolled groups in program order (else the loads of all
+                                                // SUPER groups are hoisted and the kernel spills)
         }
     }
+    // remainder (< SUPER groups, plus the padded cells of the last slice): unpipelined, P index clamped
+    for (int g = ng_main; g < ngroups; ++g) {
+        load_group(g, 0, true, ua[0], ub[0], pp[0]);
+        compute_group(ua[0], ub[0], pp[0]);
+    }
+
 
     double* out = partial + ((size_t)slice * npairs + pair) * (size_t)(GT * GT);
 #pragma unroll
