@@ -404,36 +404,23 @@ constexpr int UG = MVF_UG;  // k-steps (of 4 cells) per software-pipeline group
 template <typename T> struct CachedPipe { static constexpr int UGT = UG, NBUF = 2; };
 template <> struct CachedPipe<double> { static constexpr int UGT = MVF_DBL_UG, NBUF = MVF_DBL_NBUF; };
 
-template <typename T>
-__global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const T* __restrict__ ublk, const T* __restrict__ P,
-                                                             int64_t n, int64_t n_pad, int nt, int npairs,
-                                                             int64_t slice_len, double* __restrict__ partial) {
-    // Wave tile 32 x 128 (NA = 2 row blocks x NB = 8 column blocks of 16): the four waves of the workgroup stack in
-    // the row direction and all read the same 8 column panels (L1 hits).  Per k-step a lane does 10 loads and only
-    // TWO v_mul_f64 (P K, kept exact) for 16 MFMAs - the f64 VALU work is what steals MFMA time on gfx950.
-    constexpr int NA = 2, NB = 8;
+// One wave's share of a tile: NA x NB blocks of 16 x 16 (TRI: only the blocks b >= a of a square arrangement) whose
+// first row block is `rb0` and first column block `cb0` (absolute 16-wide block indices into Ublk); results go to
+// out[(orow0 + ...) * GT + ocol0 + ...] of the 128 x 128 partial tile.
+template <typename T, int NA, int NB, bool TRI>
+__device__ __forceinline__ void cached_block(const T* __restrict__ ublk, const T* __restrict__ P, int64_t n,
+                                             int64_t n_pad, int64_t n0, int64_t n1, int64_t rb0, int64_t cb0,
+                                             double* __restrict__ out, int orow0, int ocol0) {
     constexpr int UGT = CachedPipe<T>::UGT, NBUF = CachedPipe<T>::NBUF;
-    const int pair = blockIdx.x % npairs;
-    const int64_t slice = blockIdx.x / npairs;
-    int ti, tj;
-    decode_pair(pair, nt, ti, tj);
-    const int64_t n0 = slice * slice_len;
-    const int64_t n1 = min(n_pad, n0 + slice_len);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
 
     const T* pa[NA];
     const T* pb[NB];
 #pragma unroll
-    for (int a = 0; a < NA; ++a) {
-        const int64_t cba = ((int64_t)ti * GT + wave * 32) / UB + a;
-        pa[a] = ublk + (cba * n_pad + n0 + lk) * UB + li;
-    }
+    for (int a = 0; a < NA; ++a) pa[a] = ublk + ((rb0 + a) * n_pad + n0 + lk) * UB + li;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int64_t cbb = ((int64_t)tj * GT) / UB + b;
-        pb[b] = ublk + (cbb * n_pad + n0 + lk) * UB + li;
-    }
+    for (int b = 0; b < NB; ++b) pb[b] = ublk + ((cb0 + b) * n_pad + n0 + lk) * UB + li;
 
     f64x4 acc[NA][NB];
 #pragma unroll
@@ -444,10 +431,10 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
     T ua[NBUF][UGT][NA], ub[NBUF][UGT][NB], pp[NBUF][UGT];
     const int ngroups = (int)((n1 - n0) / (4 * UGT));  // slices are multiples of 256 cells
 
-    // Address arithmetic is VALU work too (64-bit adds) and VALU time is additive to f64 MFMA time: the ten operand
+    // Address arithmetic is VALU work too (64-bit adds) and VALU time is additive to f64 MFMA time: the operand
     // pointers and the P pointer advance ONCE per superblock of SUPER groups (4 KB per pointer); inside it every load
     // uses a compile-time immediate offset.  P is read branch-free: cached rows of padded cells are zero, so any finite
-    // P does; only the slice that crosses n clamps its index (tail == true).
+    // P does; only the remainder loop clamps its index.
     constexpr int SUPER = 4096 / (UGT * 4 * UB * (int)sizeof(T));  // groups per 4 KB of one pointer's stream
     const T* pP = P + n0 + lk;
     const int pmax = (int)min((int64_t)0x3fffffff, n - 1 - n0 - lk);  // last valid index from pP (may be < 0: P[n-1])
@@ -503,7 +490,8 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
             for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                    if (!TRI || b >= a)
+                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
 #ifndef MVF_PROBE_NO_SETPRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
@@ -535,18 +523,60 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
         compute_group(ua[0], ub[0], pp[0]);
     }
 
-
-    double* out = partial + ((size_t)slice * npairs + pair) * (size_t)(GT * GT);
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
+            if (!TRI || b >= a) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wave * 32 + a * 16 + lk + 4 * r;
-                const int col = b * 16 + li;
-                out[row * GT + col] = acc[a][b][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int row = orow0 + a * 16 + lk + 4 * r;
+                    const int col = ocol0 + b * 16 + li;
+                    out[row * GT + col] = acc[a][b][r];
+                }
             }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const T* __restrict__ ublk, const T* __restrict__ P,
+                                                             int64_t n, int64_t n_pad, int64_t m, int nt, int npairs,
+                                                             int64_t slice_len, double* __restrict__ partial) {
+    // Off-diagonal tile: wave tile 32 x 128 (2 row blocks x 8 column blocks of 16) - the four waves stack in the row
+    // direction and all read the same 8 column panels (L1 hits); per k-step a lane does 10 loads and only TWO
+    // v_mul_f64 (P K, kept exact) for 16 MFMAs - the f64 VALU work is what steals MFMA time on gfx950.
+    // Work that the reduction never reads is not computed:
+    //  * last tile column with <= 64 live control points (m = 3000: 56 of 128): 2 x 4 blocks per wave;
+    //  * diagonal tile: only blocks on or above the diagonal - waves 0, 1 take the upper-right 64 x 64 quadrant
+    //    (2 x 4 blocks each), waves 2, 3 the upper triangles of the two diagonal quadrants (10 of 16 blocks each).
+    const int pair = blockIdx.x % npairs;
+    const int64_t slice = blockIdx.x / npairs;
+    int ti, tj;
+    decode_pair(pair, nt, ti, tj);
+    const int64_t n0 = slice * slice_len;
+    const int64_t n1 = min(n_pad, n0 + slice_len);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* out = partial + ((size_t)slice * npairs + pair) * (size_t)(GT * GT);
+    constexpr int TB = GT / UB;  // 8 blocks per tile side
+    const int64_t rb = (int64_t)ti * TB, cb = (int64_t)tj * TB;
+#ifdef MVF_PROBE_NO_SKIP
+    constexpr bool skip = false;
+#else
+    constexpr bool skip = sizeof(T) == 4;  // measured: +1.6 ... 3.2 % for float, -5 % for double (register pressure)
+#endif
+    if constexpr (!skip) {
+        cached_block<T, 2, 8, false>(ublk, P, n, n_pad, n0, n1, rb + 2 * wave, cb, out, 32 * wave, 0);
+    } else if (ti != tj) {
+        const int64_t live_cols = m - (int64_t)tj * GT;  // > 0
+        if (live_cols <= 4 * UB)
+            cached_block<T, 2, 4, false>(ublk, P, n, n_pad, n0, n1, rb + 2 * wave, cb, out, 32 * wave, 0);
+        else
+            cached_block<T, 2, 8, false>(ublk, P, n, n_pad, n0, n1, rb + 2 * wave, cb, out, 32 * wave, 0);
+    } else if (wave < 2) {
+        cached_block<T, 2, 4, false>(ublk, P, n, n_pad, n0, n1, rb + 2 * wave, cb + 4, out, 32 * wave, 64);
+    } else {
+        const int q = wave - 2;
+        cached_block<T, 4, 4, true>(ublk, P, n, n_pad, n0, n1, rb + 4 * q, cb + 4 * q, out, 64 * q, 64 * q);
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -793,10 +823,10 @@ extern "C" int mvf_gram_cached(int stages, const void* ublk, const void* x4, con
         const unsigned njobs = (unsigned)(p.nslices * p.npairs);
         if (dtype == MVF_F32)
             hipLaunchKernelGGL(gram_cached_kernel<float>, dim3(njobs), dim3(256), 0, st, (const float*)ublk,
-                               (const float*)P, n, ublk_npad(n), p.nt, p.npairs, p.slice_len, (double*)workspace);
+                               (const float*)P, n, ublk_npad(n), m, p.nt, p.npairs, p.slice_len, (double*)workspace);
         else
             hipLaunchKernelGGL(gram_cached_kernel<double>, dim3(njobs), dim3(256), 0, st, (const double*)ublk,
-                               (const double*)P, n, ublk_npad(n), p.nt, p.npairs, p.slice_len, (double*)workspace);
+                               (const double*)P, n, ublk_npad(n), m, p.nt, p.npairs, p.slice_len, (double*)workspace);
         MVF_LAUNCH_CHECK();
     }
     const int rest = stages & (MVF_GRAM_STAGE_RHS | MVF_GRAM_STAGE_REDUCE | MVF_GRAM_STAGE_REDUCE_RHS);
