@@ -31,7 +31,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dens
 PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X datasheet: FP64 matrix (v_mfma_f64_16x16x4_f64) dense peak
 PEAK_HBM_GBPS = 8000.0
 # (dtype, gram_mode, cached_u, gpus, cells, ctrl) -> corrected FETCH+WRITE bytes per launch of the dominant kernel
-PMC_TRAFFIC_BYTES = {("float32", "f64acc", True, 1, 8_000_000, 3000): 2.26e12 + 1.14e9}        # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
+PMC_TRAFFIC_BYTES = {("float32", "f64acc", True, 1, 8_000_000, 3000): 3.33e12 + 1.14e9}        # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 
 
 def log(*a):
