@@ -216,8 +216,6 @@ class SparseVFCEngine:
         self.P = torch.ones(self.n_local, dtype=k.tdtype, device=k.device)
         self.V4 = [k.zeros(self.n_local, 4) for _ in range(ng)]
         self.r = None
-        # Cholesky jitter (relative to the mean diagonal): start with none - then the solve equals the reference's
-        # lstsq wherever the system has full numerical rank - and escalate only when a pivot fails (sticky afterwards)
         # U = con_K(X, ctrl) is constant across EM iterations: cache its values (cell dtype) for the Gram kernel when HBM
         # has room ("auto": sizeof(dtype) n M bytes plus headroom), else the Gram kernel regenerates them every iteration
         self.cached_u = False
@@ -230,6 +228,8 @@ class SparseVFCEngine:
             if free is None or need + (8 << 30) < free:
                 k.build_ublk(self.x4, self.ctrl4, self.beta)
                 self.cached_u = True
+        # Cholesky jitter (relative to the mean diagonal): start with none - then the solve equals the reference's
+        # lstsq wherever the system has full numerical rank - and escalate only when a pivot fails (sticky afterwards)
         self.jitter = 0.0
         self.jitter_first = 1e-15  # both modes: G is accumulated in float64 (exact for the float32 kernel values)
         self.jitter_max = 1e-3

@@ -21,3 +21,11 @@ def golden():
     path = os.path.join(ROOT, "tests", "golden", "ref_twins.npz")
     with np.load(path) as z:
         return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def golden_align():
+    """Outputs of the real alignment-side reference functions (tests/golden/make_golden_align.py)."""
+    path = os.path.join(ROOT, "tests", "golden", "ref_align.npz")
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}

@@ -486,3 +486,17 @@ def test_full_size_c4_invariants_float32(st):
     # residuals and sigma^2 are consistent with V
     r_s = ((eng.y4[0][sel][:, :3].double() - got) ** 2).sum(1)
     assert float((eng.r[sel].double() - r_s).abs().max() / r_s.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-12), ("float32", 1e-5)])
+def test_ba_transform_against_reference_goldens(st, golden_align, dtype, tol):
+    """Alignment-side caller: BA_transform on the GPU against the outputs of the real
+    spateo/alignment/transform.py, and con_K against the alignment module's ||x||^2+||y||^2-2x.y formulation."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _align_case import check_ba
+
+    g = golden_align
+    check_ba(st.align.BA_transform, g, tol, dtype=dtype)
+    K = st.con_K(g["ak_x"], g["ak_y"], float(g["ak_beta"]), dtype=dtype)
+    assert _rel(K, g["ak_K"]) < (1e-13 if dtype == "float64" else 1e-6)

@@ -421,3 +421,20 @@ def test_unique_rows_matches_numpy_unique():
     a, ai = np.unique(Xn, axis=0, return_index=True)
     b, bi = unique_rows(Xn)
     assert np.array_equal(ai, bi) and np.array_equal(a, b, equal_nan=True)
+
+
+def test_ba_transform_matches_reference(cpu_kernels, golden_align):
+    """spateo_amd.align.BA_transform (host composition around the device field evaluation) against the outputs of the
+    real spateo/alignment/transform.py::BA_transform; con_K against the alignment module's own formulation."""
+    from _align_case import ba_dict, check_ba
+
+    g = golden_align
+    check_ba(st.align.BA_transform, g, 1e-12)
+    np.testing.assert_allclose(st.con_K(g["ak_x"], g["ak_y"], float(g["ak_beta"])), g["ak_K"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(st.con_K(g["ak_x2"], g["ak_y2"], 0.7), g["ak_K2"], rtol=1e-12, atol=0)
+    with pytest.raises(AssertionError):  # feature mismatch: the reference's con_K assertion (normalize_c False) ...
+        st.align.BA_transform(ba_dict(g, False), g["ba_raw_q"][:, :2])
+    with pytest.raises(ValueError):  # ... or NumPy's broadcast error in the normalisation, as in the reference
+        st.align.BA_transform(ba_dict(g, True), g["ba_q"][:, :2])
+    with pytest.raises(ValueError):
+        st.align.BA_transform(ba_dict(g, True), g["ba_q"], dtype="float16")

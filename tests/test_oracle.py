@@ -213,3 +213,17 @@ def test_bandwidth_selector_matches_bruteforce():
     d = np.sort(cdist(c, c), axis=1)[:, : max(2, int(0.2 * 50))]
     h = np.sqrt(2) * np.mean(d[:, 1:]) / 1.5
     np.testing.assert_allclose(svo.bandwidth_selector(c), h, rtol=1e-12)
+
+
+def test_alignment_oracle_pinned_by_reference(golden_align):
+    """oracle/align_oracle.py against outputs of the REAL spateo/alignment/methods/utils.py::con_K and
+    spateo/alignment/transform.py::BA_transform (tests/golden/make_golden_align.py)."""
+    from _align_case import check_ba
+    from oracle import align_oracle as ao
+
+    g = golden_align
+    np.testing.assert_allclose(ao.con_K(g["ak_x"], g["ak_y"], float(g["ak_beta"])), g["ak_K"], rtol=1e-13, atol=0)
+    np.testing.assert_allclose(ao.con_K(g["ak_x2"], g["ak_y2"], 0.7), g["ak_K2"], rtol=1e-13, atol=0)
+    # the dynamo-style oracle (cdist formulation) agrees with the alignment formulation to rounding
+    np.testing.assert_allclose(svo.con_K(g["ak_x"], g["ak_y"], float(g["ak_beta"])), g["ak_K"], rtol=1e-12, atol=0)
+    check_ba(ao.BA_transform, g, 1e-14)
