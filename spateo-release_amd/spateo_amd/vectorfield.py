@@ -69,12 +69,21 @@ def bandwidth_selector(X: np.ndarray) -> float:
     return float(np.sqrt(2) * d)
 
 
+_RNG_LOCK = __import__("threading").Lock()
+
+
 def sample_by_velocity(V: np.ndarray, n: int, seed: int = 19491001) -> np.ndarray:
-    """dynamo ``sample_by_velocity``: |V|-weighted sampling without replacement (re-seeds the global RNG, as dynamo)."""
-    np.random.seed(seed)
+    """dynamo ``sample_by_velocity``: |V|-weighted sampling without replacement.  dynamo re-seeds NumPy's GLOBAL RNG
+    (``np.random.seed(seed)``) and draws from it; here the draw comes from a private ``RandomState(seed)`` - the same
+    MT19937 stream, so the same indices - and the global RNG is then left in the state dynamo would leave it in, so
+    concurrent fits (``SparseVFC_many``) cannot interleave their draws."""
+    rs = np.random.RandomState(seed)
     tmp_V = np.linalg.norm(V, axis=1)
     p = tmp_V / np.sum(tmp_V)
-    return np.random.choice(np.arange(len(V)), size=n, p=p, replace=False)
+    idx = rs.choice(np.arange(len(V)), size=n, p=p, replace=False)
+    with _RNG_LOCK:
+        np.random.set_state(rs.get_state())
+    return idx
 
 
 def unique_rows(X: np.ndarray):
@@ -104,13 +113,9 @@ def unique_rows(X: np.ndarray):
     return S[keep], order[keep]
 
 
-_PREPROCESS_LOCK = __import__("threading").Lock()  # the sampling re-seeds NumPy's GLOBAL RNG (as dynamo does)
-
-
 def sparsevfc_preprocess(X, Y, M=100, beta=None, velocity_based_sampling=True, seed=0):
     """valid rows, unique rows, control points and beta exactly as dynamo's SparseVFC picks them."""
-    with _PREPROCESS_LOCK:
-        return _sparsevfc_preprocess(X, Y, M, beta, velocity_based_sampling, seed)
+    return _sparsevfc_preprocess(X, Y, M, beta, velocity_based_sampling, seed)
 
 
 def _sparsevfc_preprocess(X, Y, M, beta, velocity_based_sampling, seed):
@@ -121,7 +126,8 @@ def _sparsevfc_preprocess(X, Y, M, beta, velocity_based_sampling, seed):
     tmp_X, uid = unique_rows(Xv)
     M = min(M, tmp_X.shape[0])
     if velocity_based_sampling:
-        np.random.seed(seed)
+        # (dynamo seeds the global RNG with `seed` here and sample_by_velocity immediately re-seeds it with its own
+        # default, so `seed` has no effect on this branch - SURVEY App. A [VERIFY]; kept as is)
         idx = sample_by_velocity(Yv[uid], M)
     else:
         idx = np.random.RandomState(seed=seed).permutation(tmp_X.shape[0])

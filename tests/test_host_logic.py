@@ -438,3 +438,24 @@ def test_ba_transform_matches_reference(cpu_kernels, golden_align):
         st.align.BA_transform(ba_dict(g, True), g["ba_q"][:, :2])
     with pytest.raises(ValueError):
         st.align.BA_transform(ba_dict(g, True), g["ba_q"], dtype="float16")
+
+
+def test_sample_by_velocity_same_draw_and_same_global_rng_state_as_dynamo():
+    """The product draws from a private RandomState (thread-safe for SparseVFC_many) but must pick the same indices and
+    leave NumPy's global RNG where dynamo's `np.random.seed(seed); np.random.choice(...)` leaves it."""
+    import threading
+
+    from spateo_amd.vectorfield import sample_by_velocity
+
+    rng = np.random.default_rng(3)
+    V = rng.standard_normal((4000, 3))
+    a = sample_by_velocity(V, 150)
+    x1 = np.random.rand(3)
+    b = svo.sample_by_velocity(V, 150)
+    x2 = np.random.rand(3)
+    assert np.array_equal(a, b) and np.array_equal(x1, x2)
+    out = [None] * 6
+    ths = [threading.Thread(target=lambda i=i: out.__setitem__(i, sample_by_velocity(V, 150))) for i in range(6)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert all(np.array_equal(o, a) for o in out)
