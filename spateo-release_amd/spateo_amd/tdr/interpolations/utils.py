@@ -25,20 +25,17 @@ def get_X_Y_grid(
     """Returns ``(X, Y, Grid, grid_in_hull)``: a regular grid over the bounding box of X padded by 1 % per side
     (``utils.py:40-47``; note the reference pads ``max`` with the ALREADY padded ``min``), plus the convex-hull mask
     (``:50-53``).  Like the reference this is 3-D only (``:50`` indexes ``X[:, 2]``)."""
-    lm.main_info("Learn a continuous mapping from space to gene expression pattern")
     X, Y = adata.obsm["spatial"] if X is None else X, adata[:, genes].X if Y is None else Y
 
-    lm.main_info("Generate grid...")
+    lm.main_info(f"grid {list(grid_num)} over the 1 %-padded bounding box + convex-hull mask")
     min_vec, max_vec = X.min(0), X.max(0)
     min_vec = min_vec - 0.01 * np.abs(max_vec - min_vec)
     max_vec = max_vec + 0.01 * np.abs(max_vec - min_vec)
     axes = [np.linspace(lo, hi, k) for lo, hi, k in zip(min_vec, max_vec, grid_num)]
     Grid = np.stack([g.flatten() for g in np.meshgrid(*axes)], axis=1)
 
-    lm.main_info("Creating a Convex Hull...")
     from scipy.spatial import ConvexHull
 
     hull = ConvexHull(np.column_stack((X[:, 0], X[:, 1], X[:, 2])))
-    lm.main_info("Identify grid points within the Convex Hull...")
     grid_in_hull = _in_hull(Grid, hull.points[hull.vertices, :])
     return X, Y, Grid, grid_in_hull
