@@ -459,3 +459,35 @@ def test_sample_by_velocity_same_draw_and_same_global_rng_state_as_dynamo():
     [t.start() for t in ths]
     [t.join() for t in ths]
     assert all(np.array_equal(o, a) for o in out)
+
+
+def test_unique_rows_and_shard_bounds_properties():
+    """Property tests (hypothesis): unique_rows == np.unique(axis=0, return_index=True) on arbitrary small-alphabet
+    float matrices (many ties, signed zeros), and shard_bounds tiles [0, n) contiguously with sizes differing by <= 1."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as hs
+    from hypothesis.extra import numpy as hnp
+
+    from spateo_amd.vectorfield import shard_bounds, unique_rows
+
+    vals = hs.sampled_from([-2.0, -0.0, 0.0, 0.5, 1.0, 3.25, 1e-300, -1e300])
+
+    @settings(max_examples=150, deadline=None)
+    @given(hnp.arrays(np.float64, hnp.array_shapes(min_dims=2, max_dims=2, min_side=1, max_side=40).filter(
+        lambda s: s[1] <= 3), elements=vals))
+    def uniq(X):
+        a, ai = np.unique(X, axis=0, return_index=True)
+        b, bi = unique_rows(X)
+        assert np.array_equal(ai, bi) and a.tobytes() == b.tobytes()
+
+    @settings(max_examples=200, deadline=None)
+    @given(hs.integers(0, 10**7), hs.integers(1, 64))
+    def shards(n, world):
+        b = [shard_bounds(n, r, world) for r in range(world)]
+        assert b[0][0] == 0 and b[-1][1] == n
+        assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        sizes = [hi - lo for lo, hi in b]
+        assert max(sizes) - min(sizes) <= 1 and sorted(sizes, reverse=True) == sizes
+
+    uniq()
+    shards()
