@@ -45,7 +45,7 @@ enum {
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
 const char* mvf_last_error(void);
-int mvf_version(void);                 /* ABI version, currently 1 */
+int mvf_version(void);                 /* ABI version, currently 2 */
 int mvf_device_count(int* count);      /* number of visible HIP devices (0 without a GPU) */
 
 /* ---- con_K ----------------------------------------------------------------------------------------------------
@@ -84,10 +84,12 @@ int mvf_estep_p(const void* r, int64_t n, double sigma2, double gamma, double a,
 
 /* ---- M-step assembly:  G = U^T diag(P) U (m x m),  R = U^T diag(P) Y (m x 3)  --------------------------------
  * Replaces: `UP = U.T * repmat(P.T, M, 1); lhs = UP.dot(U) ...; rhs = UP.dot(Y)` of SparseVFC (App. A 5c; same
- * shape in-tree at spateo/alignment/methods/morpho_class.py:1266-1293).  MFMA kernel; U tiles are regenerated from
- * x4/ctrl4 in registers, accumulated in short float32 MFMA chains folded into float64, reduced deterministically.
- * Outputs are float64: G (m x m, full symmetric), R (m x 3).  They hold THIS rank's partial sums; the caller
- * all-reduces [G | R | scalars] across ranks (one RCCL all-reduce per EM step). */
+ * shape in-tree at spateo/alignment/methods/morpho_class.py:1266-1293).  MFMA kernel; the kernel values (cell dtype)
+ * are regenerated from x4/ctrl4 in registers and accumulated with v_mfma_f64_16x16x4_f64, so G is the exact Gram
+ * matrix of those values; per-slice partial tiles are summed in a fixed order (deterministic).
+ * Outputs are float64: G (m x m, full symmetric), R (m x 3).  They hold THIS rank's partial sums.  The collective is
+ * the CALLER's: the library holds no communicator; the host all-reduces the contiguous [G | R | scalars] buffer with
+ * torch.distributed (RCCL over xGMI) - one all-reduce per EM step. */
 size_t mvf_gram_workspace_bytes(int64_t n, int64_t m, mvf_dtype dtype);
 /* How the MVF_F32 Gram kernel accumulates (process-wide; MVF_F64 is unaffected):
  *   MVF_GRAM_MODE_F64_ACC  (default) float32 operand generation, v_mfma_f64_16x16x4_f64 accumulation: G is the exact
@@ -120,15 +122,37 @@ int mvf_gram_cached(int stages, const void* ublk, const void* x4, const void* P,
                     const void* ctrl4, int64_t m, double beta, double* G, double* R, void* workspace,
                     size_t workspace_bytes, mvf_dtype dtype, void* stream);
 
-/* ---- coefficient solve:  (G + lambda_sigma2 * K + jitter * mean(diag) * I) C = R  ------------------------------
- * Replaces: dynamo `lstsq_solver(lhs, rhs, "scipy")` as Spateo calls it (sparsevfc.py:110,194,250).  Blocked
- * right-looking Cholesky in float64 (MFMA f64 for the trailing update) + forward/back substitution.  The system is
- * symmetric PSD and numerically rank-deficient; see DESIGN.md for why the field (not C) is the parity quantity.
- * G, K: m x m float64 (read-only), R: m x nrhs, C out: m x nrhs.  info[0] = 0 on success, or 1 + index of the first
- * non-positive pivot (caller retries with a larger jitter).  workspace >= mvf_solve_workspace_bytes. */
+/* ---- coefficient solve ------------------------------------------------------------------------------------------
+ * Replaces: dynamo `lstsq_solver(lhs, rhs, "scipy")` as Spateo calls it (sparsevfc.py:110,194,250) =
+ * scipy.linalg.lstsq = LAPACK gelsd: the MINIMUM-NORM solution with singular values below eps * s_max dropped
+ * (in-tree analogue: `_pinv(SigmaInv)` spateo/alignment/methods/morpho_class.py:1287).  lhs = G + lambda_sigma2 * K is
+ * symmetric, numerically positive SEMI-definite and, at Spateo's default lambda_ = 0.02, rank deficient.  Two entry
+ * points; the host (vectorfield.py) uses the first when it certifies full numerical rank and the second otherwise:
+ *
+ * mvf_solve: (G + lambda_sigma2 K + jitter * mean(diag) * I) C = R by blocked right-looking Cholesky in float64 (f64
+ *   MFMA trailing update) + forward/back substitution.  With jitter = 0 and a matrix of full numerical rank this IS
+ *   the gelsd solution (nothing is truncated).  info[0] = 0 on success, or 1 + index of the first non-positive pivot.
+ *   pivots (may be NULL): [0] = min_j L_jj^2, [1] = max_j L_jj^2 - min L_jj^2 is an upper bound of lambda_min, the
+ *   host's rank certificate.  G, K: m x m float64 (read-only), R: m x nrhs, C out: m x nrhs, nrhs <= 8.
+ *
+ * mvf_solve_minnorm: C = sum_{|lambda_i| > rcond max|lambda|} q_i (q_i^T R) / lambda_i over the eigenpairs of
+ *   G + lambda_sigma2 K (for a symmetric matrix exactly gelsd's SVD-truncated minimum-norm solution; rcond =
+ *   DBL_EPSILON reproduces scipy's default).  Hand-written symmetric eigensolver: Cholesky of the matrix shifted by
+ *   delta = shift * mean(diag) (0 < shift < 1; the shift only makes the factorisation exist and is subtracted from the
+ *   eigenvalues again), then one-sided block Jacobi (f64 MFMA Gram and update tiles, 64 x 64 subproblems in LDS) on
+ *   the factor's columns until a whole sweep applies no rotation.  info[0] != 0: the shift was too small for this
+ *   matrix (the caller retries with a larger one); C is then not written.  einfo (12 float64, device): [0] = sweeps
+ *   (x.5 if max_sweeps was hit first), [1] = kept rank, [2] = max|lambda|, [3] = min kept |lambda|, [4] = delta,
+ *   [5] = min lambda.  NOT asynchronous: it synchronises `stream` once per sweep to read the rotation counter.
+ *   reuse != 0: the decomposition of the previous call on this workspace (same matrix) is applied to another R (a
+ *   wide Y is solved in groups of <= 8 columns); asynchronous, einfo must hold 12 float64 ([6..11] = this call's). */
 size_t mvf_solve_workspace_bytes(int64_t m, int nrhs);
 int mvf_solve(const double* G, const double* K, double lambda_sigma2, double jitter, const double* R, int64_t m,
-              int nrhs, double* C, int* info, void* workspace, size_t workspace_bytes, void* stream);
+              int nrhs, double* C, int* info, double* pivots, void* workspace, size_t workspace_bytes, void* stream);
+size_t mvf_solve_minnorm_workspace_bytes(int64_t m, int nrhs);
+int mvf_solve_minnorm(const double* G, const double* K, double lambda_sigma2, double shift, double rcond,
+                      const double* R, int64_t m, int nrhs, double* C, int* info, double* einfo, int max_sweeps,
+                      int reuse, void* workspace, size_t workspace_bytes, void* stream);
 
 /* trace(C^T K C) -> out[0] (float64), the regulariser of the energy (App. A 5b). K: m x m, C: m x nrhs. */
 int mvf_quadform(const double* K, const double* C, int64_t m, int nrhs, double* out, void* stream);

@@ -20,7 +20,7 @@ int set_error(const char* fmt, ...) {
 
 extern "C" const char* mvf_last_error(void) { return mvf::err_buf(); }
 
-extern "C" int mvf_version(void) { return 1; }
+extern "C" int mvf_version(void) { return 2; }
 
 extern "C" int mvf_device_count(int* count) {
     if (!count) return mvf::set_error("mvf_device_count: null pointer");

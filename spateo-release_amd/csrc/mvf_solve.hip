@@ -13,10 +13,11 @@
 // The right-hand sides ride along as extra ROWS of the trapezoidal matrix, so the forward substitution L Y = R falls
 // out of trsm/syrk for free; the back substitution L^T C = Y is one small kernel per block column.
 #include "mvf_common.h"
+#include "mvf_solve.h"
 
 namespace mvf {
 
-constexpr int NB = 64;
+constexpr int NB = CHOL_NB;
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // mean of the diagonal of G + ls2*K  ->  scal[0];  scal[1] = jitter * mean
@@ -339,50 +340,67 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const double* __restrict
     if (i < count) dst[i] = src[i];
 }
 
-}  // namespace mvf
-
-using namespace mvf;
+// min / max of the squared Cholesky pivots L_jj^2 (j < m) from rdiag = 1 / L_jj  ->  piv[0], piv[1]
+__global__ __launch_bounds__(256) void pivot_range_kernel(const double* __restrict__ rdiag, int64_t m,
+                                                          double* __restrict__ piv) {
+    double lo = INFINITY, hi = 0.0;
+    for (int64_t i = threadIdx.x; i < m; i += 256) {
+        const double l = 1.0 / rdiag[i];
+        lo = fmin(lo, l * l);
+        hi = fmax(hi, l * l);
+    }
+    __shared__ double red[4];
+    const double tlo = block_min<256>(lo, red);
+    const double thi = -block_min<256>(-hi, red);
+    if (threadIdx.x == 0) {
+        piv[0] = tlo;
+        piv[1] = thi;
+    }
+}
 
 static inline int64_t solve_mp(int64_t m) { return cdiv(m, NB) * NB; }
 
-extern "C" size_t mvf_solve_workspace_bytes(int64_t m, int nrhs) {
+size_t chol_workspace_bytes(int64_t m, int nrhs) {
     if (m <= 0) return 0;
     const int64_t mp = solve_mp(m), mr = mp + NB;
     return align_up((size_t)mr * mp * sizeof(double), 256) + align_up((size_t)mp * std::max(nrhs, 1) * sizeof(double), 256) +
            align_up((size_t)mp * 8 * sizeof(double), 256) + align_up((size_t)mp * sizeof(double), 256) + 256;
 }
 
-extern "C" int mvf_solve(const double* G, const double* K, double lambda_sigma2, double jitter, const double* R,
-                         int64_t m, int nrhs, double* C, int* info, void* workspace, size_t workspace_bytes,
-                         void* stream) {
-    MVF_REQUIRE(m >= 0 && nrhs >= 1 && nrhs <= 8, "mvf_solve: need m >= 0 and 1 <= nrhs <= 8 (got m=%lld nrhs=%d)",
-                (long long)m, nrhs);
-    MVF_REQUIRE(info, "mvf_solve: null info");
-    hipStream_t st = (hipStream_t)stream;
-    MVF_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
-    if (m == 0) return 0;
-    MVF_REQUIRE(G && K && R && C, "mvf_solve: null pointer");
-    MVF_REQUIRE(std::isfinite(lambda_sigma2) && lambda_sigma2 >= 0.0 && jitter >= 0.0, "mvf_solve: bad regularisation");
-    const size_t need = mvf_solve_workspace_bytes(m, nrhs);
-    MVF_REQUIRE(workspace && workspace_bytes >= need, "mvf_solve: workspace too small (%zu < %zu)", workspace_bytes, need);
+// Lays out the workspace, builds W = [G + ls2 K + shift mean(diag) I ; R^T] and factors it in place (lower triangle of
+// the first mp rows = L, rows mp.. = the forward-substituted right-hand sides).  Asynchronous on `st`; info[0] = 0 or
+// 1 + index of the first non-positive pivot.
+void chol_layout(int64_t m, int nrhs, void* workspace, CholPlan* pl) {
     const int64_t mp = solve_mp(m), mr = mp + NB;
-    const int nb = (int)(mp / NB), nbr = nb + 1;
-    double* W = (double*)workspace;
-    double* Cp = (double*)((char*)workspace + align_up((size_t)mr * mp * sizeof(double), 256));
-    double* Yw = (double*)((char*)Cp + align_up((size_t)mp * nrhs * sizeof(double), 256));
-    double* rdiag = (double*)((char*)Yw + align_up((size_t)mp * 8 * sizeof(double), 256));
-    double* scal = (double*)((char*)rdiag + align_up((size_t)mp * sizeof(double), 256));
+    pl->mp = mp;
+    pl->mr = mr;
+    pl->nb = (int)(mp / NB);
+    pl->nbr = pl->nb + 1;
+    pl->W = (double*)workspace;
+    pl->Cp = (double*)((char*)workspace + align_up((size_t)mr * mp * sizeof(double), 256));
+    pl->Yw = (double*)((char*)pl->Cp + align_up((size_t)mp * std::max(nrhs, 1) * sizeof(double), 256));
+    pl->rdiag = (double*)((char*)pl->Yw + align_up((size_t)mp * 8 * sizeof(double), 256));
+    pl->scal = (double*)((char*)pl->rdiag + align_up((size_t)mp * sizeof(double), 256));
+}
 
-    hipLaunchKernelGGL(diag_mean_kernel, dim3(1), dim3(256), 0, st, G, K, lambda_sigma2, jitter, m, scal);
+int chol_factor(hipStream_t st, const double* G, const double* K, double ls2, double shift, const double* R, int64_t m,
+                int nrhs, void* workspace, CholPlan* pl, int* info) {
+    chol_layout(m, nrhs, workspace, pl);
+    const int64_t mp = pl->mp, mr = pl->mr;
+    const int nb = pl->nb, nbr = pl->nbr;
+    double* W = pl->W;
+    MVF_REQUIRE(mr <= 65535, "coefficient solve: m too large (%lld)", (long long)m);
+    MVF_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+    hipLaunchKernelGGL(diag_mean_kernel, dim3(1), dim3(256), 0, st, G, K, ls2, shift, m, pl->scal);
     MVF_LAUNCH_CHECK();
-    MVF_REQUIRE(mr <= 65535, "mvf_solve: m too large (%lld)", (long long)m);
-    hipLaunchKernelGGL(chol_prepare_kernel, dim3((unsigned)cdiv(mp, 256), (unsigned)mr), dim3(256), 0, st, G, K,
-                       lambda_sigma2, scal, R, m, nrhs, mp, mr, W);
+    hipLaunchKernelGGL(chol_prepare_kernel, dim3((unsigned)cdiv(mp, 256), (unsigned)mr), dim3(256), 0, st, G, K, ls2,
+                       pl->scal, R, m, nrhs, mp, mr, W);
     MVF_LAUNCH_CHECK();
     for (int k = 0; k < nb; ++k) {
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, W, mp, k, rdiag, info);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, W, mp, k, pl->rdiag, info);
         const int64_t rows_below = mr - (int64_t)(k + 1) * NB;
-        hipLaunchKernelGGL(trsm_panel_kernel, dim3((unsigned)cdiv(rows_below, 64)), dim3(256), 0, st, W, mp, mr, k, rdiag);
+        hipLaunchKernelGGL(trsm_panel_kernel, dim3((unsigned)cdiv(rows_below, 64)), dim3(256), 0, st, W, mp, mr, k,
+                           pl->rdiag);
         // tiles: sum over i in (k, nbr) of (min(i, nb-1) - k)
         int64_t ntiles = 0;
         for (int i = k + 1; i < nbr; ++i) ntiles += std::min(i, nb - 1) - k;
@@ -390,11 +408,42 @@ extern "C" int mvf_solve(const double* G, const double* K, double lambda_sigma2,
             hipLaunchKernelGGL(syrk_update_kernel, dim3((unsigned)ntiles), dim3(256), 0, st, W, mp, k, nb, nbr);
     }
     MVF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bsub_init_kernel<8>, dim3((unsigned)cdiv(mp, 256)), dim3(256), 0, st, W, mp, nrhs, Yw);
-    for (int k = nb - 1; k >= 0; --k)
-        hipLaunchKernelGGL(bsub_step_kernel<8>, dim3((unsigned)(k + 1)), dim3(256), 0, st, W, mp, k, nrhs, rdiag, Yw, Cp);
+    return 0;
+}
+
+}  // namespace mvf
+
+using namespace mvf;
+
+extern "C" size_t mvf_solve_workspace_bytes(int64_t m, int nrhs) { return chol_workspace_bytes(m, nrhs); }
+
+extern "C" int mvf_solve(const double* G, const double* K, double lambda_sigma2, double jitter, const double* R,
+                         int64_t m, int nrhs, double* C, int* info, double* pivots, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    MVF_REQUIRE(m >= 0 && nrhs >= 1 && nrhs <= 8, "mvf_solve: need m >= 0 and 1 <= nrhs <= 8 (got m=%lld nrhs=%d)",
+                (long long)m, nrhs);
+    MVF_REQUIRE(info, "mvf_solve: null info");
+    hipStream_t st = (hipStream_t)stream;
+    if (m == 0) {
+        MVF_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+        return 0;
+    }
+    MVF_REQUIRE(G && K && R && C, "mvf_solve: null pointer");
+    MVF_REQUIRE(std::isfinite(lambda_sigma2) && lambda_sigma2 >= 0.0 && jitter >= 0.0, "mvf_solve: bad regularisation");
+    const size_t need = mvf_solve_workspace_bytes(m, nrhs);
+    MVF_REQUIRE(workspace && workspace_bytes >= need, "mvf_solve: workspace too small (%zu < %zu)", workspace_bytes, need);
+    CholPlan pl;
+    if (int rc = chol_factor(st, G, K, lambda_sigma2, jitter, R, m, nrhs, workspace, &pl, info)) return rc;
+    if (pivots) {
+        hipLaunchKernelGGL(pivot_range_kernel, dim3(1), dim3(256), 0, st, pl.rdiag, m, pivots);
+        MVF_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(bsub_init_kernel<8>, dim3((unsigned)cdiv(pl.mp, 256)), dim3(256), 0, st, pl.W, pl.mp, nrhs, pl.Yw);
+    for (int k = pl.nb - 1; k >= 0; --k)
+        hipLaunchKernelGGL(bsub_step_kernel<8>, dim3((unsigned)(k + 1)), dim3(256), 0, st, pl.W, pl.mp, k, nrhs,
+                           pl.rdiag, pl.Yw, pl.Cp);
     MVF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)cdiv(m * nrhs, 256)), dim3(256), 0, st, Cp, m * nrhs, C);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)cdiv(m * nrhs, 256)), dim3(256), 0, st, pl.Cp, m * nrhs, C);
     MVF_LAUNCH_CHECK();
     return 0;
 }

@@ -34,6 +34,7 @@ class HipKernels:
         self.tdtype, self.cdtype = _DT[dtype]
         self._gram_ws = None
         self._solve_ws = None
+        self._mn_ws = None
         self._mins = torch.empty(_lib.MVF_ESTEP_MIN_DOUBLES, dtype=torch.float64, device=self.device)
         # optional per-launch timing of the dominant (Gram MFMA) kernel: list of (start, end) torch events recorded
         # on the launch stream; bench.py sets this to [] to enable it
@@ -159,14 +160,33 @@ class HipKernels:
         self.gram_events.append((e0, e1))
         run(_lib.GRAM_RHS | _lib.GRAM_REDUCE | _lib.GRAM_REDUCE_RHS)
 
-    def solve(self, G, K, lambda_sigma2, jitter, R, C_out, info):
+    def solve(self, G, K, lambda_sigma2, jitter, R, C_out, info, pivots=None):
+        """Cholesky solve of (G + ls2 K + jitter mean(diag) I) C = R.  info[0] != 0: non-positive pivot.
+        pivots (float64[2], optional): [min L_jj^2, max L_jj^2] - the host's numerical-rank certificate."""
         m, nrhs = R.shape
         need = self.lib.mvf_solve_workspace_bytes(m, nrhs)
         if self._solve_ws is None or self._solve_ws.numel() < need:
             self._solve_ws = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
         _lib.check(self.lib.mvf_solve(_ptr(G), _ptr(K), float(lambda_sigma2), float(jitter), _ptr(R), m, nrhs,
-                                      _ptr(C_out), _ptr(info), _ptr(self._solve_ws), self._solve_ws.numel(),
-                                      self._stream()), "mvf_solve")
+                                      _ptr(C_out), _ptr(info), _ptr(pivots), _ptr(self._solve_ws),
+                                      self._solve_ws.numel(), self._stream()), "mvf_solve")
+
+    def solve_minnorm(self, G, K, lambda_sigma2, shift, R, C_out, info, einfo, rcond=None, reuse=False, max_sweeps=60):
+        """Minimum-norm solve with the gelsd cut-off (eigenvalues below rcond * max|lambda| dropped; rcond = float64
+        eps = scipy.linalg.lstsq's default).  reuse=True applies the decomposition left in the workspace by the
+        previous call (same matrix) to another right-hand side.  Synchronises the stream (once per Jacobi sweep)."""
+        m, nrhs = R.shape
+        need = self.lib.mvf_solve_minnorm_workspace_bytes(m, nrhs)
+        if self._mn_ws is None or self._mn_ws.numel() < need:
+            if reuse:
+                raise RuntimeError("solve_minnorm(reuse=True) without a previous decomposition")
+            self._mn_ws = None
+            self._mn_ws = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
+        rc = float(np.finfo(np.float64).eps) if rcond is None else float(rcond)
+        _lib.check(self.lib.mvf_solve_minnorm(_ptr(G), _ptr(K), float(lambda_sigma2), float(shift), rc, _ptr(R), m,
+                                              nrhs, _ptr(C_out), _ptr(info), _ptr(einfo), int(max_sweeps),
+                                              1 if reuse else 0, _ptr(self._mn_ws), self._mn_ws.numel(),
+                                              self._stream()), "mvf_solve_minnorm")
 
     def quadform(self, K, C, out):
         _lib.check(self.lib.mvf_quadform(_ptr(K), _ptr(C), K.shape[0], C.shape[1], _ptr(out), self._stream()),

@@ -45,6 +45,27 @@ def _make_kernels(device, dtype):
     return HipKernels(device, dtype)
 
 
+_LSTSQ_WARNED = set()
+
+
+def _check_lstsq_method(method):
+    """"scipy": the reference's call (Spateo always passes it, sparsevfc.py:110,194,250) - minimum-norm solve with
+    gelsd's eps * s_max cut-off.  "drouin" (dynamo's default: np.linalg.solve on the normal equations lhs^T lhs) has
+    the same exact-arithmetic solution; its squared-condition-number arithmetic is not reproduced - the "scipy" solve is
+    used and a warning says so once.  "cholesky" (extension): jitter-escalated Cholesky, no truncation."""
+    if method in ("scipy", "cholesky"):
+        return method
+    if method not in _LSTSQ_WARNED:
+        _LSTSQ_WARNED.add(method)
+        import warnings
+
+        what = "the normal-equations arithmetic of 'drouin' is not reproduced" if method == "drouin" else \
+            f"unknown lstsq_method {method!r} (dynamo falls back to 'drouin' with a warning)"
+        warnings.warn(f"spateo_amd.SparseVFC: {what}; solving with the 'scipy' (minimum-norm, gelsd cut-off) "
+                      f"semantics on the device.", RuntimeWarning, stacklevel=3)
+    return "scipy"
+
+
 def set_default_dtype(dtype: str):
     """Cell dtype used when a call does not pass ``dtype=``: "float64" (parity mode) or "float32" (fast mode)."""
     global _DEFAULT_DTYPE
@@ -234,10 +255,20 @@ class SparseVFCEngine:
             if free is None or need + (8 << 30) < free:
                 k.build_ublk(self.x4, self.ctrl4, self.beta)
                 self.cached_u = True
-        # Cholesky jitter (relative to the mean diagonal): start with none - then the solve equals the reference's
-        # lstsq wherever the system has full numerical rank - and escalate only when a pivot fails (sticky afterwards)
+        # Coefficient solve (lstsq_method "scipy" = the reference's gelsd semantics): Cholesky with NO regularisation
+        # while the pivots certify full numerical rank (then nothing is truncated and it IS the gelsd solution), else
+        # the truncated minimum-norm solve (mvf_solve_minnorm).  Rank deficiency is sticky within a fit: sigma^2 only
+        # shrinks, so lambda sigma^2 K never comes back.
+        self.lstsq_method = "scipy"
+        self.rank_deficient = False
+        self.mn_shift = 2.0 ** -36       # Cholesky shift of the eigensolver (relative to mean(diag); subtracted again)
+        self.pivot_ratio = 2.0 ** -40    # full rank is certified when min L_jj^2 > pivot_ratio * max L_jj^2
+        self.solver_stats = {"cholesky": 0, "minnorm": 0, "sweeps": [], "rank": []}
+        self.pivots = k.zeros(2, dtype=f64)
+        self.einfo = k.zeros(12, dtype=f64)
+        # lstsq_method="cholesky" (extension, not a reference mode): jitter-escalated Cholesky, the round-1 solver
         self.jitter = 0.0
-        self.jitter_first = 1e-15  # both modes: G is accumulated in float64 (exact for the float32 kernel values)
+        self.jitter_first = 1e-15
         self.jitter_max = 1e-3
         self.solve_retries = 0
         self.E = 1.0
@@ -266,6 +297,7 @@ class SparseVFCEngine:
         self.sigma2 = 1e-7 if s2 < 1e-8 else s2
         self.gamma = float(gamma)
         self.E, self.tecr, self.iteration = 1.0, 1.0, 0
+        self.rank_deficient = False
 
     def _apply_all(self, ctrl4):
         """V_g = U C_g for every column group; r = sum_g ||Y_g - V_g||^2; spr += sum P r."""
@@ -295,34 +327,9 @@ class SparseVFCEngine:
         for g in range(self.ng):
             k.quadform(self.K, self.C[g], self.quad[g : g + 1])
         self._all_reduce(self.red)  # the one big collective per EM step: [G | R | stats]
-        # ---- coefficient solve (jitter escalates only if a pivot fails; it is sticky afterwards)
-        ls2 = lambda_ * self.sigma2
-        while True:
-            fail = 0
-            if self.ng == 1:
-                k.solve(self.G, self.K, ls2, self.jitter, self.R[0], self.C_new[0], self.info)
-            else:
-                # wide Y: one factorisation serves two 3-column groups (mvf_solve takes up to 8 right-hand sides)
-                for g0 in range(0, self.ng, 2):
-                    gs = list(range(g0, min(g0 + 2, self.ng)))
-                    Rcat = torch.cat([self.R[g] for g in gs], dim=1).contiguous()
-                    Ccat = torch.empty_like(Rcat)
-                    k.solve(self.G, self.K, ls2, self.jitter, Rcat, Ccat, self.info)
-                    for j, g in enumerate(gs):
-                        self.C_new[g].copy_(Ccat[:, 3 * j : 3 * j + 3])
-                    if gs[-1] + 1 < self.ng:
-                        fail = max(fail, int(self.info.cpu()[0]))
-            host = torch.cat([self.st, self.quad.sum().reshape(1), self.info.to(torch.float64)]).cpu()
-            host[5] = max(float(host[5]), float(fail))
-            if int(host[5]) == 0:
-                break
-            self.solve_retries += 1
-            self.jitter = max(self.jitter * 10.0, self.jitter_first)
-            if self.jitter > self.jitter_max:
-                raise _lib.MVFError(
-                    f"coefficient solve failed: non-positive pivot at {int(host[5]) - 1} even with jitter "
-                    f"{self.jitter:g}; the system is not numerically PSD (NaN/Inf in the inputs?)"
-                )
+        # ---- coefficient solve
+        self._solve_all(lambda_ * self.sigma2)
+        host = torch.cat([self.st, self.quad.sum().reshape(1)]).cpu()
         s_pr, s_p, s_pf, s_cnt, quad = (float(host[i]) for i in range(5))
         E_old = self.E
         E = s_pr / (2 * self.sigma2) + s_p * math.log(self.sigma2) * self.Dy / 2 + lambda_ / 2 * quad
@@ -339,7 +346,72 @@ class SparseVFCEngine:
         self.iteration += 1
         return self.E, self.tecr
 
-    def fit(self, *, a=5, gamma=0.9, lambda_=3, minP=1e-5, MaxIter=500, theta=0.75, ecr=1e-5):
+    def _rhs_batches(self):
+        """Column groups are solved two at a time (mvf_solve / mvf_solve_minnorm take up to 8 right-hand sides)."""
+        return [list(range(g0, min(g0 + 2, self.ng))) for g0 in range(0, self.ng, 2)]
+
+    def _solve_batch(self, gs, fn):
+        """fn(R, C_out) for the concatenated right-hand sides of the column groups `gs`; scatters C back."""
+        if len(gs) == 1:
+            fn(self.R[gs[0]], self.C_new[gs[0]])
+            return
+        Rcat = torch.cat([self.R[g] for g in gs], dim=1).contiguous()
+        Ccat = torch.empty_like(Rcat)
+        fn(Rcat, Ccat)
+        for j, g in enumerate(gs):
+            self.C_new[g].copy_(Ccat[:, 3 * j : 3 * j + 3])
+
+    def _solve_all(self, ls2):
+        """C_new = lstsq(G + ls2 K, R) for every column group, with the semantics `self.lstsq_method` names."""
+        k = self.k
+        batches = self._rhs_batches()
+        if self.lstsq_method == "cholesky":
+            while True:
+                fail = 0
+                for gs in batches:
+                    self._solve_batch(gs, lambda R, C: k.solve(self.G, self.K, ls2, self.jitter, R, C, self.info))
+                    fail = max(fail, int(self.info.cpu()[0]))
+                if fail == 0:
+                    self.solver_stats["cholesky"] += 1
+                    return
+                self.solve_retries += 1
+                self.jitter = max(self.jitter * 10.0, self.jitter_first)
+                if self.jitter > self.jitter_max:
+                    raise _lib.MVFError(
+                        f"coefficient solve failed: non-positive pivot at {fail - 1} even with jitter "
+                        f"{self.jitter:g}; the system is not numerically PSD (NaN/Inf in the inputs?)")
+        if not self.rank_deficient:
+            # un-regularised Cholesky; its pivots certify (or refute) full numerical rank
+            self._solve_batch(batches[0], lambda R, C: k.solve(self.G, self.K, ls2, 0.0, R, C, self.info, self.pivots))
+            h = torch.cat([self.info.to(torch.float64), self.pivots]).cpu()
+            ok = int(h[0]) == 0 and float(h[1]) > self.pivot_ratio * float(h[2])
+            if ok:
+                for gs in batches[1:]:
+                    self._solve_batch(gs, lambda R, C: k.solve(self.G, self.K, ls2, 0.0, R, C, self.info))
+                self.solver_stats["cholesky"] += 1
+                return
+            self.rank_deficient = True
+        # truncated minimum-norm solve (gelsd cut-off eps * max|lambda|); the shift only has to make the Cholesky
+        # factorisation inside the eigensolver exist, it is subtracted from the eigenvalues again
+        while True:
+            self._solve_batch(batches[0], lambda R, C: k.solve_minnorm(self.G, self.K, ls2, self.mn_shift, R, C,
+                                                                       self.info, self.einfo))
+            if int(self.info.cpu()[0]) == 0:
+                break
+            self.mn_shift *= 16.0
+            if self.mn_shift > 2.0 ** -12:
+                raise _lib.MVFError("coefficient solve failed: G + lambda sigma^2 K is not numerically positive "
+                                    "semi-definite (NaN/Inf in the inputs?)")
+        for gs in batches[1:]:
+            self._solve_batch(gs, lambda R, C: k.solve_minnorm(self.G, self.K, ls2, self.mn_shift, R, C, self.info,
+                                                               self.einfo, reuse=True))
+        e = self.einfo.cpu()
+        self.solver_stats["minnorm"] += 1
+        self.solver_stats["sweeps"].append(float(e[0]))
+        self.solver_stats["rank"].append(int(e[1]))
+
+    def fit(self, *, a=5, gamma=0.9, lambda_=3, minP=1e-5, MaxIter=500, theta=0.75, ecr=1e-5, lstsq_method="scipy"):
+        self.lstsq_method = _check_lstsq_method(lstsq_method)
         self.init_state(gamma)
         tecr_vec, E_vec = [], []
         while self.iteration < MaxIter and self.tecr > ecr and self.sigma2 > 1e-8:
@@ -476,8 +548,12 @@ def SparseVFC(
 
     Extra keyword-only arguments: ``dtype`` ("float64" parity mode | "float32" fast mode), ``device``,
     ``distributed``/``group`` (every rank passes the same full X, Y; cells are block-sharded across ranks).
-    ``lstsq_method`` is accepted for compatibility: both "scipy" and "drouin" map to the device Cholesky solve
-    (DESIGN.md "Solve parity").  Returns the reference's dict with host NumPy float64 arrays.
+    ``lstsq_method``: "scipy" (what Spateo passes) = minimum-norm solve with gelsd's eps * s_max cut-off on the
+    device (Cholesky while the pivots certify full numerical rank, else the hand-written symmetric eigensolver);
+    "drouin" maps to the same solve with a warning; "cholesky" is a non-reference fast mode.  The coefficients ``C`` are
+    NOT a parity quantity (the reference's own solver only fixes them up to the numerical null space of the Gram
+    system) - the field ``V`` / ``grid_V``, ``sigma2`` and ``P`` are.
+    Returns the reference's dict with host NumPy float64 arrays.
     """
     if div_cur_free_kernels:
         raise NotImplementedError("div_cur_free_kernels=True is out of scope (SURVEY.md Appendix A)")
@@ -498,7 +574,8 @@ def SparseVFC(
     lo, hi = shard_bounds(N, rank, world)
     eng = SparseVFCEngine(Xv[lo:hi], Yv[lo:hi], ctrl_pts, beta, dtype=dtype, device=device, distributed=distributed,
                           group=group, n_total=N, kernels=_kernels)
-    tecr_vec, E_vec = eng.fit(a=a, gamma=gamma, lambda_=lambda_, minP=minP, MaxIter=MaxIter, theta=theta, ecr=ecr)
+    tecr_vec, E_vec = eng.fit(a=a, gamma=gamma, lambda_=lambda_, minP=minP, MaxIter=MaxIter, theta=theta, ecr=ecr,
+                              lstsq_method=lstsq_method)
     V, P, C = eng.results()
     grid_V = eng.predict(Grid) if Grid is not None else None
     i = eng.iteration

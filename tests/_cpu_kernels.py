@@ -89,15 +89,33 @@ class CpuKernels:
             G.copy_(torch.from_numpy(UP @ U))
         R.copy_(torch.from_numpy(UP @ _np(y4)[:, :3]))
 
-    def solve(self, G, K, lambda_sigma2, jitter, R, C_out, info):
+    def solve(self, G, K, lambda_sigma2, jitter, R, C_out, info, pivots=None):
         A = _np(G) + lambda_sigma2 * _np(K)
         A = A + jitter * np.trace(A) / len(A) * np.eye(len(A))
         try:
-            c = scipy.linalg.cho_solve(scipy.linalg.cho_factor(A, lower=True), _np(R))
+            L = np.linalg.cholesky(A)
+            c = scipy.linalg.cho_solve((L, True), _np(R))
             info.zero_()
             C_out.copy_(torch.from_numpy(c))
+            if pivots is not None:
+                d = np.diag(L) ** 2
+                pivots.copy_(torch.tensor([d.min(), d.max()], dtype=torch.float64))
         except np.linalg.LinAlgError:
             info.fill_(1)
+
+    def solve_minnorm(self, G, K, lambda_sigma2, shift, R, C_out, info, einfo, rcond=None, reuse=False, max_sweeps=60):
+        """Truncated minimum-norm solve through a symmetric eigendecomposition (what the device eigensolver computes)."""
+        rc = np.finfo(float).eps if rcond is None else rcond
+        if not reuse:
+            A = _np(G) + lambda_sigma2 * _np(K)
+            self._eig = np.linalg.eigh((A + A.T) / 2)
+        w, q = self._eig
+        keep = np.abs(w) > rc * np.abs(w).max()
+        c = (q[:, keep] / w[keep]) @ (q[:, keep].T @ _np(R))
+        C_out.copy_(torch.from_numpy(c))
+        info.zero_()
+        einfo[:6] = torch.tensor([1.0, keep.sum(), np.abs(w).max(), np.abs(w[keep]).min(), shift * np.trace(_np(G)) / len(w),
+                                  w.min()], dtype=torch.float64)
 
     def quadform(self, K, C, out):
         c = _np(C)

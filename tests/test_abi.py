@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libmvf.so does not export {name}"
     assert sorted(_lib.SIGNATURES) == declared, "ctypes table and include/mvf.h disagree"
-    assert lib.mvf_version() == 1
+    assert lib.mvf_version() == 2
 
 
 def test_constants_match_header():
@@ -62,8 +62,12 @@ def test_error_channel_without_launching_anything():
     rc = lib.mvf_con_k(None, 4, None, 4, 3, 0.1, None, _lib.MVF_F32, None)
     assert rc != 0 and b"null pointer" in lib.mvf_last_error()
     info = ctypes.c_int(0)
-    rc = lib.mvf_solve(None, None, 0.0, 0.0, None, -1, 3, None, ctypes.byref(info), None, 0, None)
+    rc = lib.mvf_solve(None, None, 0.0, 0.0, None, -1, 3, None, ctypes.byref(info), None, None, 0, None)
     assert rc != 0 and b"mvf_solve" in lib.mvf_last_error()
+    rc = lib.mvf_solve_minnorm(None, None, 0.0, 1e-11, 2.2e-16, None, 5, 9, None, ctypes.byref(info), None, 0, 0, None, 0,
+                               None)
+    assert rc != 0 and b"mvf_solve_minnorm" in lib.mvf_last_error()
+    assert lib.mvf_solve_minnorm_workspace_bytes(3000, 3) >= 2 * 3008 * 3008 * 8
     with pytest.raises(_lib.MVFError, match="mvf_set_gram_mode"):
         _lib.check(lib.mvf_set_gram_mode(7), "mvf_set_gram_mode")
     # empty problems are fine and launch nothing

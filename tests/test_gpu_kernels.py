@@ -246,6 +246,161 @@ def test_solve_spd_vs_numpy(st, m, nrhs):
     assert _relmax(C.cpu().numpy(), Cr) < 1e-9
 
 
+def test_solve_pivot_range(st):
+    """pivots = [min L_jj^2, max L_jj^2] of the un-regularised Cholesky: the host's numerical-rank certificate."""
+    m = 200
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((m, 3 * m))
+    G = A @ A.T / m
+    k = _k("float64")
+    dev = "cuda:0"
+    C = torch.empty(m, 3, dtype=torch.float64, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    piv = torch.zeros(2, dtype=torch.float64, device=dev)
+    k.solve(torch.from_numpy(G).to(dev), torch.zeros(m, m, dtype=torch.float64, device=dev), 0.0, 0.0,
+            torch.ones(m, 3, dtype=torch.float64, device=dev), C, info, piv)
+    d = np.diag(np.linalg.cholesky(G)) ** 2
+    np.testing.assert_allclose(piv.cpu().numpy(), [d.min(), d.max()], rtol=1e-10)
+
+
+def _minnorm_ref(A, R, rcond=np.finfo(float).eps):
+    w, q = np.linalg.eigh((A + A.T) / 2)
+    keep = np.abs(w) > rcond * np.abs(w).max()
+    return (q[:, keep] / w[keep]) @ (q[:, keep].T @ R), w, keep
+
+
+def _run_minnorm(k, G, K, ls2, R, shift=2.0 ** -36, reuse_R=None, rcond=None):
+    dev = "cuda:0"
+    m, nrhs = R.shape
+    Gd, Kd, Rd = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (G, K, R))
+    C = torch.empty(m, nrhs, dtype=torch.float64, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    einfo = torch.zeros(12, dtype=torch.float64, device=dev)
+    k.solve_minnorm(Gd, Kd, ls2, shift, Rd, C, info, einfo, rcond=rcond)
+    out = [C.cpu().numpy(), int(info.cpu()[0]), einfo.cpu().numpy()]
+    if reuse_R is not None:
+        R2 = torch.from_numpy(np.ascontiguousarray(reuse_R)).to(dev)
+        C2 = torch.empty_like(R2)
+        k.solve_minnorm(Gd, Kd, ls2, shift, R2, C2, info, einfo, reuse=True)
+        out.append(C2.cpu().numpy())
+    return out
+
+
+@pytest.mark.parametrize("m,nrhs", [(2, 1), (33, 3), (64, 3), (100, 6), (300, 2), (517, 8)])
+def test_solve_minnorm_full_rank_equals_the_inverse(st, m, nrhs):
+    """Well conditioned SPD system: nothing is truncated, the minimum-norm solve is the ordinary solve; the reported
+    extreme eigenvalues are LAPACK's."""
+    rng = np.random.default_rng(m)
+    A = rng.standard_normal((m, 2 * m))
+    G = A @ A.T / (2 * m)
+    Kc = rng.standard_normal((m, m))
+    K = Kc @ Kc.T / m
+    R = rng.standard_normal((m, nrhs))
+    ls2 = 0.37
+    C, info, e, C2 = _run_minnorm(_k("float64"), G, K, ls2, R, reuse_R=R[:, :1] * 2.0)
+    assert info == 0 and e[0] == np.floor(e[0]) and e[0] < 40, e  # converged (x.5 would mean the sweep cap was hit)
+    w = np.linalg.eigvalsh(G + ls2 * K)
+    assert int(e[1]) == m
+    np.testing.assert_allclose([e[2], e[3]], [w.max(), w.min()], rtol=1e-10)
+    assert _relmax(C, np.linalg.solve(G + ls2 * K, R)) < 1e-9
+    assert _relmax(C2, 2.0 * C[:, :1]) < 1e-12  # reuse applies the same decomposition to another right-hand side
+
+
+@pytest.mark.parametrize("m,rank", [(96, 40), (200, 1), (257, 130)])
+def test_solve_minnorm_exactly_rank_deficient(st, m, rank):
+    """A = B B^T with B m x rank: with a cut-off above the rounding level of the null-space eigenvalues (rcond = 1e-12;
+    at the default eps some of them land above it, for LAPACK just the same) the result is pinv(A) R."""
+    rng = np.random.default_rng(rank)
+    B = rng.standard_normal((m, rank))
+    G = B @ B.T
+    R = G @ rng.standard_normal((m, 3))  # consistent right-hand sides, as U^T P Y is for U^T P U
+    C, info, e = _run_minnorm(_k("float64"), G, np.zeros((m, m)), 0.0, R, rcond=1e-12)
+    assert info == 0 and int(e[1]) == rank
+    Cr = np.linalg.pinv(G, rcond=1e-13, hermitian=True) @ R
+    assert _relmax(C, Cr) < 1e-8
+    assert _relmax(G @ C, R) < 1e-10
+
+
+def _kernel_system(n, m, seed=0, lambda_=0.02, s2=1e-3):
+    """A numerically rank-deficient SparseVFC system: Gaussian-kernel Gram of n cells on m control points."""
+    from spateo_amd._synthetic import make_config
+
+    X, Y, _ = make_config("C2", N=n)
+    valid, Xv, Yv, idx, ctrl, beta = svo.sparsevfc_setup(X, Y, M=m, seed=seed)
+    K = svo.con_K(ctrl, ctrl, beta)
+    U = svo.con_K(Xv, ctrl, beta)
+    P = np.clip(np.random.default_rng(seed).random(len(Xv)), 1e-5, 1.0)
+    UP = U.T * P[None, :]
+    return U, UP @ U, K, UP @ Yv, lambda_ * s2
+
+
+@pytest.mark.parametrize("n,m", [(4000, 300), (6000, 1000)])
+def test_solve_minnorm_kernel_gram_vs_scipy_lstsq(st, n, m):
+    """The regime Spateo's default lambda_ puts the solve in: U^T P U + lambda sigma^2 K numerically rank deficient.
+    Parity quantity = the FIELD U C (C lives in the numerical null space).  The reference noise floor is the deviation
+    between scipy.linalg.lstsq (gelsd) and the mathematically identical truncated eigh solve, both on the CPU."""
+    import scipy.linalg
+
+    U, G, K, R, ls2 = _kernel_system(n, m)
+    A = G + ls2 * K
+    C_ls = scipy.linalg.lstsq(A, R)[0]
+    C_eh, w, keep = _minnorm_ref(A, R)
+    F = U @ C_ls
+    sc = np.abs(F).max()
+    floor = np.abs(U @ C_eh - F).max() / sc
+    C, info, e = _run_minnorm(_k("float64"), G, K, ls2, R)
+    dev = np.abs(U @ C - F).max() / sc
+    print(f"m={m}: cond {w.max() / np.abs(w).min():.1e} kept {keep.sum()} gpu kept {int(e[1])} sweeps {e[0]} "
+          f"floor(lstsq vs eigh) {floor:.2e}  gpu vs lstsq {dev:.2e}")
+    assert info == 0
+    assert dev < max(2.0 * floor, 1e-9)
+    assert abs(int(e[1]) - int(keep.sum())) <= max(2, m // 50)  # eigenvalues at the cut-off may fall either side
+    np.testing.assert_allclose(e[2], w.max(), rtol=1e-9)
+
+
+@pytest.mark.parametrize("m", [2000, 3000])
+def test_solve_large_rank_deficient_vs_scipy_lstsq(st, m):
+    """the coefficient solve at the headline size against scipy.linalg.lstsq on a genuinely
+    rank-deficient U^T P U + lambda sigma^2 K, asserting on the field U C; the jitter-Cholesky mode is measured
+    beside it (deviation as a function of the jitter it needed)."""
+    import time
+
+    import scipy.linalg
+
+    U, G, K, R, ls2 = _kernel_system(12000, m)
+    A = G + ls2 * K
+    C_ls = scipy.linalg.lstsq(A, R)[0]
+    C_eh, w, keep = _minnorm_ref(A, R)
+    F = U @ C_ls
+    sc = np.abs(F).max()
+    floor = np.abs(U @ C_eh - F).max() / sc
+    k = _k("float64")
+    _run_minnorm(k, G, K, ls2, R)  # warm-up (workspace allocation)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    C, info, e = _run_minnorm(k, G, K, ls2, R)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0)
+    dev = np.abs(U @ C - F).max() / sc
+    # jitter-escalated Cholesky (lstsq_method="cholesky") on the same system
+    d = "cuda:0"
+    Gd, Kd, Rd = (torch.from_numpy(a).to(d) for a in (G, K, R))
+    Cc = torch.empty(m, 3, dtype=torch.float64, device=d)
+    inf = torch.zeros(1, dtype=torch.int32, device=d)
+    jit, devs = 0.0, []
+    while True:
+        k.solve(Gd, Kd, ls2, jit, Rd, Cc, inf)
+        if int(inf.cpu()[0]) == 0:
+            devs.append((jit, np.abs(U @ Cc.cpu().numpy() - F).max() / sc))
+            if len(devs) == 3:
+                break
+        jit = max(jit * 10, 1e-15)
+    print(f"m={m}: kept {keep.sum()}/{m} (gpu {int(e[1])}), sweeps {e[0]}, {ms:.1f} ms incl. H2D; floor {floor:.2e}; "
+          f"min-norm vs lstsq {dev:.2e}; jitter-Cholesky vs lstsq: " + ", ".join(f"{j:g}: {v:.2e}" for j, v in devs))
+    assert info == 0 and e[0] == np.floor(e[0])
+    assert dev < max(2.0 * floor, 1e-9)
+
+
 def test_solve_reports_non_psd(st):
     m = 96
     G = -np.eye(m)

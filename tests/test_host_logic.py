@@ -105,7 +105,9 @@ def test_em_driver_stops_like_the_reference(cpu_kernels):
         assert got["grid_V"] is None and got["grid"] is None
 
 
-def test_jitter_escalates_only_on_failed_pivots(cpu_kernels):
+def test_solve_policy_cholesky_while_certified_then_minimum_norm(cpu_kernels):
+    """lstsq_method="scipy": un-regularised Cholesky while the pivots certify full numerical rank, the truncated
+    minimum-norm solve once they do not (sticky within a fit); the eigensolver's shift escalates only on failure."""
     from spateo_amd.vectorfield import SparseVFCEngine
 
     X, V = _data(400)
@@ -113,19 +115,91 @@ def test_jitter_escalates_only_on_failed_pivots(cpu_kernels):
     eng = SparseVFCEngine(Xv, Yv, ctrl, beta, kernels=cpu_kernels)
     eng.init_state()
     eng.em_step(lambda_=3.0)
-    assert eng.jitter == 0.0 and eng.solve_retries == 0  # well conditioned: solved without regularisation
+    assert eng.solver_stats["cholesky"] == 1 and eng.solver_stats["minnorm"] == 0 and not eng.rank_deficient
+
+    class TinyPivot(CpuKernels):
+        chol = mn = 0
+
+        def solve(self, G, K, ls2, jitter, R, C_out, info, pivots=None):
+            TinyPivot.chol += 1
+            super().solve(G, K, ls2, jitter, R, C_out, info, pivots)
+            if pivots is not None:
+                pivots[0] = 1e-14 * pivots[1]  # a pivot at rounding level: full rank is NOT certified
+
+        def solve_minnorm(self, *a, **kw):
+            TinyPivot.mn += 1
+            super().solve_minnorm(*a, **kw)
+
+    eng2 = SparseVFCEngine(Xv, Yv, ctrl, beta, kernels=TinyPivot())
+    eng2.init_state()
+    eng2.em_step(lambda_=3.0)
+    assert eng2.rank_deficient and (TinyPivot.chol, TinyPivot.mn) == (1, 1)
+    eng2.em_step(lambda_=3.0)
+    assert (TinyPivot.chol, TinyPivot.mn) == (1, 2)  # sticky: no more Cholesky attempts in this fit
+    assert eng2.solver_stats["minnorm"] == 2 and eng2.solver_stats["rank"] == [30, 30]
+    # well conditioned system: both paths give the same field
+    np.testing.assert_allclose(eng2.results()[0], _two_steps(Xv, Yv, ctrl, beta, cpu_kernels), rtol=1e-9, atol=1e-12)
+
+    class ShiftTooSmall(CpuKernels):
+        shifts = []
+
+        def solve(self, G, K, ls2, jitter, R, C_out, info, pivots=None):
+            info.fill_(3)  # non-positive pivot without regularisation
+
+        def solve_minnorm(self, G, K, ls2, shift, R, C_out, info, einfo, **kw):
+            ShiftTooSmall.shifts.append(shift)
+            if len(ShiftTooSmall.shifts) <= 2:
+                info.fill_(7)
+                return
+            super().solve_minnorm(G, K, ls2, shift, R, C_out, info, einfo, **kw)
+
+    eng3 = SparseVFCEngine(Xv, Yv, ctrl, beta, kernels=ShiftTooSmall())
+    eng3.init_state()
+    eng3.em_step(lambda_=3.0)
+    assert ShiftTooSmall.shifts == [2.0 ** -36, 2.0 ** -32, 2.0 ** -28] and eng3.mn_shift == 2.0 ** -28
+
+    class AlwaysFail(CpuKernels):
+        def solve(self, G, K, ls2, jitter, R, C_out, info, pivots=None):
+            info.fill_(1)
+
+        def solve_minnorm(self, G, K, ls2, shift, R, C_out, info, einfo, **kw):
+            info.fill_(1)
+
+    eng4 = SparseVFCEngine(Xv, Yv, ctrl, beta, kernels=AlwaysFail())
+    eng4.init_state()
+    with pytest.raises(RuntimeError, match="not numerically positive semi-definite"):
+        eng4.em_step(lambda_=3.0)
+
+
+def _two_steps(Xv, Yv, ctrl, beta, kernels):
+    from spateo_amd.vectorfield import SparseVFCEngine
+
+    e = SparseVFCEngine(Xv, Yv, ctrl, beta, kernels=kernels)
+    e.init_state()
+    e.em_step(lambda_=3.0)
+    e.em_step(lambda_=3.0)
+    return e.results()[0]
+
+
+def test_cholesky_mode_jitter_escalates_only_on_failed_pivots(cpu_kernels):
+    """lstsq_method="cholesky" (non-reference fast mode): jitter 0 -> 1e-15 -> x10 ..., sticky."""
+    from spateo_amd.vectorfield import SparseVFCEngine
+
+    X, V = _data(400)
+    valid, Xv, Yv, idx, ctrl, beta = vfm.sparsevfc_preprocess(X, V, M=30, seed=0)
 
     class FailTwice(CpuKernels):
         calls = 0
 
-        def solve(self, G, K, ls2, jitter, R, C_out, info):
+        def solve(self, G, K, ls2, jitter, R, C_out, info, pivots=None):
             FailTwice.calls += 1
             if FailTwice.calls <= 2:
                 info.fill_(5)
                 return
-            super().solve(G, K, ls2, jitter, R, C_out, info)
+            super().solve(G, K, ls2, jitter, R, C_out, info, pivots)
 
     eng2 = SparseVFCEngine(Xv, Yv, ctrl, beta, kernels=FailTwice())
+    eng2.lstsq_method = "cholesky"
     eng2.init_state()
     eng2.em_step(lambda_=3.0)
     assert eng2.solve_retries == 2 and eng2.jitter == pytest.approx(1e-14)  # 0 -> 1e-15 -> 1e-14, then sticky
@@ -133,13 +207,26 @@ def test_jitter_escalates_only_on_failed_pivots(cpu_kernels):
     assert eng2.jitter == pytest.approx(1e-14)
 
     class AlwaysFail(CpuKernels):
-        def solve(self, G, K, ls2, jitter, R, C_out, info):
+        def solve(self, G, K, ls2, jitter, R, C_out, info, pivots=None):
             info.fill_(1)
 
     eng3 = SparseVFCEngine(Xv, Yv, ctrl, beta, kernels=AlwaysFail())
+    eng3.lstsq_method = "cholesky"
     eng3.init_state()
     with pytest.raises(RuntimeError, match="non-positive pivot"):
         eng3.em_step(lambda_=3.0)
+
+
+def test_lstsq_method_is_honoured_or_warned(cpu_kernels):
+    X, V = _data(300)
+    kw = dict(M=20, MaxIter=3, lambda_=3.0, _kernels=cpu_kernels)
+    a = vfm.SparseVFC(X, V, None, lstsq_method="scipy", **kw)
+    vfm._LSTSQ_WARNED.clear()
+    with pytest.warns(RuntimeWarning, match="normal-equations arithmetic of 'drouin' is not reproduced"):
+        b = vfm.SparseVFC(X, V, None, lstsq_method="drouin", **kw)
+    np.testing.assert_array_equal(a["V"], b["V"])
+    c = vfm.SparseVFC(X, V, None, lstsq_method="cholesky", **kw)
+    np.testing.assert_allclose(a["V"], c["V"], rtol=1e-9, atol=1e-12)
 
 
 def test_engine_rejects_unsupported_shapes(cpu_kernels):
