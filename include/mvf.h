@@ -145,14 +145,19 @@ int mvf_gram_cached(int stages, const void* ublk, const void* x4, const void* P,
  *   (x.5 if max_sweeps was hit first), [1] = kept rank, [2] = max|lambda|, [3] = min kept |lambda|, [4] = delta,
  *   [5] = min lambda.  NOT asynchronous: it synchronises `stream` once per sweep to read the rotation counter.
  *   reuse != 0: the decomposition of the previous call on this workspace (same matrix) is applied to another R (a
- *   wide Y is solved in groups of <= 8 columns); asynchronous, einfo must hold 12 float64 ([6..11] = this call's). */
+ *   wide Y is solved in groups of <= 8 columns); asynchronous, einfo must hold 12 float64 ([6..11] = this call's).
+ *   basis (may be NULL; mvf_solve_minnorm_basis_bytes, caller-owned): on exit the orthonormal eigenvectors (row i =
+ *   eigenvector i).  warm != 0: on entry it holds the eigenvectors of a NEARBY matrix (the previous EM iteration's):
+ *   the matrix is first transformed to that basis (f64 MFMA GEMMs), where it is nearly diagonal, so the Jacobi
+ *   sweeps start in their quadratic phase - same result, several times fewer sweeps. */
 size_t mvf_solve_workspace_bytes(int64_t m, int nrhs);
 int mvf_solve(const double* G, const double* K, double lambda_sigma2, double jitter, const double* R, int64_t m,
               int nrhs, double* C, int* info, double* pivots, void* workspace, size_t workspace_bytes, void* stream);
 size_t mvf_solve_minnorm_workspace_bytes(int64_t m, int nrhs);
 int mvf_solve_minnorm(const double* G, const double* K, double lambda_sigma2, double shift, double rcond,
                       const double* R, int64_t m, int nrhs, double* C, int* info, double* einfo, int max_sweeps,
-                      int reuse, void* workspace, size_t workspace_bytes, void* stream);
+                      int reuse, double* basis, int warm, void* workspace, size_t workspace_bytes, void* stream);
+size_t mvf_solve_minnorm_basis_bytes(int64_t m);
 
 /* trace(C^T K C) -> out[0] (float64), the regulariser of the energy (App. A 5b). K: m x m, C: m x nrhs. */
 int mvf_quadform(const double* K, const double* C, int64_t m, int nrhs, double* out, void* stream);

@@ -420,10 +420,109 @@ __global__ __launch_bounds__(256) void jac_back_reduce_kernel(const double* __re
     C[e] = s;
 }
 
+// ---- warm start: the eigenvector basis of the previous EM iteration's matrix pre-diagonalises this one's ---------
+// A changes little between EM iterations (only P and sigma^2 move), so A' = Wt A Wt^T with the previous eigenvectors
+// (rows of Wt) is nearly diagonal and the Jacobi sweeps on chol(A' + delta I) start in their quadratic phase.
+
+// Afull (mp x mp) = G + ls2 K on the leading m x m, zero on the padding
+__global__ __launch_bounds__(256) void assemble_kernel(const double* __restrict__ G, const double* __restrict__ K,
+                                                       double ls2, int64_t m, int64_t mp, double* __restrict__ A) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j >= mp) return;
+    A[i * mp + j] = (i < m && j < m) ? G[i * m + j] + ls2 * K[i * m + j] : 0.0;
+}
+
+// C = A op(B), all n x n row-major (n a multiple of 64), f64 MFMA, 64 x 64 output tile per workgroup, K in stages of 32
+// through LDS.  TB = false: C = A B (B staged k-major);  TB = true: C = A B^T (B staged row-major like A).
+constexpr int GK = 32;
+constexpr int GLR = GK + 2;   // row-major stage stride: [64 rows][32 k]
+constexpr int GLK = JP + 16;  // k-major stage stride:   [32 k][64 cols]
+template <bool TB>
+__global__ __launch_bounds__(256) void gemm64_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                     double* __restrict__ C, int64_t n) {
+    __shared__ double sa[64 * GLR];
+    __shared__ double sb[TB ? 64 * GLR : GK * GLK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    const int li = lane & 15, lk = lane >> 4;
+    const int64_t i0 = (int64_t)blockIdx.y * 64, j0 = (int64_t)blockIdx.x * 64;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+    // loaders: row-major stage = 64 rows x 32 k: thread -> row tid >> 2, 8 consecutive k;  k-major stage = 32 k x 64
+    // columns: thread -> k row tid >> 3, 8 consecutive columns
+    const int rr = tid >> 2, rc = (tid & 3) * 8;
+    const int kr = tid >> 3, kc = (tid & 7) * 8;
+    double va[8], vb[8];
+    for (int64_t k0 = 0; k0 < n; k0 += GK) {
+        const double* ap = A + (i0 + rr) * n + k0 + rc;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) va[q] = ap[q];
+        if (TB) {
+            const double* bp = B + (j0 + rr) * n + k0 + rc;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) vb[q] = bp[q];
+        } else {
+            const double* bp = B + (k0 + kr) * n + j0 + kc;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) vb[q] = bp[q];
+        }
+        __syncthreads();  // the previous stage has been consumed
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sa[rr * GLR + rc + q] = va[q];
+        if (TB) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sb[rr * GLR + rc + q] = vb[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sb[kr * GLK + kc + q] = vb[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 4) {
+            double fa[2], fb[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                fa[a] = sa[(wr + a * 16 + li) * GLR + kk + lk];  // A[i][k]
+                fb[a] = TB ? sb[(wc + a * 16 + li) * GLR + kk + lk]   // B^T: B[j][k]
+                           : sb[(kk + lk) * GLK + wc + a * 16 + li];  // B[k][j]
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr + a * 16 + lk + 4 * r;
+                const int col = wc + b * 16 + li;
+                C[(i0 + row) * n + j0 + col] = acc[a][b][r];
+            }
+}
+
+// Wt[i][:] = Y[i][:] / sigma_i  (row i = eigenvector i);  the zero rows of the padding become unit vectors
+__global__ __launch_bounds__(256) void basis_extract_kernel(const double* __restrict__ Y, const double* __restrict__ sig2,
+                                                            int64_t mp, double* __restrict__ Wt) {
+    const int64_t i = blockIdx.y;
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= mp) return;
+    const double s2 = sig2[i];
+    Wt[i * mp + n] = s2 > 0.0 ? Y[i * mp + n] * (1.0 / sqrt(s2)) : (n == i ? 1.0 : 0.0);
+}
+
 struct JacPlan {
     int64_t mp;
     int nb, npairs, nsplit, kchunks, bsplit, rows_per_split;
-    size_t off_y, off_spart, off_j, off_flags, off_sig2, off_t, off_part, off_rot, total;
+    size_t off_y, off_aux, off_spart, off_j, off_flags, off_sig2, off_t, off_part, off_rot, total;
 };
 
 static JacPlan jac_plan(int64_t m, int nrhs) {
@@ -440,6 +539,8 @@ static JacPlan jac_plan(int64_t m, int nrhs) {
     p.rows_per_split = (int)cdiv(p.mp, p.bsplit);
     size_t o = align_up(chol_workspace_bytes(m, 1), 256);
     p.off_y = o;
+    o += align_up((size_t)p.mp * p.mp * sizeof(double), 256);
+    p.off_aux = o;  // warm start: assembled matrix / transformed matrix / back-transformed factor
     o += align_up((size_t)p.mp * p.mp * sizeof(double), 256);
     p.off_spart = o;
     o += align_up((size_t)p.npairs * p.nsplit * JP * JP * sizeof(double), 256);
@@ -468,9 +569,16 @@ extern "C" size_t mvf_solve_minnorm_workspace_bytes(int64_t m, int nrhs) {
     return jac_plan(m, nrhs).total;
 }
 
+extern "C" size_t mvf_solve_minnorm_basis_bytes(int64_t m) {
+    if (m <= 0) return 0;
+    const int64_t mp = cdiv(m, 64) * 64;
+    return (size_t)mp * mp * sizeof(double);
+}
+
 extern "C" int mvf_solve_minnorm(const double* G, const double* K, double lambda_sigma2, double shift, double rcond,
                                  const double* R, int64_t m, int nrhs, double* C, int* info, double* einfo,
-                                 int max_sweeps, int reuse, void* workspace, size_t workspace_bytes, void* stream) {
+                                 int max_sweeps, int reuse, double* basis, int warm, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
     MVF_REQUIRE(m >= 0 && nrhs >= 1 && nrhs <= 8, "mvf_solve_minnorm: need m >= 0 and 1 <= nrhs <= 8 (got m=%lld nrhs=%d)",
                 (long long)m, nrhs);
     MVF_REQUIRE(info && einfo, "mvf_solve_minnorm: null info / einfo");
@@ -511,9 +619,21 @@ extern "C" int mvf_solve_minnorm(const double* G, const double* K, double lambda
         MVF_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
         return 0;
     }
-    // 1. A + delta I = L L^T (no right-hand sides ride along)
+    // 1. A + delta I = L L^T (no right-hand sides ride along); warm: of A' = Wt A Wt^T
     CholPlan cp;
-    if (int rc = chol_factor(st, G, K, lambda_sigma2, shift, nullptr, m, 0, workspace, &cp, info)) return rc;
+    double* aux = (double*)(ws + p.off_aux);
+    MVF_REQUIRE(!warm || basis, "mvf_solve_minnorm: warm start without a basis");
+    const dim3 ggrid((unsigned)(mp / 64), (unsigned)(mp / 64));
+    if (warm) {
+        hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)cdiv(mp, 256), (unsigned)mp), dim3(256), 0, st, G, K,
+                           lambda_sigma2, m, mp, aux);
+        hipLaunchKernelGGL(gemm64_kernel<true>, ggrid, dim3(256), 0, st, aux, basis, Y, mp);   // T1 = A Wt^T
+        hipLaunchKernelGGL(gemm64_kernel<false>, ggrid, dim3(256), 0, st, basis, Y, aux, mp);  // A' = Wt T1
+        MVF_LAUNCH_CHECK();
+        if (int rc = chol_factor_mat(st, aux, mp, shift, m, workspace, &cp, info)) return rc;
+    } else if (int rc = chol_factor(st, G, K, lambda_sigma2, shift, nullptr, m, 0, workspace, &cp, info)) {
+        return rc;
+    }
     int hinfo = 0;
     MVF_CHECK_HIP(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, st));
     MVF_CHECK_HIP(hipStreamSynchronize(st));
@@ -547,6 +667,13 @@ extern "C" int mvf_solve_minnorm(const double* G, const double* K, double lambda
         if (hrot == 0) break;
     }
 
+    if (warm) {
+        // back to the original coordinates: row i of Y (= sigma_i x eigenvector i of A') -> Y Wt
+        hipLaunchKernelGGL(gemm64_kernel<false>, ggrid, dim3(256), 0, st, Y, basis, aux, mp);
+        MVF_LAUNCH_CHECK();
+        MVF_CHECK_HIP(hipMemcpyAsync(Y, aux, (size_t)mp * mp * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+
     // 3. truncated minimum-norm solve
     hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(mp, 4)), dim3(256), 0, st, Y, mp, m, R, nrhs, sig2, T);
     hipLaunchKernelGGL(jac_scale_kernel, dim3(1), dim3(256), 0, st, sig2, mp, cp.scal, rcond, T, einfo);
@@ -554,6 +681,9 @@ extern "C" int mvf_solve_minnorm(const double* G, const double* K, double lambda
                        p.rows_per_split, part);
     hipLaunchKernelGGL(jac_back_reduce_kernel, dim3((unsigned)cdiv(m * nrhs, 256)), dim3(256), 0, st, part, p.bsplit, m,
                        nrhs, C);
+    if (basis)
+        hipLaunchKernelGGL(basis_extract_kernel, dim3((unsigned)cdiv(mp, 256), (unsigned)mp), dim3(256), 0, st, Y, sig2,
+                           mp, basis);
     MVF_LAUNCH_CHECK();
     const double hs[1] = {(double)sweeps + (hrot != 0 ? 0.5 : 0.0)};  // x.5 = sweep cap hit before convergence
     MVF_CHECK_HIP(hipMemcpyAsync(einfo, hs, sizeof(double), hipMemcpyHostToDevice, st));

@@ -16,5 +16,7 @@ size_t chol_workspace_bytes(int64_t m, int nrhs);
 void chol_layout(int64_t m, int nrhs, void* workspace, CholPlan* pl);
 int chol_factor(hipStream_t st, const double* G, const double* K, double ls2, double shift, const double* R, int64_t m,
                 int nrhs, void* workspace, CholPlan* pl, int* info);
+int chol_factor_mat(hipStream_t st, const double* A, int64_t ld, double shift, int64_t m, void* workspace, CholPlan* pl,
+                    int* info);
 
 }  // namespace mvf

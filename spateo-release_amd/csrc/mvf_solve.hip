@@ -383,19 +383,11 @@ void chol_layout(int64_t m, int nrhs, void* workspace, CholPlan* pl) {
     pl->scal = (double*)((char*)pl->rdiag + align_up((size_t)mp * sizeof(double), 256));
 }
 
-int chol_factor(hipStream_t st, const double* G, const double* K, double ls2, double shift, const double* R, int64_t m,
-                int nrhs, void* workspace, CholPlan* pl, int* info) {
-    chol_layout(m, nrhs, workspace, pl);
+// the factorisation proper: W (prepared by one of the chol_prepare kernels) -> L in its lower triangle
+static int chol_run(hipStream_t st, CholPlan* pl, int* info) {
     const int64_t mp = pl->mp, mr = pl->mr;
     const int nb = pl->nb, nbr = pl->nbr;
     double* W = pl->W;
-    MVF_REQUIRE(mr <= 65535, "coefficient solve: m too large (%lld)", (long long)m);
-    MVF_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
-    hipLaunchKernelGGL(diag_mean_kernel, dim3(1), dim3(256), 0, st, G, K, ls2, shift, m, pl->scal);
-    MVF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(chol_prepare_kernel, dim3((unsigned)cdiv(mp, 256), (unsigned)mr), dim3(256), 0, st, G, K, ls2,
-                       pl->scal, R, m, nrhs, mp, mr, W);
-    MVF_LAUNCH_CHECK();
     for (int k = 0; k < nb; ++k) {
         hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, W, mp, k, pl->rdiag, info);
         const int64_t rows_below = mr - (int64_t)(k + 1) * NB;
@@ -409,6 +401,65 @@ int chol_factor(hipStream_t st, const double* G, const double* K, double ls2, do
     }
     MVF_LAUNCH_CHECK();
     return 0;
+}
+
+int chol_factor(hipStream_t st, const double* G, const double* K, double ls2, double shift, const double* R, int64_t m,
+                int nrhs, void* workspace, CholPlan* pl, int* info) {
+    chol_layout(m, nrhs, workspace, pl);
+    const int64_t mp = pl->mp, mr = pl->mr;
+    MVF_REQUIRE(mr <= 65535, "coefficient solve: m too large (%lld)", (long long)m);
+    MVF_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+    hipLaunchKernelGGL(diag_mean_kernel, dim3(1), dim3(256), 0, st, G, K, ls2, shift, m, pl->scal);
+    MVF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chol_prepare_kernel, dim3((unsigned)cdiv(mp, 256), (unsigned)mr), dim3(256), 0, st, G, K, ls2,
+                       pl->scal, R, m, nrhs, mp, mr, pl->W);
+    MVF_LAUNCH_CHECK();
+    return chol_run(st, pl, info);
+}
+
+// same for a matrix that is already assembled: A (leading m x m of a row-major array with leading dimension ld)
+__global__ __launch_bounds__(256) void mat_diag_mean_kernel(const double* __restrict__ A, int64_t ld, double shift,
+                                                            int64_t m, double* __restrict__ scal) {
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < m; i += 256) s += A[i * ld + i];
+    __shared__ double red[4];
+    const double t = block_sum<256>(s, red);
+    if (threadIdx.x == 0) {
+        const double mean = t / (double)m;
+        scal[0] = mean;
+        scal[1] = shift * mean;
+    }
+}
+
+__global__ __launch_bounds__(256) void chol_prepare_mat_kernel(const double* __restrict__ A, int64_t ld,
+                                                               const double* __restrict__ scal, int64_t m, int64_t mp,
+                                                               double* __restrict__ W) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j >= mp) return;
+    double v = 0.0;
+    if (i < mp) {
+        if (i < m && j < m) {
+            v = A[i * ld + j];
+            if (i == j) v += scal[1];
+        } else if (i == j) {
+            v = 1.0;
+        }
+    }
+    W[i * mp + j] = v;
+}
+
+int chol_factor_mat(hipStream_t st, const double* A, int64_t ld, double shift, int64_t m, void* workspace, CholPlan* pl,
+                    int* info) {
+    chol_layout(m, 0, workspace, pl);
+    const int64_t mp = pl->mp, mr = pl->mr;
+    MVF_REQUIRE(mr <= 65535, "coefficient solve: m too large (%lld)", (long long)m);
+    MVF_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+    hipLaunchKernelGGL(mat_diag_mean_kernel, dim3(1), dim3(256), 0, st, A, ld, shift, m, pl->scal);
+    hipLaunchKernelGGL(chol_prepare_mat_kernel, dim3((unsigned)cdiv(mp, 256), (unsigned)mr), dim3(256), 0, st, A, ld,
+                       pl->scal, m, mp, pl->W);
+    MVF_LAUNCH_CHECK();
+    return chol_run(st, pl, info);
 }
 
 }  // namespace mvf

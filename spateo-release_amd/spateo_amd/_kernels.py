@@ -171,10 +171,13 @@ class HipKernels:
                                       _ptr(C_out), _ptr(info), _ptr(pivots), _ptr(self._solve_ws),
                                       self._solve_ws.numel(), self._stream()), "mvf_solve")
 
-    def solve_minnorm(self, G, K, lambda_sigma2, shift, R, C_out, info, einfo, rcond=None, reuse=False, max_sweeps=60):
+    def solve_minnorm(self, G, K, lambda_sigma2, shift, R, C_out, info, einfo, rcond=None, reuse=False, max_sweeps=60,
+                      basis=None, warm=False):
         """Minimum-norm solve with the gelsd cut-off (eigenvalues below rcond * max|lambda| dropped; rcond = float64
         eps = scipy.linalg.lstsq's default).  reuse=True applies the decomposition left in the workspace by the
-        previous call (same matrix) to another right-hand side.  Synchronises the stream (once per Jacobi sweep)."""
+        previous call (same matrix) to another right-hand side.  ``basis`` (float64 tensor from ``minnorm_basis``)
+        receives the eigenvectors; ``warm=True`` starts from the ones it holds (the previous EM iteration's).
+        Synchronises the stream (once per Jacobi sweep)."""
         m, nrhs = R.shape
         need = self.lib.mvf_solve_minnorm_workspace_bytes(m, nrhs)
         if self._mn_ws is None or self._mn_ws.numel() < need:
@@ -185,8 +188,12 @@ class HipKernels:
         rc = float(np.finfo(np.float64).eps) if rcond is None else float(rcond)
         _lib.check(self.lib.mvf_solve_minnorm(_ptr(G), _ptr(K), float(lambda_sigma2), float(shift), rc, _ptr(R), m,
                                               nrhs, _ptr(C_out), _ptr(info), _ptr(einfo), int(max_sweeps),
-                                              1 if reuse else 0, _ptr(self._mn_ws), self._mn_ws.numel(),
-                                              self._stream()), "mvf_solve_minnorm")
+                                              1 if reuse else 0, _ptr(basis), 1 if warm else 0, _ptr(self._mn_ws),
+                                              self._mn_ws.numel(), self._stream()), "mvf_solve_minnorm")
+
+    def minnorm_basis(self, m):
+        """Uninitialised eigenvector-basis buffer for solve_minnorm's warm start (m x m padded to multiples of 64)."""
+        return torch.empty(int(self.lib.mvf_solve_minnorm_basis_bytes(m)) // 8, dtype=torch.float64, device=self.device)
 
     def quadform(self, K, C, out):
         _lib.check(self.lib.mvf_quadform(_ptr(K), _ptr(C), K.shape[0], C.shape[1], _ptr(out), self._stream()),

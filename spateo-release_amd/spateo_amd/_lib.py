@@ -40,7 +40,8 @@ SIGNATURES = {
     "mvf_solve_workspace_bytes": (_sz, [_i64, _i]),
     "mvf_solve": (_i, [_p, _p, _d, _d, _p, _i64, _i, _p, _p, _p, _p, _sz, _p]),
     "mvf_solve_minnorm_workspace_bytes": (_sz, [_i64, _i]),
-    "mvf_solve_minnorm": (_i, [_p, _p, _d, _d, _d, _p, _i64, _i, _p, _p, _p, _i, _i, _p, _sz, _p]),
+    "mvf_solve_minnorm": (_i, [_p, _p, _d, _d, _d, _p, _i64, _i, _p, _p, _p, _i, _i, _p, _i, _p, _sz, _p]),
+    "mvf_solve_minnorm_basis_bytes": (_sz, [_i64]),
     "mvf_quadform": (_i, [_p, _p, _i64, _i, _p, _p]),
     "mvf_eval": (_i, [_p, _i64, _p, _i64, _d, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "mvf_eval_affine": (_i, [_p, _i64, _p, _i64, _d, _p, C.POINTER(C.c_double), _i, _p, _p, _p, _p, _p, _p, _p, _p, _i,

