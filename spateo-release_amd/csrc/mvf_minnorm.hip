@@ -169,7 +169,8 @@ __device__ __forceinline__ void inner_pair(int r, int l, int& p, int& q) {
 
 // One cyclic two-sided Jacobi sweep on the 64 x 64 Gram tile of a block pair, in LDS.  Rotation (p, q) is applied when
 // |s_pq| > tol sqrt(s_pp s_qq) (the one-sided criterion: the two columns are not yet orthogonal relative to their
-// norms).  Thread (l = tid & 31, kq = tid >> 5).  Phase A: EVERY lane computes the rotation of its pair l (redundantly
+// norms).
+// Thread (l = tid & 31, kq = tid >> 5).  Phase A: EVERY lane computes the rotation of its pair l (redundantly
 // in all four waves: its own (c_l, s_l) then sit in registers and any other pair's come from a wave shuffle - no LDS
 // round trip).  Phase B: the 2 x 2 blocks S_kl <- Rot_k^T S_kl Rot_l for k = kq + 8 j and the column pair l of J for
 // rows kq + 8 j.  Blocks partition S, so phase B is in place; two barriers per round (A -> B and B -> next A).

@@ -10,12 +10,14 @@ from spateo_amd.vectorfield import SparseVFCEngine, sparsevfc_preprocess
 
 M = int(sys.argv[1]); N = int(sys.argv[2]) if len(sys.argv) > 2 else 20 * M
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+shift = 2.0 ** -int(sys.argv[4]) if len(sys.argv) > 4 else None
 X, Y, _ = make_config("C2", N=N)
 valid, Xv, Yv, idx, ctrl, beta = sparsevfc_preprocess(X, Y, M=M, seed=0)
 out = {"M": M, "N": N}
 for warm in (True, False):
     eng = SparseVFCEngine(Xv, Yv, ctrl, beta, dtype="float64", device="cuda:0")
     eng.warm_start = warm
+    if shift: eng.mn_shift = shift
     eng.init_state()
     orig = eng._solve_all
     ms = []
