@@ -9,8 +9,10 @@ application, sigma^2 / gamma update - SURVEY.md Appendix A step 5) over the whol
 inputs resident in HBM.  Workload: BASELINE config 4 = 8 M cells, M = 3000 control points, float32 cells; it fits one
 MI355X, so the same total problem is run at every N (cells block-sharded across ranks: strong scaling).
 Rank 0 prints ONE JSON line.  Extra objects: ``roofline`` (dominant kernel = the MFMA Gram kernel, timed with HIP
-events on its launch stream), ``con_k`` (the materialised-kernel HBM-write bandwidth) and ``cpu_baseline`` (the
-float64 NumPy oracle on the host cores; N = 1 only, bounded sample).
+events on its launch stream; ``traffic`` = the PMC figure parsed from the committed ``profiles/r02_pmc_traffic.json``),
+``solve`` (the coefficient solve: path, Jacobi sweeps, ms), ``f64`` (the SAME workload in float64 mode - the mode the
+1e-5 parity clause is about - with its own roofline; N = 1 only), ``con_k`` (the materialised-kernel HBM-write
+bandwidth) and ``cpu_baseline`` (the float64 NumPy oracle on the host cores at two sample sizes; N = 1 only).
 """
 from __future__ import annotations
 
@@ -30,29 +32,34 @@ for _p in (ROOT, os.path.join(ROOT, "spateo-release_amd")):
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (spec; 155 measured)
 PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X datasheet: FP64 matrix (v_mfma_f64_16x16x4_f64) dense peak
 PEAK_HBM_GBPS = 8000.0
-# (dtype, gram_mode, cached_u, gpus, cells, ctrl) -> corrected FETCH+WRITE bytes per launch of the dominant kernel
-PMC_TRAFFIC_BYTES = {("float32", "f64acc", True, 1, 8_000_000, 3000): 3.33e12 + 1.14e9}        # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+
+
+def pmc_traffic(dtype, gram_mode, cached_u, gpus, cells_per_rank, ctrl):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, gfx950 corrections applied; profiles/r02_hbm_traffic_pmc.md explains each entry).  None if this
+    configuration was not measured."""
+    try:
+        with open(PMC_TRAFFIC_FILE) as f:
+            entries = json.load(f)["entries"]
+    except (OSError, ValueError, KeyError):
+        return None, None
+    for e in entries:
+        if (e["dtype"], e["gram_mode"], bool(e["cached_u"]), int(e["cells_per_rank"]), int(e["ctrl"])) == \
+                (dtype, gram_mode, bool(cached_u), int(cells_per_rank), int(ctrl)):
+            return float(e["fetch_bytes"]) + float(e["write_bytes"]), e.get("source")
+    return None, None
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(M, lambda_, n_cpu, steps=2):
-    """The float64 NumPy/SciPy oracle (kind "port": dynamo is not installable) on a bounded sample of the SAME
-    workload: the C4 generator at n_cpu cells with the same M; cells/s per EM iteration is size independent at fixed
-    M, which is what makes the sample comparable."""
+def _cpu_steps(M, lambda_, n_cpu, steps):
     from oracle import sparsevfc_oracle as svo
     from spateo_amd._synthetic import make_config
 
-    try:
-        from threadpoolctl import threadpool_info
-
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
     X, V, _ = make_config("C4", N=n_cpu)
-    t0 = time.perf_counter()
     valid, Xv, Yv, idx, ctrl, beta = svo.sparsevfc_setup(X, V, M=M, seed=0)
     K = svo.con_K(ctrl, ctrl, beta)
     t1 = time.perf_counter()
@@ -67,7 +74,24 @@ def cpu_baseline(M, lambda_, n_cpu, steps=2):
         P, E, tecr, C, Vc, s2, gamma = svo.em_step(U, K, Yv, Vc, C, s2, gamma, E, a=5, lambda_=lambda_, minP=1e-5,
                                                    theta=0.75, lstsq_method="scipy")
         ts.append(time.perf_counter() - t2)
-    t_step = float(np.median(ts))
+    return N, len(ctrl), float(np.median(ts)), t_conk, U.nbytes
+
+
+def cpu_baseline(M, lambda_, n_cpu, steps=3):
+    """The float64 NumPy/SciPy oracle (kind "port": dynamo is not installable) on a bounded sample of the SAME
+    workload: the C4 generator at n_cpu cells and at n_cpu / 2 with the same M, median of `steps` EM steps each
+    (BASELINE.md section 3).  cells/s per EM iteration is size independent at fixed M up to the O(M^3) solve, which the
+    two sizes separate: t(N) = a N + b."""
+    try:
+        from threadpoolctl import threadpool_info
+
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    N, Mc, t_step, t_conk, ubytes = _cpu_steps(M, lambda_, n_cpu, steps)
+    Nh, _, t_half, _, _ = _cpu_steps(M, lambda_, n_cpu // 2, steps)
+    a = (t_step - t_half) / (N - Nh)  # seconds per cell (the part that scales with N)
+    b = t_step - a * N                # the N-independent part (lstsq of the M x M system)
     return {
         "value": N / t_step,
         "unit": "cells/s",
@@ -75,9 +99,14 @@ def cpu_baseline(M, lambda_, n_cpu, steps=2):
         "host_cpus": os.cpu_count(),
         "kind": "port",
         "sample": f"float64 NumPy oracle (cdist+exp con_K, U.T*repmat(P) temporary, scipy.linalg.lstsq), C4 generator at "
-                  f"N_cpu={N} cells, M={len(ctrl)}, median of {steps} EM steps ({t_step:.2f} s/step); con_K "
-                  f"{t_conk:.2f} s = {U.nbytes / t_conk / 1e9:.2f} GB/s of output",
+                  f"N_cpu={N} and {Nh} cells, M={Mc}, median of {steps} EM steps each ({t_step:.2f} / {t_half:.2f} s/step); "
+                  f"con_K {t_conk:.2f} s = {ubytes / t_conk / 1e9:.2f} GB/s of output",
         "ms_per_step": 1e3 * t_step,
+        "half_sample": {"cells": Nh, "ms_per_step": 1e3 * t_half, "value": Nh / t_half},
+        "linearity_ratio": (Nh / t_half) / (N / t_step),
+        "fit_seconds_per_cell": a,
+        "fit_constant_seconds": b,
+        "asymptotic_cells_per_s": (1.0 / a) if a > 0 else None,
     }
 
 
@@ -90,7 +119,12 @@ def main():
     ap.add_argument("--ctrl", type=int, default=3000, help="control points M")
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
     ap.add_argument("--lambda_", type=float, default=0.02, help="Spateo's default regularisation")
-    ap.add_argument("--cpu-cells", type=int, default=20_000, help="sample size of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-cells", type=int, default=100_000,
+                    help="sample size of the CPU baseline, also run at half of it (0 = skip)")
+    ap.add_argument("--no-f64", action="store_true", help="skip the float64-mode run of the same workload")
+    ap.add_argument("--lstsq", default="scipy", choices=["scipy", "cholesky"],
+                    help="coefficient solve: scipy = the reference's minimum-norm gelsd semantics (default); cholesky = "
+                         "jitter-escalated Cholesky (non-reference fast mode)")
     ap.add_argument("--gram-mode", default="f64acc", choices=["f64acc", "f32mfma"],
                     help="float32 Gram kernel: f64acc = float32 operands + float64 MFMA accumulation (default, meets "
                          "the 1e-3 field tolerance); f32mfma = all-float32 MFMA (2x peak, noisier)")
@@ -143,14 +177,8 @@ def main():
     if rank == 0:
         log(f"[bench] generated + preprocessed N={N} M={len(ctrl)} beta={beta:.4g} in {time.perf_counter() - t0:.1f}s; "
             f"rank shard = {hi - lo} cells")
-    kern = HipKernels(device, args.dtype, gram_mode=args.gram_mode)
-    cache_u = {"auto": "auto", "on": True, "off": False}[args.cache_u]
-    if args.gram_mode == "f32mfma":
-        cache_u = False
-    eng = SparseVFCEngine(Xv[lo:hi], Yv[lo:hi], ctrl, beta, dtype=args.dtype, device=device, distributed=distributed,
-                          n_total=N, kernels=kern, cache_u=cache_u)
-    del X, V
-    eng.init_state(gamma=0.9)
+    n_loc = hi - lo
+    Mc = len(ctrl)
     step_kw = dict(a=5.0, lambda_=args.lambda_, minP=1e-5, theta=0.75)
 
     def barrier():
@@ -159,50 +187,103 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        eng.em_step(**step_kw)
-    kern.gram_events = []
-    barrier()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        eng.em_step(**step_kw)
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.cpu()[0])
-    gram_ms = [e0.elapsed_time(e1) for e0, e1 in kern.gram_events]
-    kern.gram_events = None
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = N * args.steps / elapsed
+    def run_mode(dtype, steps, warmup):
+        """W warm-up + K timed EM iterations of the whole workload in one cell dtype; returns the timing record."""
+        kern = HipKernels(device, dtype, gram_mode=args.gram_mode)
+        cache_u = {"auto": "auto", "on": True, "off": False}[args.cache_u]
+        if args.gram_mode == "f32mfma":
+            cache_u = False
+        eng = SparseVFCEngine(Xv[lo:hi], Yv[lo:hi], ctrl, beta, dtype=dtype, device=device, distributed=distributed,
+                              n_total=N, kernels=kern, cache_u=cache_u)
+        eng.lstsq_method = args.lstsq
+        eng.init_state(gamma=0.9)
+        # the coefficient solve, bracketed by events on the launch stream (it synchronises internally once per Jacobi
+        # sweep, so event time == wall time of the call)
+        solve_events = []
+        inner = eng._solve_all
 
-    # ---------------------------------------------------------------- roofline of the dominant kernel (rank 0's shard)
-    n_loc = hi - lo
-    Mc = len(ctrl)
-    gram_avg_ms = float(np.mean(gram_ms))
-    alg_flops = float(n_loc) * Mc * (Mc + 1)  # symmetric Gram: n m (m+1) flops
-    achieved = alg_flops / (gram_avg_ms * 1e-3) / 1e12
-    f32mfma = args.dtype == "float32" and args.gram_mode == "f32mfma"
-    peak = PEAK_F32_MFMA_TFLOPS if f32mfma else PEAK_F64_MFMA_TFLOPS
-    roofline = {
-        "kernel": "gram_f32_kernel (v_mfma_f32_32x32x2_f32)" if f32mfma else
-                  (f"gram_cached_kernel<{'float' if args.dtype == 'float32' else 'double'}> (v_mfma_f64_16x16x4_f64, "
-                   f"cached {args.dtype} U streamed from HBM)" if eng.cached_u else
-                   f"gram_f64acc_kernel<{'float' if args.dtype == 'float32' else 'double'}> (v_mfma_f64_16x16x4_f64)"),
-        "bound": "mfma",
-        "achieved": achieved,
-        "peak": peak,
-        "unit": "TFLOP/s",
-        "frac": achieved / peak,
-        # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected per the gfx950
-        # notes of MI355X_MICROARCH.md; profiles/r01_hbm_traffic_pmc.md).  Only measured for the default workload.
-        "traffic": PMC_TRAFFIC_BYTES.get((args.dtype, args.gram_mode, bool(eng.cached_u), world, N, Mc)),
-        "avg_kernel_ms": gram_avg_ms,
-        "launches": len(gram_ms),
-        "algorithmic_flops_per_launch": alg_flops,
-        "share_of_step": gram_avg_ms / ms_per_step,
-    }
+        def timed_solve(ls2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            inner(ls2)
+            e1.record()
+            solve_events.append((e0, e1))
+
+        eng._solve_all = timed_solve
+        for _ in range(warmup):
+            eng.em_step(**step_kw)
+        kern.gram_events = []
+        solve_events.clear()
+        n_sweeps0 = len(eng.solver_stats["sweeps"])
+        barrier()
+        t_start = time.perf_counter()
+        for _ in range(steps):
+            eng.em_step(**step_kw)
+        barrier()
+        elapsed = time.perf_counter() - t_start
+        if distributed:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.cpu()[0])
+        gram_ms = [e0.elapsed_time(e1) for e0, e1 in kern.gram_events]
+        solve_ms = [e0.elapsed_time(e1) for e0, e1 in solve_events]
+        kern.gram_events = None
+        ms_per_step = 1e3 * elapsed / steps
+        gram_avg_ms = float(np.mean(gram_ms))
+        alg_flops = float(n_loc) * Mc * (Mc + 1)  # symmetric Gram: n m (m+1) flops (DESIGN.md)
+        achieved = alg_flops / (gram_avg_ms * 1e-3) / 1e12
+        f32mfma = dtype == "float32" and args.gram_mode == "f32mfma"
+        peak = PEAK_F32_MFMA_TFLOPS if f32mfma else PEAK_F64_MFMA_TFLOPS
+        ctype = "float" if dtype == "float32" else "double"
+        traffic, traffic_src = pmc_traffic(dtype, args.gram_mode, eng.cached_u, world, n_loc, Mc)
+        rec = {
+            "value": N * steps / elapsed,
+            "ms_per_step": ms_per_step,
+            "steps": steps,
+            "warmup": warmup,
+            "roofline": {
+                "kernel": "gram_f32_kernel (v_mfma_f32_32x32x2_f32)" if f32mfma else
+                          (f"gram_cached_kernel<{ctype}> (v_mfma_f64_16x16x4_f64, cached {dtype} U streamed from HBM)"
+                           if eng.cached_u else f"gram_f64acc_kernel<{ctype}> (v_mfma_f64_16x16x4_f64)"),
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": peak,
+                "unit": "TFLOP/s",
+                "frac": achieved / peak,
+                # HBM bytes per launch (FETCH_SIZE + WRITE_SIZE PMC passes with the gfx950 corrections) parsed from the
+                # committed profiles/r02_pmc_traffic.json for exactly this (dtype, cells per rank, M); null otherwise
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                "avg_kernel_ms": gram_avg_ms,
+                "launches": len(gram_ms),
+                "algorithmic_flops_per_launch": alg_flops,
+                "share_of_step": gram_avg_ms / ms_per_step,
+            },
+            "solve": {
+                "lstsq_method": eng.lstsq_method,
+                "path": "minimum-norm (Cholesky + one-sided block Jacobi eigensolver, eps*lambda_max cut-off)"
+                        if eng.rank_deficient else "Cholesky (pivots certify full numerical rank)",
+                "avg_ms": float(np.mean(solve_ms)),
+                "share_of_step": float(np.mean(solve_ms)) / ms_per_step,
+                "jacobi_sweeps": eng.solver_stats["sweeps"][n_sweeps0:],
+                "kept_rank": eng.solver_stats["rank"][-1] if eng.solver_stats["rank"] else Mc,
+                "warm_start": bool(eng.warm_start),
+                "jitter": eng.jitter,
+            },
+            "cached_u": bool(eng.cached_u),
+            "sigma2_after": eng.sigma2,
+            # SURVEY.md 8(d): whole-step rates over all ranks, U counted as materialised (2 s N M bytes, 2 N M^2 flop)
+            "step_effective_GBps": 2.0 * (4 if dtype == "float32" else 8) * N * Mc / (ms_per_step * 1e-3) / 1e9,
+            "step_TFLOPs_2NM2": 2.0 * N * Mc * Mc / (ms_per_step * 1e-3) / 1e12,
+        }
+        kern.drop_ublk()
+        del eng, kern
+        torch.cuda.empty_cache()
+        return rec
+
+    del X, V
+    main_rec = run_mode(args.dtype, args.steps, args.warmup)
+    value, ms_per_step = main_rec["value"], main_rec["ms_per_step"]
 
     out = {
         "metric": "cells/s per SparseVFC EM iter",
@@ -223,23 +304,28 @@ def main():
             "cells": N,
             "ctrl_points": Mc,
             "parallelism": f"cells block-sharded over {world} GPU(s), one all-reduce of [G|R|stats] per EM step",
-            "sigma2_after": eng.sigma2,
-            "solve_jitter": eng.jitter,
-            "solve_retries": eng.solve_retries,
+            "sigma2_after": main_rec["sigma2_after"],
             "gram_mode": args.gram_mode,
-            "cached_u": bool(eng.cached_u),
-            # whole-step rates over all ranks, U counted as materialised (2 s N M bytes, 2 N M^2 flop)
-            "step_effective_GBps": 2.0 * (4 if args.dtype == "float32" else 8) * N * Mc / (ms_per_step * 1e-3) / 1e9,
-            "step_TFLOPs_2NM2": 2.0 * N * Mc * Mc / (ms_per_step * 1e-3) / 1e12,
+            "cached_u": main_rec["cached_u"],
+            "step_effective_GBps": main_rec["step_effective_GBps"],
+            "step_TFLOPs_2NM2": main_rec["step_TFLOPs_2NM2"],
         },
-        "roofline": roofline,
+        "roofline": main_rec["roofline"],
+        "solve": main_rec["solve"],
     }
+
+    # ---------------------------------------------------------------- the same workload in float64 mode (N = 1)
+    if world == 1 and args.dtype == "float32" and not args.no_f64:
+        k64, w64 = max(2, min(args.steps, 5)), 1
+        r64 = run_mode("float64", k64, w64)
+        out["f64"] = {"metric": out["metric"], "unit": "cells/s", "dtype": "f64", "value": r64["value"],
+                      "ms_per_step": r64["ms_per_step"], "steps": k64, "warmup": w64, "roofline": r64["roofline"],
+                      "solve": r64["solve"], "cached_u": r64["cached_u"], "sigma2_after": r64["sigma2_after"],
+                      "note": "same cells, control points and lambda_ as the headline line, float64 cells and kernel "
+                              "values (the mode the 1e-5 parity clause refers to)"}
 
     # ---------------------------------------------------------------- con_K HBM bandwidth (N = 1, rank 0)
     if rank == 0 and world == 1 and not args.no_conk:
-        kern.drop_ublk()
-        del eng
-        torch.cuda.empty_cache()
         nk, mk = 2_000_000, 2000  # BASELINE config 3: con_K roofline run (16 GB of float32 output)
         xs = torch.from_numpy((Xv[:nk] - ctrl.mean(0)).astype(np.float32)).to(device)
         cs = torch.from_numpy((ctrl[:mk] - ctrl.mean(0)).astype(np.float32)).to(device)
