@@ -1,8 +1,9 @@
 """TEST INFRASTRUCTURE - float64 NumPy restatement of the alignment-side callers of the Gaussian kernel
 (SURVEY.md section 8f rank 4).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 
-Parity status: PINNED - ``tests/golden/ref_align.npz`` holds outputs of the real reference functions executed in the
-build container (``tests/golden/make_golden_align.py``); ``tests/test_oracle.py`` checks this file against them.
+Parity status: PINNED - ``tests/golden/ref_align.npz`` / ``ref_em.npz`` hold outputs of the real reference functions
+executed in the build container (``tests/golden/make_golden_align.py``, ``make_golden_em.py``); ``tests/test_oracle.py``
+checks this file against them.
 """
 from __future__ import annotations
 
@@ -40,3 +41,21 @@ def BA_transform(vecfld, quary_points, deformation_scale=1):
         vel = vel * scale
         opt = opt * scale + mean_ref
     return hat, vel, opt
+
+
+def update_nonrigid(coordsA, coordsB, P, K_NA, RnA, inducing_variables, beta, sigma2, lambdaVF):
+    """``Morpho_pairwise._construct_kernel`` kernels (``morpho_class.py:858-860``) + ``_update_nonrigid``
+    (``:1254-1298``; no guidance, no SVI): returns dict(GammaSparse, U, SigmaInv, PXB_term, Coff, VnA, SigmaDiag).
+    ``_pinv`` on the NumPy backend is ``scipy.linalg.pinv`` (``methods/utils.py:11,1435``)."""
+    from scipy.linalg import pinv
+
+    Gamma = con_K(inducing_variables, inducing_variables, beta)
+    U = con_K(coordsA, inducing_variables, beta)
+    SigmaInv = sigma2 * lambdaVF * Gamma + np.dot(U.T, np.einsum("ij,i->ij", U, K_NA))
+    PXB = np.dot(P, coordsB) - np.einsum("ij,i->ij", RnA, K_NA)
+    UPXB = np.dot(U.T, PXB)
+    Sigma = pinv(SigmaInv)
+    Coff = np.dot(Sigma, UPXB)
+    VnA = np.dot(U, Coff)
+    SigmaDiag = sigma2 * np.einsum("ij->i", np.einsum("ij,ji->ij", U, np.dot(Sigma, U.T)))
+    return dict(GammaSparse=Gamma, U=U, SigmaInv=SigmaInv, PXB_term=PXB, Coff=Coff, VnA=VnA, SigmaDiag=SigmaDiag)

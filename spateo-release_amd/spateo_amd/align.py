@@ -1,4 +1,5 @@
-"""Alignment-side caller of the same Gaussian kernel: ``BA_transform``.
+"""Alignment-side callers of the same Gaussian kernel and M-step: ``BA_transform`` and
+``update_nonrigid`` (the non-rigid update of ``Morpho_pairwise``: the SparseVFC M-step with Gamma <-> K, K_NA <-> P).
 
 Mirror of ``spateo/alignment/transform.py:61-116``: the learned non-rigid alignment ``vecfld`` (output of
 ``st.align.morpho_align``) applied to query points.  The N x M kernel contraction ``con_K(x, ctrl, beta) @ Coff`` runs
@@ -10,9 +11,70 @@ from __future__ import annotations
 
 import numpy as np
 
+import torch
+
+from . import _lib
+from . import vectorfield as _vf
 from .vectorfield import vector_field_function
 
-__all__ = ["BA_transform"]
+__all__ = ["BA_transform", "update_nonrigid"]
+
+
+def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, lambdaVF, dtype: str = "float64",
+                    device=None):
+    """The non-rigid update of Spateo's alignment, ``Morpho_pairwise._update_nonrigid``
+    (``spateo/alignment/methods/morpho_class.py:1254-1298``, no guidance, no SVI), on the MI355X with the kernels of the
+    SparseVFC M-step - it is the same computation (``SigmaInv = sigma2 lambdaVF Gamma + U^T diag(K_NA) U``,
+    ``Coff = pinv(SigmaInv) U^T PXB_term``, ``VnA = U Coff``; Gamma = con_K(ctrl, ctrl), U = con_K(coordsA, ctrl) as
+    ``_construct_kernel`` builds them, ``:825-875``):
+
+    * ``U^T diag(K_NA) U`` and ``U^T PXB_term``  -> ``mvf_gram`` (f64 MFMA; U is never materialised),
+    * ``pinv(SigmaInv) @ rhs``                   -> ``mvf_solve_minnorm`` with scipy.linalg.pinv's default cut-off
+      ``max(M, M) * eps * s_max`` (what ``_pinv`` resolves to on the NumPy backend, ``methods/utils.py:11,1435``),
+    * ``U @ Coff``                               -> ``mvf_apply``.
+
+    ``PXB_term`` (n x D) is the reference's ``P @ coordsB - RnA * K_NA[:, None]`` (O(n nb) host work that belongs to the
+    assignment step, not to this one).  Returns ``{"SigmaInv", "Coff", "VnA"}`` as host float64.  ``SigmaDiag`` (the
+    n-vector ``sigma2 diag(U pinv(SigmaInv) U^T)`` feeding the alignment's variational sigma^2) is not computed."""
+    if dtype not in ("float32", "float64"):
+        raise ValueError("dtype must be 'float32' or 'float64'")
+    X = np.asarray(coordsA, dtype=np.float64)
+    ctrl = np.asarray(inducing_variables, dtype=np.float64)
+    w = np.asarray(K_NA, dtype=np.float64).reshape(-1)
+    B = np.asarray(PXB_term, dtype=np.float64)
+    if X.ndim != 2 or ctrl.ndim != 2 or X.shape[1] != ctrl.shape[1]:
+        raise AssertionError("X and Y do not have the same number of features.")  # con_K's assertion (utils.py:1150)
+    if len(w) != len(X) or B.shape[0] != len(X) or B.ndim != 2 or not (1 <= B.shape[1] <= 3):
+        raise ValueError("K_NA must be (n,) and PXB_term (n, D) with D <= 3")
+    n, m, D = len(X), len(ctrl), B.shape[1]
+    k = _vf._make_kernels(device, dtype)
+    center = ctrl.mean(0)
+    x4, c4 = k.to_x4(X, center), k.to_x4(ctrl, center)
+    cc = np.zeros((m, 3))
+    cc[:, : ctrl.shape[1]] = ctrl - center
+    c64 = torch.from_numpy(cc).to(k.device)
+    Gamma = k.con_k(c64, c64, float(beta), dtype="float64")
+    # rhs = U^T PXB = U^T diag(K_NA) Y with Y = PXB / K_NA (rows with K_NA == 0 have PXB == 0: cells without a partner)
+    Y = np.divide(B, w[:, None], out=np.zeros_like(B), where=w[:, None] != 0)
+    y4 = k.to_x4(Y)
+    Pw = torch.from_numpy(w.astype(np.float32 if dtype == "float32" else np.float64)).to(k.device)
+    f64 = torch.float64
+    G, R = k.zeros(m, m, dtype=f64), k.zeros(m, 3, dtype=f64)
+    k.gram(x4, Pw, y4, c4, float(beta), G, R)
+    ls2 = float(sigma2) * float(lambdaVF)
+    C, info, einfo = k.zeros(m, 3, dtype=f64), k.zeros(1, dtype=torch.int32), k.zeros(12, dtype=f64)
+    shift = 2.0 ** -36
+    while True:
+        k.solve_minnorm(G, Gamma, ls2, shift, R, C, info, einfo, rcond=m * float(np.finfo(np.float64).eps))
+        if int(info.cpu()[0]) == 0:
+            break
+        shift *= 16.0
+        if shift > 2.0 ** -12:
+            raise _lib.MVFError("update_nonrigid: SigmaInv is not numerically positive semi-definite")
+    V4, _ = k.apply(x4, c4, float(beta), C)
+    SigmaInv = G.cpu().numpy() + ls2 * Gamma.cpu().numpy()
+    return {"SigmaInv": SigmaInv, "Coff": C.cpu().numpy()[:, :D].copy(),
+            "VnA": V4[:, :D].to(f64).cpu().numpy()}
 
 
 def BA_transform(vecfld, quary_points, deformation_scale: int = 1, dtype: str = "float64", device=None):

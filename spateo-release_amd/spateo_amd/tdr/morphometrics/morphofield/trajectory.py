@@ -5,7 +5,9 @@ The reference hands the field to dynamo's ``fate`` (adaptive RK45 + arc-length r
 reference tree).  Here the whole integration runs in ONE fused HIP kernel (``mvf_integrate``: classical RK4, one lane per
 trajectory) and the trajectories are sampled at ``interpolation_num`` UNIFORM time points - documented deviation,
 parity unpinned.  Output slots are the reference's: ``uns[key_added]["t"][i]`` (times) and
-``uns[key_added]["prediction"][i]`` ((d, n_t) states) per cell."""
+``uns[key_added]["prediction"][i]`` ((n_t, d) states: the reference transposes dynamo ``fate``'s (d, n_t) arrays,
+``trajectory.py:113``, and its consumer concatenates ``init_states[[i]]`` with it along axis 0,
+``tdr/models/models_migration/morphopath_model.py:225``) per cell; ``init_cells`` = the cells' ``obs_names``."""
 from __future__ import annotations
 
 from typing import Optional, Union
@@ -13,6 +15,11 @@ from typing import Optional, Union
 import numpy as np
 
 from ....vectorfield import integrate_field
+
+
+def _obs_names(adata, n):
+    names = getattr(adata, "obs_names", None)
+    return [str(x) for x in names] if names is not None and len(names) == n else [str(i) for i in range(n)]
 
 
 def morphopath(
@@ -47,10 +54,10 @@ def morphopath(
     n = len(pred)
     adata.uns[key_added] = {
         "init_states": init_states,
-        "init_cells": list(range(len(init_states))),
+        "init_cells": _obs_names(adata, len(init_states)),
         "average": average,
         "genes": None,
         "t": {i: t[i] for i in range(n)},
-        "prediction": {i: pred[i].T for i in range(n)},
+        "prediction": {i: pred[i] for i in range(n)},
     }
     return None if inplace else adata

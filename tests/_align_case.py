@@ -24,3 +24,24 @@ def check_ba(fn, g, rtol, **kw):
             ref = g[f"ba_{tag}_{key}"]
             assert got.shape == ref.shape and got.dtype == np.float64
             assert np.abs(got - ref).max() <= rtol * np.abs(ref).max(), (tag, key)
+
+
+def check_update_nonrigid(fn, g, dtype, device=None):
+    """fn = spateo_amd.align.update_nonrigid against the goldens of the real Morpho_pairwise._update_nonrigid."""
+    tol = {"float64": (1e-8, 1e-8, 5e-3), "float32": (2e-3, 1e-3, 2e-2)}[dtype]
+    out = {}
+    for tag in ("a", "b"):
+        r = fn(g[f"{tag}_coordsA"], g[f"{tag}_inducing_variables"], float(g[f"{tag}_beta"]), g[f"{tag}_K_NA"],
+               g[f"{tag}_PXB_term"], float(g[f"{tag}_sigma2"]), float(g[f"{tag}_lambdaVF"]), dtype=dtype, device=device)
+        rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())  # noqa: E731
+        assert r["Coff"].shape == g[f"{tag}_Coff"].shape and r["VnA"].shape == g[f"{tag}_VnA"].shape
+        e_s = rel(r["SigmaInv"], g[f"{tag}_SigmaInv"])
+        e_v = rel(r["VnA"], g[f"{tag}_VnA"])
+        out[tag] = (e_s, e_v)
+        assert e_s < (1e-10 if dtype == "float64" else 1e-5), (tag, e_s)
+        if tag == "a":  # well conditioned: the coefficients themselves are determined
+            assert rel(r["Coff"], g["a_Coff"]) < tol[0]
+            assert e_v < tol[1], e_v
+        else:  # rank deficient (99 of 120 directions kept): the field, to the noise level of that system (6e-4)
+            assert e_v < tol[2], e_v
+    return out

@@ -29,3 +29,12 @@ def golden_align():
     path = os.path.join(ROOT, "tests", "golden", "ref_align.npz")
     with np.load(path) as z:
         return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def golden_em():
+    """Inputs / outputs of the real Morpho_pairwise._construct_kernel + _update_nonrigid (tests/golden/make_golden_em.py):
+    the in-tree statement of the SparseVFC M-step arithmetic."""
+    path = os.path.join(ROOT, "tests", "golden", "ref_em.npz")
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}

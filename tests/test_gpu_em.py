@@ -500,3 +500,45 @@ def test_ba_transform_against_reference_goldens(st, golden_align, dtype, tol):
     check_ba(st.align.BA_transform, g, tol, dtype=dtype)
     K = st.con_K(g["ak_x"], g["ak_y"], float(g["ak_beta"]), dtype=dtype)
     assert _rel(K, g["ak_K"]) < (1e-13 if dtype == "float64" else 1e-6)
+
+
+# ------------------------------------------------------------------------------------------- kernel_interpolation
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_kernel_interpolation_wrapper_on_the_gpu(st, dtype):
+    """``st.tdr.kernel_interpolation`` itself (interpolation_sparseVFC.py:13-85: obs keys + genes -> wide Y -> grid_V split
+    back) on the real kernels, against the oracle at the SparseVFC seam."""
+    import spateo_amd.vectorfield as vfm
+
+    rng = np.random.default_rng(3)
+    n = 5000
+    S = rng.uniform(-1, 1, (n, 3)) * 50
+    genes = np.column_stack([np.sin(S[:, 0] / 20), np.cos(S[:, 1] / 15), S[:, 2] / 50, np.sin(S[:, 0] / 9) ** 2,
+                             np.cos(S[:, 2] / 11) * np.sin(S[:, 1] / 13)])
+    genes += 0.01 * rng.standard_normal(genes.shape)
+    score = np.cos(S[:, 2] / 25)
+    ad = st.AnnDataLite(X=genes, var_names=["g0", "g1", "g2", "g3", "g4"], obs={"score": score}, obsm={"spatial": S})
+    tgt = rng.uniform(-1, 1, (300, 3)) * 45
+    kw = dict(M=120, MaxIter=10, seed=0)
+    old = vfm._DEFAULT_DTYPE
+    vfm.set_default_dtype(dtype)
+    try:
+        out = st.tdr.kernel_interpolation(ad, target_points=tgt, keys=["g2", "score", "g0", "g3", "g4"], lambda_=3.0, **kw)
+    finally:
+        vfm.set_default_dtype(old)
+    info = np.column_stack([score, genes[:, [2, 0, 3, 4]]])  # obs keys first, then genes, each in `keys` order
+    ref = svo.SparseVFC(S, info, tgt, lambda_=3.0, lstsq_method="scipy", **kw)["grid_V"]
+    got = np.column_stack([np.asarray(out.obs["score"], dtype=float), np.asarray(out.X)])
+    assert got.shape == (300, 5) and list(out.var_names) == ["g2", "g0", "g3", "g4"]
+    assert _rel(got, ref) < TOL[dtype]
+    np.testing.assert_array_equal(np.asarray(out.obsm["spatial"]), tgt)
+
+
+# ------------------------------------------------------------------------------------------- alignment M-step
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_update_nonrigid_against_reference_goldens(st, golden_em, dtype):
+    """mvf_gram + mvf_solve_minnorm + mvf_apply against the outputs of the REAL Morpho_pairwise._construct_kernel +
+    _update_nonrigid (tests/golden/make_golden_em.py): the in-tree reference statement of the M-step arithmetic."""
+    from _align_case import check_update_nonrigid
+
+    errs = check_update_nonrigid(st.align.update_nonrigid, golden_em, dtype, device="cuda:0")
+    print(f"update_nonrigid {dtype}: (SigmaInv, VnA) errors vs reference: {errs}")

@@ -422,21 +422,24 @@ def test_morphopath_slots_and_accuracy(cpu_kernels, golden):
     ad.uns["VecFld_morpho"] = vf
     assert st.tdr.morphopath(ad, interpolation_num=21, t_end=40.0, direction="both") is None
     fate = ad.uns["fate_morpho"]
-    assert set(fate["t"].keys()) == set(range(6)) and fate["prediction"][0].shape == (3, 41)
+    assert set(fate["t"].keys()) == set(range(6)) and fate["prediction"][0].shape == (41, 3)  # (n_t, d) as the reference
+    # the reference's consumer (construct_trajectory_X, morphopath_model.py:225) prepends the start point along axis 0
+    assert np.concatenate([fate["init_states"][[0]], fate["prediction"][0]], axis=0).shape == (42, 3)
+    assert fate["init_cells"] == [str(i) for i in range(6)]
     np.testing.assert_allclose(fate["t"][0], np.linspace(-40, 40, 41))
-    np.testing.assert_allclose(fate["prediction"][2][:, 20], g["a_X"][2])  # t = 0 is the start point
+    np.testing.assert_allclose(fate["prediction"][2][20], g["a_X"][2])  # t = 0 is the start point
     tq = np.linspace(0, 40, 21)
     ref = tro.integrate(vf, g["a_X"][:6], tq)
-    got = np.stack([fate["prediction"][i].T[20:] for i in range(6)])
+    got = np.stack([fate["prediction"][i][20:] for i in range(6)])
     assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-7
     refb = tro.integrate(vf, g["a_X"][:6], -tq)
-    gotb = np.stack([fate["prediction"][i].T[20::-1] for i in range(6)])
+    gotb = np.stack([fate["prediction"][i][20::-1] for i in range(6)])
     assert np.abs(gotb - refb).max() / np.abs(refb).max() < 1e-7
     # default t_end (dynamo getTend), averaging modes, copies, errors
     ad2 = st.tdr.morphopath(ad, interpolation_num=5, average="origin", inplace=False, key_added="f2")
     assert "f2" in ad2.uns and "f2" not in ad.uns and len(ad2.uns["f2"]["prediction"]) == 1
     st.tdr.morphopath(ad, interpolation_num=5, t_end=3.0, average="trajectory", key_added="f3")
-    assert ad.uns["f3"]["prediction"][0].shape == (3, 5)
+    assert ad.uns["f3"]["prediction"][0].shape == (5, 3)
     ad.uns["bad"] = {"method": "other", "X": g["a_X"][:2]}
     with pytest.raises(Exception, match="not in avaliable"):
         st.tdr.morphopath(ad, vf_key="bad")
@@ -578,3 +581,14 @@ def test_unique_rows_and_shard_bounds_properties():
 
     uniq()
     shards()
+
+
+def test_update_nonrigid_host_composition_matches_reference(cpu_kernels, golden_em):
+    """spateo_amd.align.update_nonrigid (host composition around gram / min-norm solve / apply) against the outputs of
+    the real Morpho_pairwise._update_nonrigid (device replaced by the CPU double; the GPU test runs the kernels)."""
+    from _align_case import check_update_nonrigid
+
+    check_update_nonrigid(st.align.update_nonrigid, golden_em, "float64")
+    with pytest.raises(AssertionError):
+        st.align.update_nonrigid(golden_em["a_coordsA"][:, :2], golden_em["a_inducing_variables"], 0.5,
+                                 golden_em["a_K_NA"], golden_em["a_PXB_term"], 0.5, 100.0)

@@ -227,3 +227,49 @@ def test_alignment_oracle_pinned_by_reference(golden_align):
     # the dynamo-style oracle (cdist formulation) agrees with the alignment formulation to rounding
     np.testing.assert_allclose(svo.con_K(g["ak_x"], g["ak_y"], float(g["ak_beta"])), g["ak_K"], rtol=1e-12, atol=0)
     check_ba(ao.BA_transform, g, 1e-14)
+
+
+def _field_rel(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def test_m_step_arithmetic_pinned_by_the_reference_alignment_code(golden_em):
+    """The SparseVFC M-step as REAL reference code states it in-tree: ``Morpho_pairwise._construct_kernel`` +
+    ``_update_nonrigid`` (spateo/alignment/methods/morpho_class.py:825-875,1254-1298), executed by
+    tests/golden/make_golden_em.py.  (i) the alignment oracle reproduces it; (ii) the SparseVFC oracle's own M-step
+    lines (``lhs = U^T P U + lambda sigma^2 K``, ``rhs = U^T P Y``, ``lstsq``, ``V = U C``) reproduce the same numbers
+    with Gamma <-> K, K_NA <-> P, PXB_term <-> P * Y."""
+    from oracle import align_oracle as ao
+    from oracle import sparsevfc_oracle as svo
+
+    g = golden_em
+    # ---- (i) case a, every quantity
+    r = ao.update_nonrigid(g["a_coordsA"], g["a_coordsB"], g["a_P"], g["a_K_NA"], g["a_RnA"], g["a_inducing_variables"],
+                           float(g["a_beta"]), float(g["a_sigma2"]), float(g["a_lambdaVF"]))
+    for key, tol in (("GammaSparse", 1e-12), ("U", 1e-12), ("SigmaInv", 1e-12), ("PXB_term", 1e-12), ("Coff", 1e-8),
+                     ("VnA", 1e-9), ("SigmaDiag", 1e-8)):
+        assert _field_rel(r[key], g[f"a_{key}"]) < tol, key
+    # ---- (ii) the SparseVFC oracle's M-step on the same data
+    for tag, ctol, vtol in (("a", 1e-8, 1e-9), ("b", None, 5e-3)):
+        ctrl, beta = g[f"{tag}_inducing_variables"], float(g[f"{tag}_beta"])
+        s2, lam = float(g[f"{tag}_sigma2"]), float(g[f"{tag}_lambdaVF"])
+        P, PXB = g[f"{tag}_K_NA"], g[f"{tag}_PXB_term"]
+        # dynamo's con_K (cdist) vs the alignment's (||x||^2 + ||y||^2 - 2 x.y): same kernel, different rounding
+        K = svo.con_K(ctrl, ctrl, beta)
+        U = svo.con_K(g[f"{tag}_coordsA"], ctrl, beta)
+        Y = np.divide(PXB, P[:, None], out=np.zeros_like(PXB), where=P[:, None] != 0)
+        UP = U.T * np.tile(P[None, :], (len(ctrl), 1))  # the repmat temporary of SparseVFC
+        lhs = UP.dot(U) + lam * s2 * K
+        rhs = UP.dot(Y)
+        assert _field_rel(lhs, g[f"{tag}_SigmaInv"]) < 1e-10
+        if tag == "a":  # well conditioned: dynamo's lstsq and the alignment's pinv are the same solve
+            C = svo.lstsq_solver(lhs, rhs, "scipy")
+            assert _field_rel(C, g["a_Coff"]) < ctol
+        else:
+            # numerically rank deficient (99 of 120 directions above scipy.linalg.pinv's M eps cut-off): same cut-off as
+            # the reference; the field agrees to the noise level of this system (a 1e-13 perturbation moves it by 6e-4)
+            import scipy.linalg
+
+            C = scipy.linalg.pinv(lhs).dot(rhs)
+        V = U.dot(C)
+        assert _field_rel(V, g[f"{tag}_VnA"]) < vtol, (tag, _field_rel(V, g[f"{tag}_VnA"]))
