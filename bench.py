@@ -213,6 +213,7 @@ def main():
         for _ in range(warmup):
             eng.em_step(**step_kw)
         kern.gram_events = []
+        eng.comm_events = [] if distributed else None
         solve_events.clear()
         n_sweeps0 = len(eng.solver_stats["sweeps"])
         barrier()
@@ -276,6 +277,21 @@ def main():
             "step_effective_GBps": 2.0 * (4 if dtype == "float32" else 8) * N * Mc / (ms_per_step * 1e-3) / 1e9,
             "step_TFLOPs_2NM2": 2.0 * N * Mc * Mc / (ms_per_step * 1e-3) / 1e12,
         }
+        if distributed:
+            # what the first multi-GPU run needs to explain itself: per-rank Gram time and the collectives
+            big = [(e0.elapsed_time(e1), nb) for e0, e1, nb in eng.comm_events if nb > 1024]
+            small = [e0.elapsed_time(e1) for e0, e1, nb in eng.comm_events if nb <= 1024]
+            mine = {"rank": rank, "cells": n_loc, "gram_ms": gram_avg_ms, "solve_ms": float(np.mean(solve_ms)),
+                    "allreduce_ms": float(np.mean([t for t, _ in big])) if big else None,
+                    "allreduce_bytes": big[0][1] if big else 0,
+                    "scalar_allreduce_ms": float(np.mean(small)) if small else None}
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+            rec["per_rank"] = allr
+            rec["comm"] = {"collectives_per_step": len(eng.comm_events) / steps, "allreduce_bytes": mine["allreduce_bytes"],
+                           "allreduce_ms_max": max((r_["allreduce_ms"] or 0.0) for r_ in allr),
+                           "note": "event time on the compute stream around each all_reduce: includes waiting for the "
+                                   "slowest rank to arrive"}
         kern.drop_ublk()
         del eng, kern
         torch.cuda.empty_cache()
@@ -313,6 +329,11 @@ def main():
         "roofline": main_rec["roofline"],
         "solve": main_rec["solve"],
     }
+    if distributed:
+        out["per_rank"], out["comm"] = main_rec["per_rank"], main_rec["comm"]
+        out["config"]["parallelism"] = (f"cells block-sharded over {world} GPUs; per EM step one all-reduce of "
+                                        f"[tri(G) | R | stats] ({main_rec['comm']['allreduce_bytes'] / 1e6:.1f} MB) + one "
+                                        f"scalar all-reduce; redundant coefficient solve on every rank")
 
     # ---------------------------------------------------------------- the same workload in float64 mode (N = 1)
     if world == 1 and args.dtype == "float32" and not args.no_f64:

@@ -64,9 +64,12 @@ int mvf_con_k_d(const void* x, int64_t n, const void* y, int64_t m, int d, doubl
  * U is never materialised: kernel values are recomputed from x and ctrl.  x4: n x 4, ctrl4: m x 4 (dtype),
  * C: m x 3 float64 (unused columns zero), V4 out: n x 4 (dtype, 4th = 0).
  * If y4 != NULL also writes r[i] = ||y_i - V_i||^2 (dtype) and, if P != NULL (dtype, n), accumulates
- * stats[0] += sum_i P_i r_i  (float64; caller zeroes stats). */
+ * stats[0] += sum_i P_i r_i  (float64; caller zeroes stats).  Reductions over cells are DETERMINISTIC everywhere in
+ * this library: per-workgroup partials go to `scratch` (caller-provided, >= mvf_reduce_scratch_doubles(n) float64,
+ * needed whenever P != NULL) and are summed in workgroup order by one workgroup - no floating-point atomics. */
+size_t mvf_reduce_scratch_doubles(int64_t n);
 int mvf_apply(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, const double* C, void* V4,
-              const void* y4, const void* P, void* r, double* stats, mvf_dtype dtype, void* stream);
+              const void* y4, const void* P, void* r, double* stats, double* scratch, mvf_dtype dtype, void* stream);
 
 /* ---- E-step ---------------------------------------------------------------------------------------------------
  * Replaces: dynamo `get_P` + the `P = max(P, minP)` / numcorr lines of SparseVFC.
@@ -74,13 +77,18 @@ int mvf_apply(const void* x4, int64_t n, const void* ctrl4, int64_t m, double be
  * min(temp1[temp1 != 0])` can be made global across ranks between them:
  *   mvf_estep_min : mins[0] = min non-zero exp(-r/(2 sigma2)) (float64, +inf if none), mins[1] = #zeros;
  *                   `mins` must hold MVF_ESTEP_MIN_DOUBLES float64 (the tail is block-partial scratch)
- *   mvf_estep_p   : P_out (dtype, n) = max(P, minP) with P = t1/(t1+t2);  stats (float64[4], caller zeroes):
- *                   [0] += sum P_unfloored * r, [1] += sum P_unfloored, [2] += sum P_floored, [3] += #(P_floored > theta)
+ *   mvf_estep_p   : P_out (dtype, n) = max(P, minP) with P = t1/(t1+t2);  stats (float64[5], caller zeroes):
+ *                   [0] += sum P_unfloored * r, [1] += sum P_unfloored, [2] += sum P_floored, [3] += #(P_floored > theta),
+ *                   [4] += #(t1 == 0), the cells that took t1_zero_fill.  The host runs mvf_estep_p FIRST with
+ *                   t1_zero_fill = 0 and only if the (all-reduced) [4] is non-zero - exp(-r / 2 sigma2) underflowed
+ *                   for some cell: gross outliers at a small sigma2, rare - repeats the E-step through mvf_estep_min;
+ *                   the common path then needs neither the MIN collective nor a host round trip before the Gram.
+ *                   scratch: >= mvf_reduce_scratch_doubles(n) float64 (deterministic two-level sums).
  * All arithmetic in float64 regardless of dtype. */
 #define MVF_ESTEP_MIN_DOUBLES 4098
 int mvf_estep_min(const void* r, int64_t n, double sigma2, double* mins, mvf_dtype dtype, void* stream);
 int mvf_estep_p(const void* r, int64_t n, double sigma2, double gamma, double a, int dy, double minP, double theta,
-                double t1_zero_fill, void* P_out, double* stats, mvf_dtype dtype, void* stream);
+                double t1_zero_fill, void* P_out, double* stats, double* scratch, mvf_dtype dtype, void* stream);
 
 /* ---- M-step assembly:  G = U^T diag(P) U (m x m),  R = U^T diag(P) Y (m x 3)  --------------------------------
  * Replaces: `UP = U.T * repmat(P.T, M, 1); lhs = UP.dot(U) ...; rhs = UP.dot(Y)` of SparseVFC (App. A 5c; same
@@ -161,8 +169,14 @@ int mvf_solve_minnorm(const double* G, const double* K, double lambda_sigma2, do
                       int reuse, double* basis, int warm, void* workspace, size_t workspace_bytes, void* stream);
 size_t mvf_solve_minnorm_basis_bytes(int64_t m);
 
-/* trace(C^T K C) -> out[0] (float64), the regulariser of the energy (App. A 5b). K: m x m, C: m x nrhs. */
-int mvf_quadform(const double* K, const double* C, int64_t m, int nrhs, double* out, void* stream);
+/* trace(C^T K C) -> out[0] (float64), the regulariser of the energy (App. A 5b). K: m x m, C: m x nrhs;
+ * scratch >= m float64 (row partials, summed in row order). */
+int mvf_quadform(const double* K, const double* C, int64_t m, int nrhs, double* out, double* scratch, void* stream);
+
+/* Packed upper triangle (row-major, row i = columns i..m-1, m (m + 1) / 2 float64) <-> full symmetric m x m: the
+ * multi-GPU host all-reduces the packed triangle of G (36 MB instead of 72 MB at m = 3000). */
+int mvf_sym_pack(const double* G, int64_t m, double* tri, void* stream);
+int mvf_sym_unpack(const double* tri, int64_t m, double* G, void* stream);
 
 /* ---- differential-geometry evaluators -------------------------------------------------------------------------
  * Replaces: dynamo `Jacobian_rkhs_gaussian` and `compute_{acceleration,curvature,curl,torsion,divergence}` =

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const T* __restrict__ x4, in
                                                     int64_t m, T s, const double* __restrict__ C /* m x 3 */,
                                                     T* __restrict__ V4, const T* __restrict__ y4,
                                                     const T* __restrict__ P, T* __restrict__ r,
-                                                    double* __restrict__ stats) {
+                                                    double* __restrict__ block_pr) {
     using V4T = typename Vec4<T>::type;
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[APPLY_CHUNK * (sizeof(V4T) + 4 * sizeof(double))];
     V4T* sc = reinterpret_cast<V4T*>(smem_raw);                                         // scaled ctrl coords
@@ -85,10 +85,23 @@ __global__ __launch_bounds__(256) void apply_kernel(const T* __restrict__ x4, in
             }
         }
     }
-    if (y4 && P && stats) {
+    if (y4 && P && block_pr) {
         __shared__ double red[4];
         const double t = block_sum<256>(pr, red);
-        if (threadIdx.x == 0) atomicAdd(stats, t);
+        if (threadIdx.x == 0) block_pr[blockIdx.x] = t;  // summed in block order by sum_partials_kernel: deterministic
+    }
+}
+
+// out[k] += sum over b (in order) of partials[b * stride + k]   (one workgroup, K <= 8 columns; fixed summation order)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partials, int64_t nb, int stride,
+                                                           int K, double* __restrict__ out) {
+    __shared__ double red[4];
+    for (int k = 0; k < K; ++k) {
+        double s = 0.0;
+        for (int64_t b = threadIdx.x; b < nb; b += 256) s += partials[b * stride + k];
+        const double t = block_sum<256>(s, red);
+        if (threadIdx.x == 0) out[k] += t;
+        __syncthreads();
     }
 }
 
@@ -135,12 +148,15 @@ __global__ __launch_bounds__(256) void estep_min_finish(const double* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void estep_p_kernel(const T* __restrict__ r, int64_t n, double inv2s2, double t2,
                                                       double minP, double theta, double zero_fill,
-                                                      T* __restrict__ Pout, double* __restrict__ stats) {
-    double s_pr = 0.0, s_p = 0.0, s_pf = 0.0, s_cnt = 0.0;
+                                                      T* __restrict__ Pout, double* __restrict__ block_stats) {
+    double s_pr = 0.0, s_p = 0.0, s_pf = 0.0, s_cnt = 0.0, s_zero = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const double ri = (double)r[i];
         double t1 = exp(-ri * inv2s2);
-        if (t1 == 0.0) t1 = zero_fill;
+        if (t1 == 0.0) {
+            t1 = zero_fill;
+            s_zero += 1.0;
+        }
         const double p = t1 / (t1 + t2);
         s_pr += p * ri;
         s_p += p;
@@ -154,11 +170,10 @@ __global__ __launch_bounds__(256) void estep_p_kernel(const T* __restrict__ r, i
     const double b = block_sum<256>(s_p, red);
     const double c = block_sum<256>(s_pf, red);
     const double d = block_sum<256>(s_cnt, red);
+    const double e = block_sum<256>(s_zero, red);
     if (threadIdx.x == 0) {
-        atomicAdd(stats + 0, a);
-        atomicAdd(stats + 1, b);
-        atomicAdd(stats + 2, c);
-        atomicAdd(stats + 3, d);
+        double* o = block_stats + (int64_t)blockIdx.x * 5;
+        o[0] = a, o[1] = b, o[2] = c, o[3] = d, o[4] = e;
     }
 }
 
@@ -166,8 +181,8 @@ __global__ __launch_bounds__(256) void estep_p_kernel(const T* __restrict__ r, i
 // trace(C^T K C)
 // ----------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void quadform_kernel(const double* __restrict__ K, const double* __restrict__ C,
-                                                       int64_t m, int nrhs, double* __restrict__ out) {
-    // one block per row i:  sum_d C[i,d] * sum_j K[i,j] C[j,d]
+                                                       int64_t m, int nrhs, double* __restrict__ row_out) {
+    // one block per row i:  sum_d C[i,d] * sum_j K[i,j] C[j,d]  -> row_out[i] (summed in row order afterwards)
     const int64_t i = blockIdx.x;
     double acc = 0.0;
     for (int d = 0; d < nrhs; ++d) {
@@ -177,38 +192,83 @@ __global__ __launch_bounds__(256) void quadform_kernel(const double* __restrict_
     }
     __shared__ double red[4];
     const double s = block_sum<256>(acc, red);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) row_out[i] = s;
+}
+
+// packed upper triangle (row-major: row i holds columns i..m-1) <-> full symmetric matrix
+__device__ __forceinline__ int64_t tri_offset(int64_t i, int64_t m) { return i * m - i * (i - 1) / 2; }
+
+__global__ __launch_bounds__(256) void sym_pack_kernel(const double* __restrict__ G, int64_t m, double* __restrict__ tri) {
+    const int64_t i = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < m && j >= i) tri[tri_offset(i, m) + (j - i)] = G[i * m + j];
+}
+
+__global__ __launch_bounds__(256) void sym_unpack_kernel(const double* __restrict__ tri, int64_t m, double* __restrict__ G) {
+    const int64_t i = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    G[i * m + j] = j >= i ? tri[tri_offset(i, m) + (j - i)] : tri[tri_offset(j, m) + (i - j)];
 }
 
 }  // namespace mvf
 
 using namespace mvf;
 
+extern "C" int mvf_sym_pack(const double* G, int64_t m, double* tri, void* stream) {
+    MVF_REQUIRE(m >= 0 && m <= 65535, "mvf_sym_pack: bad m");
+    if (m == 0) return 0;
+    MVF_REQUIRE(G && tri, "mvf_sym_pack: null pointer");
+    hipLaunchKernelGGL(sym_pack_kernel, dim3((unsigned)cdiv(m, 256), (unsigned)m), dim3(256), 0, (hipStream_t)stream, G, m,
+                       tri);
+    MVF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mvf_sym_unpack(const double* tri, int64_t m, double* G, void* stream) {
+    MVF_REQUIRE(m >= 0 && m <= 65535, "mvf_sym_unpack: bad m");
+    if (m == 0) return 0;
+    MVF_REQUIRE(G && tri, "mvf_sym_unpack: null pointer");
+    hipLaunchKernelGGL(sym_unpack_kernel, dim3((unsigned)cdiv(m, 256), (unsigned)m), dim3(256), 0, (hipStream_t)stream,
+                       tri, m, G);
+    MVF_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int mvf_apply(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, const double* C,
-                         void* V4, const void* y4, const void* P, void* r, double* stats, mvf_dtype dtype,
-                         void* stream) {
+                         void* V4, const void* y4, const void* P, void* r, double* stats, double* scratch,
+                         mvf_dtype dtype, void* stream) {
     MVF_REQUIRE(n >= 0 && m >= 0, "mvf_apply: bad shape");
     MVF_REQUIRE(beta >= 0.0 && std::isfinite(beta), "mvf_apply: beta must be finite and >= 0");
     if (n == 0) return 0;
     MVF_REQUIRE(x4 && V4 && (m == 0 || (ctrl4 && C)), "mvf_apply: null pointer");
     MVF_REQUIRE(!y4 || r, "mvf_apply: y4 given but r is null");
-    MVF_REQUIRE(!(P && y4) || stats, "mvf_apply: P given but stats is null");
+    MVF_REQUIRE(!(P && y4) || (stats && scratch), "mvf_apply: P given but stats / scratch is null");
     hipStream_t st = (hipStream_t)stream;
     const double s = std::sqrt(beta * LOG2E);
     constexpr int CPT = 4;
-    dim3 grid((unsigned)cdiv(n, 256 * CPT));
+    const int64_t nblocks = dtype == MVF_F32 ? cdiv(n, 256 * CPT) : cdiv(n, 256 * 2);
     if (dtype == MVF_F32)
-        hipLaunchKernelGGL((apply_kernel<float, CPT>), grid, dim3(256), 0, st, (const float*)x4, n,
+        hipLaunchKernelGGL((apply_kernel<float, CPT>), dim3((unsigned)nblocks), dim3(256), 0, st, (const float*)x4, n,
                            (const float*)ctrl4, m, (float)s, C, (float*)V4, (const float*)y4, (const float*)P,
-                           (float*)r, stats);
+                           (float*)r, scratch);
     else if (dtype == MVF_F64)
-        hipLaunchKernelGGL((apply_kernel<double, 2>), dim3((unsigned)cdiv(n, 256 * 2)), dim3(256), 0, st,
-                           (const double*)x4, n, (const double*)ctrl4, m, s, C, (double*)V4, (const double*)y4,
-                           (const double*)P, (double*)r, stats);
+        hipLaunchKernelGGL((apply_kernel<double, 2>), dim3((unsigned)nblocks), dim3(256), 0, st, (const double*)x4, n,
+                           (const double*)ctrl4, m, s, C, (double*)V4, (const double*)y4, (const double*)P, (double*)r,
+                           scratch);
     else
         return set_error("mvf_apply: bad dtype %d", (int)dtype);
     MVF_LAUNCH_CHECK();
+    if (y4 && P) {
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, scratch, nblocks, 1, 1, stats);
+        MVF_LAUNCH_CHECK();
+    }
     return 0;
+}
+
+extern "C" size_t mvf_reduce_scratch_doubles(int64_t n) {
+    // apply: one partial per 512 cells; estep_p: 5 per block (<= 2048 blocks); quadform: one per control point
+    return (size_t)std::max<int64_t>(cdiv(std::max<int64_t>(n, 1), 512) + 16, 5 * 2048 + 16);
 }
 
 namespace {
@@ -238,36 +298,40 @@ extern "C" int mvf_estep_min(const void* r, int64_t n, double sigma2, double* mi
 }
 
 extern "C" int mvf_estep_p(const void* r, int64_t n, double sigma2, double gamma, double a, int dy, double minP,
-                           double theta, double t1_zero_fill, void* P_out, double* stats, mvf_dtype dtype,
-                           void* stream) {
+                           double theta, double t1_zero_fill, void* P_out, double* stats, double* scratch,
+                           mvf_dtype dtype, void* stream) {
     MVF_REQUIRE(n >= 0 && sigma2 > 0.0 && gamma > 0.0 && gamma < 1.0 && a > 0.0 && dy >= 1,
                 "mvf_estep_p: bad parameters (sigma2=%g gamma=%g a=%g dy=%d)", sigma2, gamma, a, dy);
     if (n == 0) return 0;
-    MVF_REQUIRE(r && P_out && stats, "mvf_estep_p: null pointer");
+    MVF_REQUIRE(r && P_out && stats && scratch, "mvf_estep_p: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const double inv2s2 = 1.0 / (2.0 * sigma2);
     const double t2 = std::pow(2.0 * M_PI * sigma2, dy / 2.0) * (1.0 - gamma) / (gamma * a);
     int nb = (int)std::min<int64_t>(ESTEP_MAX_BLOCKS, std::max<int64_t>(1, cdiv(n, 256 * 4)));
     if (dtype == MVF_F32)
         hipLaunchKernelGGL(estep_p_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)r, n, inv2s2, t2, minP,
-                           theta, t1_zero_fill, (float*)P_out, stats);
+                           theta, t1_zero_fill, (float*)P_out, scratch);
     else if (dtype == MVF_F64)
         hipLaunchKernelGGL(estep_p_kernel<double>, dim3(nb), dim3(256), 0, st, (const double*)r, n, inv2s2, t2, minP,
-                           theta, t1_zero_fill, (double*)P_out, stats);
+                           theta, t1_zero_fill, (double*)P_out, scratch);
     else
         return set_error("mvf_estep_p: bad dtype %d", (int)dtype);
+    MVF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, scratch, (int64_t)nb, 5, 5, stats);
     MVF_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int mvf_quadform(const double* K, const double* C, int64_t m, int nrhs, double* out, void* stream) {
+extern "C" int mvf_quadform(const double* K, const double* C, int64_t m, int nrhs, double* out, double* scratch,
+                            void* stream) {
     MVF_REQUIRE(m >= 0 && nrhs >= 1, "mvf_quadform: bad shape");
-    MVF_REQUIRE(out, "mvf_quadform: null out");
+    MVF_REQUIRE(out && (m == 0 || scratch), "mvf_quadform: null out / scratch");
     hipStream_t st = (hipStream_t)stream;
     MVF_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(double), st));
     if (m == 0) return 0;
     MVF_REQUIRE(K && C, "mvf_quadform: null pointer");
-    hipLaunchKernelGGL(quadform_kernel, dim3((unsigned)m), dim3(256), 0, st, K, C, m, nrhs, out);
+    hipLaunchKernelGGL(quadform_kernel, dim3((unsigned)m), dim3(256), 0, st, K, C, m, nrhs, scratch);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, scratch, m, 1, 1, out);
     MVF_LAUNCH_CHECK();
     return 0;
 }

@@ -36,6 +36,7 @@ class HipKernels:
         self._solve_ws = None
         self._mn_ws = None
         self._mins = torch.empty(_lib.MVF_ESTEP_MIN_DOUBLES, dtype=torch.float64, device=self.device)
+        self._scratch = None  # per-workgroup partials of the deterministic reductions (apply / estep_p / quadform)
         # optional per-launch timing of the dominant (Gram MFMA) kernel: list of (start, end) torch events recorded
         # on the launch stream; bench.py sets this to [] to enable it
         self.gram_events = None
@@ -63,6 +64,12 @@ class HipKernels:
         buf = np.zeros((a.shape[0], 4), dtype=np.float32 if self.tdtype == torch.float32 else np.float64)
         buf[:, : a.shape[1]] = a
         return torch.from_numpy(buf).to(self.device)
+
+    def _red(self, n):
+        need = int(self.lib.mvf_reduce_scratch_doubles(int(n)))
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.float64, device=self.device)
+        return self._scratch.data_ptr()
 
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.tdtype, device=self.device)
@@ -95,7 +102,7 @@ class HipKernels:
         V4 = self.empty(n, 4)
         r = self.empty(n) if y4 is not None else None
         _lib.check(self.lib.mvf_apply(_ptr(x4), n, _ptr(ctrl4), m, float(beta), _ptr(C), _ptr(V4), _ptr(y4), _ptr(P),
-                                      _ptr(r), _ptr(stats), self.cdtype, self._stream()), "mvf_apply")
+                                      _ptr(r), _ptr(stats), self._red(n), self.cdtype, self._stream()), "mvf_apply")
         return V4, r
 
     def estep_min(self, r, sigma2):
@@ -107,7 +114,7 @@ class HipKernels:
     def estep_p(self, r, sigma2, gamma, a, dy, minP, theta, zero_fill, P_out, stats):
         _lib.check(self.lib.mvf_estep_p(_ptr(r), r.shape[0], float(sigma2), float(gamma), float(a), int(dy),
                                         float(minP), float(theta), float(zero_fill), _ptr(P_out), _ptr(stats),
-                                        self.cdtype, self._stream()), "mvf_estep_p")
+                                        self._red(r.shape[0]), self.cdtype, self._stream()), "mvf_estep_p")
 
     def ublk_bytes(self, n, m):
         return int(self.lib.mvf_ublk_bytes(n, m, self.cdtype))
@@ -196,8 +203,15 @@ class HipKernels:
         return torch.empty(int(self.lib.mvf_solve_minnorm_basis_bytes(m)) // 8, dtype=torch.float64, device=self.device)
 
     def quadform(self, K, C, out):
-        _lib.check(self.lib.mvf_quadform(_ptr(K), _ptr(C), K.shape[0], C.shape[1], _ptr(out), self._stream()),
-                   "mvf_quadform")
+        _lib.check(self.lib.mvf_quadform(_ptr(K), _ptr(C), K.shape[0], C.shape[1], _ptr(out), self._red(K.shape[0]),
+                                         self._stream()), "mvf_quadform")
+
+    def sym_pack(self, G, tri):
+        """Packed upper triangle of the symmetric G (what the multi-GPU host all-reduces)."""
+        _lib.check(self.lib.mvf_sym_pack(_ptr(G), G.shape[0], _ptr(tri), self._stream()), "mvf_sym_pack")
+
+    def sym_unpack(self, tri, G):
+        _lib.check(self.lib.mvf_sym_unpack(_ptr(tri), G.shape[0], _ptr(G), self._stream()), "mvf_sym_unpack")
 
     @staticmethod
     def _affine_buf(affine):

@@ -27,9 +27,10 @@ SIGNATURES = {
     "mvf_device_count": (_i, [C.POINTER(C.c_int)]),
     "mvf_con_k": (_i, [_p, _i64, _p, _i64, _i, _d, _p, _i, _p]),
     "mvf_con_k_d": (_i, [_p, _i64, _p, _i64, _i, _d, _p, _p, _i, _p]),
-    "mvf_apply": (_i, [_p, _i64, _p, _i64, _d, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "mvf_reduce_scratch_doubles": (_sz, [_i64]),
+    "mvf_apply": (_i, [_p, _i64, _p, _i64, _d, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "mvf_estep_min": (_i, [_p, _i64, _d, _p, _i, _p]),
-    "mvf_estep_p": (_i, [_p, _i64, _d, _d, _d, _i, _d, _d, _d, _p, _p, _i, _p]),
+    "mvf_estep_p": (_i, [_p, _i64, _d, _d, _d, _i, _d, _d, _d, _p, _p, _p, _i, _p]),
     "mvf_set_gram_mode": (_i, [_i]),
     "mvf_gram_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "mvf_gram": (_i, [_p, _p, _p, _i64, _p, _i64, _d, _p, _p, _p, _sz, _i, _p]),
@@ -42,7 +43,9 @@ SIGNATURES = {
     "mvf_solve_minnorm_workspace_bytes": (_sz, [_i64, _i]),
     "mvf_solve_minnorm": (_i, [_p, _p, _d, _d, _d, _p, _i64, _i, _p, _p, _p, _i, _i, _p, _i, _p, _sz, _p]),
     "mvf_solve_minnorm_basis_bytes": (_sz, [_i64]),
-    "mvf_quadform": (_i, [_p, _p, _i64, _i, _p, _p]),
+    "mvf_quadform": (_i, [_p, _p, _i64, _i, _p, _p, _p]),
+    "mvf_sym_pack": (_i, [_p, _i64, _p, _p]),
+    "mvf_sym_unpack": (_i, [_p, _i64, _p, _p]),
     "mvf_eval": (_i, [_p, _i64, _p, _i64, _d, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "mvf_eval_affine": (_i, [_p, _i64, _p, _i64, _d, _p, C.POINTER(C.c_double), _i, _p, _p, _p, _p, _p, _p, _p, _p, _i,
                              _p]),

@@ -191,7 +191,7 @@ class SparseVFCEngine:
     """
 
     def __init__(self, X, Y, ctrl, beta, *, dtype=None, device=None, distributed=False, group=None, n_total=None,
-                 kernels=None, cache_u="auto"):
+                 kernels=None, cache_u="auto", shard_sizes=None):
         dtype = dtype or _DEFAULT_DTYPE
         X = np.asarray(X, dtype=np.float64)
         Y = np.asarray(Y, dtype=np.float64)
@@ -212,6 +212,12 @@ class SparseVFCEngine:
         self.rank, self.world = _dist_info(distributed, group)
         self.n_local = len(X)
         self.n_total = int(n_total) if n_total is not None else self.n_local
+        # rows per rank (block shards by default; the caller states them when it brings its own uneven shards)
+        self.shard_sizes = [int(v) for v in shard_sizes] if shard_sizes is not None else \
+            [hi - lo for lo, hi in (shard_bounds(self.n_total, r, self.world) for r in range(self.world))]
+        if len(self.shard_sizes) != self.world or self.shard_sizes[self.rank] != self.n_local or \
+                sum(self.shard_sizes) != self.n_total:
+            raise ValueError("shard sizes do not match the rows this rank holds / the global cell count")
         self.M = len(ctrl)
         self.beta = float(beta)
         self.ctrl = ctrl
@@ -229,12 +235,16 @@ class SparseVFCEngine:
         cc[:, : self.D] = ctrl - self.center[None, :]
         ctrl64 = torch.from_numpy(cc).to(k.device)
         self.K = k.con_k(ctrl64, ctrl64, self.beta, dtype="float64")
-        # one contiguous float64 buffer for the all-reduce: [G (M*M) | R_g (M*3) per column group | stats (4)]
+        # one contiguous float64 buffer for THE all-reduce of an EM step: [packed upper triangle of G (M (M + 1) / 2;
+        # only when there is more than one rank) | R_g (M * 3) per column group | stats (5)]
         ng = self.ng
-        self.red = k.zeros(M * M + 3 * M * ng + 4, dtype=f64)
-        self.G = self.red[: M * M].view(M, M)
-        self.R = [self.red[M * M + 3 * M * g : M * M + 3 * M * (g + 1)].view(M, 3) for g in range(ng)]
-        self.st = self.red[M * M + 3 * M * ng :]
+        self.G = k.zeros(M, M, dtype=f64)
+        ntri = M * (M + 1) // 2 if self.world > 1 else 0
+        self.red = k.zeros(ntri + 3 * M * ng + 5, dtype=f64)
+        self.tri = self.red[:ntri]
+        self.R = [self.red[ntri + 3 * M * g : ntri + 3 * M * (g + 1)].view(M, 3) for g in range(ng)]
+        self.st = self.red[ntri + 3 * M * ng :]
+        self.comm_events = None  # bench.py: list of (start, end) events around the collectives
         self.C = [k.zeros(M, 3, dtype=f64) for _ in range(ng)]
         self.C_new = [k.zeros(M, 3, dtype=f64) for _ in range(ng)]
         self.quad = k.zeros(ng, dtype=f64)
@@ -282,7 +292,14 @@ class SparseVFCEngine:
         if self.world > 1:
             import torch.distributed as dist
 
+            ev = None
+            if self.comm_events is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MIN, group=self.group)
+            if ev is not None:
+                ev[1].record()
+                self.comm_events.append(ev + (t.numel() * t.element_size(),))
         return t
 
     # ------------------------------------------------------------------ EM
@@ -312,28 +329,45 @@ class SparseVFCEngine:
             else:
                 self.r += rg
 
-    def em_step(self, *, a=5.0, lambda_=3.0, minP=1e-5, theta=0.75):
-        """One EM iteration (Appendix A step 5 a-e).  Returns (E, tecr)."""
+    def _estep_and_assemble(self, a, minP, theta, zero_fill):
+        """E-step with the given fill for underflowed t1, M-step assembly (MFMA Gram + rhs), energy regulariser with
+        the OLD coefficients, and THE collective of the step: one all-reduce of [tri(G) | R | stats]."""
         k = self.k
-        # ---- E-step: global min-non-zero rule, then posterior + statistics
-        mins = k.estep_min(self.r, self.sigma2)
-        m2 = torch.stack([mins[0], -mins[1]])
-        self._all_reduce(m2, "min")
-        mh = m2.cpu()
-        zero_fill = float(mh[0]) if (float(mh[1]) < 0 and math.isfinite(float(mh[0]))) else 0.0
         self.st.zero_()
         k.estep_p(self.r, self.sigma2, self.gamma, a, self.Dy, minP, theta, zero_fill, self.P, self.st)
-        # ---- M-step assembly (MFMA) + energy regulariser with the OLD coefficients
         k.gram(self.x4, self.P, self.y4[0], self.ctrl4, self.beta, self.G, self.R[0])
         for g in range(1, self.ng):
             k.gram(self.x4, self.P, self.y4[g], self.ctrl4, self.beta, self.G, self.R[g], rhs_only=True)
         for g in range(self.ng):
             k.quadform(self.K, self.C[g], self.quad[g : g + 1])
-        self._all_reduce(self.red)  # the one big collective per EM step: [G | R | stats]
-        # ---- coefficient solve
-        self._solve_all(lambda_ * self.sigma2)
-        host = torch.cat([self.st, self.quad.sum().reshape(1)]).cpu()
-        s_pr, s_p, s_pf, s_cnt, quad = (float(host[i]) for i in range(5))
+        if self.world > 1:
+            k.sym_pack(self.G, self.tri)
+            self._all_reduce(self.red)
+            k.sym_unpack(self.tri, self.G)
+
+    def em_step(self, *, a=5.0, lambda_=3.0, minP=1e-5, theta=0.75):
+        """One EM iteration (Appendix A step 5 a-e).  Returns (E, tecr).
+
+        Host round trips: one after the solve (pivots / statistics / energy - every control-flow decision is taken
+        from all-reduced or replicated deterministic values, so all ranks decide alike) and one for sigma^2; the
+        minimum-norm solve adds its own (one per Jacobi sweep).  Collectives: [tri(G) | R | stats] and the scalar
+        sum P r.  dynamo's rule ``t1[t1 == 0] = min(t1[t1 != 0])`` only matters when exp(-r / 2 sigma^2) underflows for
+        some cell: the E-step runs with fill 0 first and counts those cells; a non-zero (all-reduced) count - rare:
+        gross outliers at a small sigma^2 - repeats the step's first half through the two-phase global-min path."""
+        k = self.k
+        self._estep_and_assemble(a, minP, theta, 0.0)
+        ls2 = lambda_ * self.sigma2
+        host = self._solve_all(ls2)
+        if host[4] > 0:
+            mins = k.estep_min(self.r, self.sigma2)
+            m2 = torch.stack([mins[0], -mins[1]])
+            self._all_reduce(m2, "min")
+            mh = m2.cpu()
+            zero_fill = float(mh[0]) if math.isfinite(float(mh[0])) else 0.0
+            self._estep_and_assemble(a, minP, theta, zero_fill)
+            host = self._solve_all(ls2)
+        s_pr, s_p, s_pf, s_cnt = (float(host[i]) for i in range(4))
+        quad = float(sum(host[5:]))
         E_old = self.E
         E = s_pr / (2 * self.sigma2) + s_p * math.log(self.sigma2) * self.Dy / 2 + lambda_ / 2 * quad
         self.tecr = abs((E - E_old) / E)
@@ -364,19 +398,25 @@ class SparseVFCEngine:
         for j, g in enumerate(gs):
             self.C_new[g].copy_(Ccat[:, 3 * j : 3 * j + 3])
 
+    def _host_stats(self, *extra):
+        """ONE device -> host copy: [extra ... | stats (5) | quad per column group] as float64."""
+        h = torch.cat([t.to(torch.float64).reshape(-1) for t in extra] + [self.st, self.quad]).cpu()
+        return h
+
     def _solve_all(self, ls2):
-        """C_new = lstsq(G + ls2 K, R) for every column group, with the semantics `self.lstsq_method` names."""
+        """C_new = lstsq(G + ls2 K, R) for every column group, with the semantics `self.lstsq_method` names.
+        Returns the host copy of [stats (5) | quad per group] (read in the same round trip as the solve's status)."""
         k = self.k
         batches = self._rhs_batches()
         if self.lstsq_method == "cholesky":
             while True:
-                fail = 0
                 for gs in batches:
                     self._solve_batch(gs, lambda R, C: k.solve(self.G, self.K, ls2, self.jitter, R, C, self.info))
-                    fail = max(fail, int(self.info.cpu()[0]))
+                h = self._host_stats(self.info)
+                fail = int(h[0])
                 if fail == 0:
                     self.solver_stats["cholesky"] += 1
-                    return
+                    return h[1:]
                 self.solve_retries += 1
                 self.jitter = max(self.jitter * 10.0, self.jitter_first)
                 if self.jitter > self.jitter_max:
@@ -384,18 +424,17 @@ class SparseVFCEngine:
                         f"coefficient solve failed: non-positive pivot at {fail - 1} even with jitter "
                         f"{self.jitter:g}; the system is not numerically PSD (NaN/Inf in the inputs?)")
         if not self.rank_deficient:
-            # un-regularised Cholesky; its pivots certify (or refute) full numerical rank
-            self._solve_batch(batches[0], lambda R, C: k.solve(self.G, self.K, ls2, 0.0, R, C, self.info, self.pivots))
-            h = torch.cat([self.info.to(torch.float64), self.pivots]).cpu()
-            ok = int(h[0]) == 0 and float(h[1]) > self.pivot_ratio * float(h[2])
-            if ok:
-                for gs in batches[1:]:
-                    self._solve_batch(gs, lambda R, C: k.solve(self.G, self.K, ls2, 0.0, R, C, self.info))
+            # un-regularised Cholesky for every column group; its pivots certify (or refute) full numerical rank
+            for i, gs in enumerate(batches):
+                self._solve_batch(gs, lambda R, C: k.solve(self.G, self.K, ls2, 0.0, R, C, self.info,
+                                                           self.pivots if i == 0 else None))
+            h = self._host_stats(self.info, self.pivots)
+            if int(h[0]) == 0 and float(h[1]) > self.pivot_ratio * float(h[2]):
                 self.solver_stats["cholesky"] += 1
-                return
+                return h[3:]
             self.rank_deficient = True
         # truncated minimum-norm solve (gelsd cut-off eps * max|lambda|); the shift only has to make the Cholesky
-        # factorisation inside the eigensolver exist, it is subtracted from the eigenvalues again
+        # factorisation inside the eigensolver exist, it is subtracted from the eigenvalues again.
         # warm start: the previous EM iteration's eigenvectors pre-diagonalise this iteration's matrix
         if self.basis is None and hasattr(k, "minnorm_basis"):
             self.basis = k.minnorm_basis(self.M)
@@ -403,7 +442,8 @@ class SparseVFCEngine:
             self._solve_batch(batches[0], lambda R, C: k.solve_minnorm(self.G, self.K, ls2, self.mn_shift, R, C,
                                                                        self.info, self.einfo, basis=self.basis,
                                                                        warm=self.basis_valid))
-            if int(self.info.cpu()[0]) == 0:
+            h = self._host_stats(self.info, self.einfo)
+            if int(h[0]) == 0:
                 self.basis_valid = self.basis is not None and self.warm_start
                 break
             self.basis_valid = False
@@ -414,10 +454,10 @@ class SparseVFCEngine:
         for gs in batches[1:]:
             self._solve_batch(gs, lambda R, C: k.solve_minnorm(self.G, self.K, ls2, self.mn_shift, R, C, self.info,
                                                                self.einfo, reuse=True))
-        e = self.einfo.cpu()
         self.solver_stats["minnorm"] += 1
-        self.solver_stats["sweeps"].append(float(e[0]))
-        self.solver_stats["rank"].append(int(e[1]))
+        self.solver_stats["sweeps"].append(float(h[1]))
+        self.solver_stats["rank"].append(int(h[2]))
+        return h[1 + 12:]
 
     def fit(self, *, a=5, gamma=0.9, lambda_=3, minP=1e-5, MaxIter=500, theta=0.75, ecr=1e-5, lstsq_method="scipy"):
         self.lstsq_method = _check_lstsq_method(lstsq_method)
@@ -437,25 +477,34 @@ class SparseVFCEngine:
         cols = [self.k.apply(p4, self.ctrl4, self.beta, self.C[g])[0][:, :3] for g in range(self.ng)]
         return torch.cat(cols, dim=1)[:, : self.Dy].to(torch.float64).cpu().numpy()
 
-    def _gather_rows(self, t):
-        """Concatenate per-rank row blocks (sizes from shard_bounds) on every rank."""
+    def _gather_rows(self, t, root_only):
+        """Concatenate the per-rank row blocks: on every rank, or (root_only) on rank 0 - the others keep their own."""
         if self.world == 1:
             return t
         import torch.distributed as dist
 
-        sizes = [shard_bounds(self.n_total, r, self.world) for r in range(self.world)]
-        mx = max(hi - lo for lo, hi in sizes)
+        mx = max(self.shard_sizes)
         pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         pad[: t.shape[0]] = t
-        outs = [torch.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather(outs, pad, group=self.group)
-        return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(outs, sizes)], dim=0)
+        if root_only:
+            outs = [torch.empty_like(pad) for _ in range(self.world)] if self.rank == 0 else None
+            dst = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            dist.gather(pad, outs, dst=dst, group=self.group)
+            if self.rank != 0:
+                return t
+        else:
+            outs = [torch.empty_like(pad) for _ in range(self.world)]
+            dist.all_gather(outs, pad, group=self.group)
+        return torch.cat([o[:sz] for o, sz in zip(outs, self.shard_sizes)], dim=0)
 
-    def results(self):
-        """(V (N, Dy), P (N, 1), C (M, Dy)) as host float64, gathered over ranks."""
+    def results(self, gather="root"):
+        """(V (N, Dy), P (N, 1), C (M, Dy)) as host float64.  Multi-rank: ``gather="root"`` (default) collects the
+        cell rows on rank 0 only - the other ranks get their own rows back; ``"all"`` gives every rank all rows."""
+        if gather not in ("root", "all"):
+            raise ValueError("gather must be 'root' or 'all'")
         Vloc = torch.cat([v[:, :3] for v in self.V4], dim=1)[:, : self.Dy].contiguous()
-        V = self._gather_rows(Vloc).to(torch.float64).cpu().numpy()
-        P = self._gather_rows(self.P[:, None].contiguous()).to(torch.float64).cpu().numpy()
+        V = self._gather_rows(Vloc, gather == "root").to(torch.float64).cpu().numpy()
+        P = self._gather_rows(self.P[:, None].contiguous(), gather == "root").to(torch.float64).cpu().numpy()
         C = torch.cat(self.C, dim=1)[:, : self.Dy].cpu().numpy().copy()
         return V, P, C
 
@@ -551,12 +600,18 @@ def SparseVFC(
     device=None,
     distributed=False,
     group=None,
+    sharded_input=False,
+    gather="root",
     _kernels=None,
 ) -> dict:
     """Drop-in for ``dynamo.vectorfield.scVectorField.SparseVFC`` (defaults identical).
 
     Extra keyword-only arguments: ``dtype`` ("float64" parity mode | "float32" fast mode), ``device``,
-    ``distributed``/``group`` (every rank passes the same full X, Y; cells are block-sharded across ranks).
+    ``distributed``/``group`` (one process per GPU; cells are sharded across ranks, rank 0 alone does the host
+    preprocessing and broadcasts the control points), ``sharded_input`` (False: every rank passes the same full X, Y and
+    takes a block of it; True: every rank passes only ITS rows - ``Grid`` is still the same everywhere) and ``gather``
+    ("root": the per-cell outputs ``V``, ``P``, ``VFCIndex`` are complete on rank 0 only, other ranks keep their own rows;
+    "all": complete on every rank).
     ``lstsq_method``: "scipy" (what Spateo passes) = minimum-norm solve with gelsd's eps * s_max cut-off on the
     device (Cholesky while the pivots certify full numerical rank, else the hand-written symmetric eigensolver);
     "drouin" maps to the same solve with a warning; "cholesky" is a non-reference fast mode.  The coefficients ``C`` are
@@ -570,22 +625,69 @@ def SparseVFC(
     Y = np.asarray(Y, dtype=float)
     if X.ndim != 2 or Y.ndim != 2 or len(X) != len(Y):
         raise ValueError("X and Y must be 2-D arrays with the same number of rows")
+    if gather not in ("root", "all"):
+        raise ValueError("gather must be 'root' or 'all'")
     X_ori, Y_ori = X.copy(), Y.copy()
-    valid_ind, Xv, Yv, idx, ctrl_pts, beta = sparsevfc_preprocess(
-        X, Y, M=M, beta=beta, velocity_based_sampling=velocity_based_sampling, seed=seed
-    )
-    N = len(Xv)
+    rank, world = _dist_info(distributed, group)
+    shard_sizes = None
+    if world == 1:
+        valid_ind, Xv, Yv, idx, ctrl_pts, beta = sparsevfc_preprocess(
+            X, Y, M=M, beta=beta, velocity_based_sampling=velocity_based_sampling, seed=seed
+        )
+        N, lo, hi = len(Xv), 0, len(Xv)
+    else:
+        # Multi-rank: the O(N log N) host preprocessing (unique rows, control-point sampling, kNN bandwidth) runs on
+        # rank 0 ONLY and its small result (ctrl_idx, control points, beta) is broadcast.  sharded_input=False: every
+        # rank passed the same full X, Y and takes its block of the finite rows.  sharded_input=True: every rank passed
+        # ITS OWN rows (any sizes); the finite rows are gathered on rank 0 for the control-point selection only.
+        import torch.distributed as dist
+
+        root = dist.get_global_rank(group, 0) if group is not None else 0
+        valid_loc = np.where(np.isfinite(Y.sum(1)))[0]
+        if sharded_input:
+            lens = [None] * world
+            dist.all_gather_object(lens, (len(X), len(valid_loc)), group=group)
+            offset = sum(n_in for n_in, _ in lens[:rank])
+            shard_sizes = [n_v for _, n_v in lens]
+            vparts = [None] * world
+            dist.all_gather_object(vparts, valid_loc + offset, group=group)  # global row numbers of the finite rows
+            valid_ind = np.concatenate(vparts)
+            Xloc, Yloc = X[valid_loc], Y[valid_loc]
+            parts = [None] * world if rank == 0 else None
+            dist.gather_object((Xloc, Yloc), parts, dst=root, group=group)
+            if rank == 0:
+                Xall, Yall = np.concatenate([p_[0] for p_ in parts]), np.concatenate([p_[1] for p_ in parts])
+            N = sum(shard_sizes)
+        else:
+            valid_ind = valid_loc
+            Xall, Yall = X[valid_loc], Y[valid_loc]
+            N = len(valid_loc)
+            lo, hi = shard_bounds(N, rank, world)
+            Xloc, Yloc = Xall[lo:hi], Yall[lo:hi]
+        if N == 0:
+            raise ValueError("SparseVFC: no row of Y is finite - nothing to fit.")
+        box = [None]
+        if rank == 0:
+            try:
+                _, _, _, idx0, ctrl0, beta0 = sparsevfc_preprocess(Xall, Yall, M=M, beta=beta,
+                                                                   velocity_based_sampling=velocity_based_sampling, seed=seed)
+                box = [(idx0, ctrl0, beta0)]
+            except Exception as exc:  # every rank must leave the collective: ship the error
+                box = [exc]
+        dist.broadcast_object_list(box, src=root, group=group)
+        if isinstance(box[0], Exception):
+            raise box[0]
+        idx, ctrl_pts, beta = box[0]
+        Xv, Yv, lo, hi = Xloc, Yloc, 0, len(Xloc)
     if len(ctrl_pts) < 2:
         # reference behaviour: con_K(ctrl, ctrl) of a single control point is flattened to 1-D (gaussian_process.py:23-24)
         # and the energy term C.T.dot(K).dot(C) then fails with a ValueError
         raise ValueError("SparseVFC needs at least 2 control points (shapes (3,) and (1,3) not aligned in the reference)")
-    rank, world = _dist_info(distributed, group)
-    lo, hi = shard_bounds(N, rank, world)
     eng = SparseVFCEngine(Xv[lo:hi], Yv[lo:hi], ctrl_pts, beta, dtype=dtype, device=device, distributed=distributed,
-                          group=group, n_total=N, kernels=_kernels)
+                          group=group, n_total=N, kernels=_kernels, shard_sizes=shard_sizes)
     tecr_vec, E_vec = eng.fit(a=a, gamma=gamma, lambda_=lambda_, minP=minP, MaxIter=MaxIter, theta=theta, ecr=ecr,
                               lstsq_method=lstsq_method)
-    V, P, C = eng.results()
+    V, P, C = eng.results(gather=gather)
     grid_V = eng.predict(Grid) if Grid is not None else None
     i = eng.iteration
     return {

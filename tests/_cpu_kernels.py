@@ -74,12 +74,13 @@ class CpuKernels:
     def estep_p(self, r, sigma2, gamma, a, dy, minP, theta, zero_fill, P_out, stats):
         rr = _np(r)
         t1 = np.exp(-rr / (2 * sigma2))
+        nzero = float((t1 == 0).sum())
         t1[t1 == 0] = zero_fill
         t2 = (2 * np.pi * sigma2) ** (dy / 2) * (1 - gamma) / (gamma * a)
         p = t1 / (t1 + t2)
         pf = np.maximum(p, minP)
         P_out.copy_(torch.from_numpy(pf))
-        stats += torch.tensor([p @ rr, p.sum(), pf.sum(), float((pf > theta).sum())], dtype=torch.float64)
+        stats += torch.tensor([p @ rr, p.sum(), pf.sum(), float((pf > theta).sum()), nzero], dtype=torch.float64)
 
     def gram(self, x4, P, y4, ctrl4, beta, G, R, rhs_only=False):
         X, ctrl = _np(x4)[:, :3], _np(ctrl4)[:, :3]
@@ -117,6 +118,17 @@ class CpuKernels:
         info.zero_()
         einfo[:6] = torch.tensor([1.0, keep.sum(), np.abs(w).max(), np.abs(w[keep]).min(), shift * np.trace(_np(G)) / len(w),
                                   w.min()], dtype=torch.float64)
+
+    def sym_pack(self, G, tri):
+        g = _np(G)
+        tri.copy_(torch.from_numpy(g[np.triu_indices(len(g))]))
+
+    def sym_unpack(self, tri, G):
+        m = G.shape[0]
+        g = np.zeros((m, m))
+        g[np.triu_indices(m)] = _np(tri)
+        g = g + np.triu(g, 1).T
+        G.copy_(torch.from_numpy(g))
 
     def quadform(self, K, C, out):
         c = _np(C)

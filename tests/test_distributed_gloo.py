@@ -1,5 +1,7 @@
-"""world_size-2 ``gloo`` runs of the multi-GPU path on CPU: cells block-sharded across ranks, one all-reduce of
-[G | R | stats] per EM step, the global min-non-zero rule of the E-step, gathered outputs.  The device is replaced by
+"""world_size-2 ``gloo`` runs of the multi-GPU path on CPU: cells sharded across ranks (block shards of a replicated
+input, or every rank bringing its own uneven rows), rank 0 alone preprocessing and broadcasting the control points, one
+all-reduce of [tri(G) | R | stats] per EM step, the global min-non-zero rule of the E-step, outputs gathered on rank 0
+or on every rank.  The device is replaced by
 the oracle-backed test double (tests/_cpu_kernels.py); what is under test is the sharding / collective protocol."""
 import os
 import socket
@@ -20,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case, out_dir):
+def _worker(rank, world, port, case, out_dir, mode="all"):
     for p in (ROOT, os.path.join(ROOT, "spateo-release_amd"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -45,9 +47,27 @@ def _worker(rank, world, port, case, out_dir):
 
         Grid = X[::30]
         kw = dict(M=25, lambda_=3.0, lstsq_method="scipy", MaxIter=6, seed=0)
-        got = st.SparseVFC(X, V, Grid, distributed=True, _kernels=Recording(), **kw)
+        if case == "wide":
+            V = np.column_stack([V, np.sin(X[:, 0] / 70), np.cos(X[:, 1] / 50)])  # Dy = 5: two column groups
+        calls = {"unique": 0}
+        import spateo_amd.vectorfield as vfm
+
+        orig_unique = vfm.unique_rows
+
+        def counting_unique(a):
+            calls["unique"] += 1
+            return orig_unique(a)
+
+        vfm.unique_rows = counting_unique
+        if mode == "sharded":  # every rank brings ITS OWN rows: 401 + 200, not the block split
+            lo, hi = (0, 401) if rank == 0 else (401, 601)
+            got = st.SparseVFC(X[lo:hi], V[lo:hi], Grid, distributed=True, sharded_input=True, gather="root",
+                               _kernels=Recording(), **kw)
+        else:
+            got = st.SparseVFC(X, V, Grid, distributed=True, gather=mode, _kernels=Recording(), **kw)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), V=got["V"], P=got["P"], C=got["C"], grid_V=got["grid_V"],
-                 sigma2=got["sigma2"], iteration=got["iteration"], E=got["E_traj"], fills=np.array(Recording.fills))
+                 sigma2=got["sigma2"], iteration=got["iteration"], E=got["E_traj"], fills=np.array(Recording.fills),
+                 unique_calls=calls["unique"], valid_ind=got["valid_ind"], vfc=got["VFCIndex"])
     finally:
         dist.destroy_process_group()
 
@@ -80,6 +100,37 @@ def test_two_rank_gloo_matches_single_process(tmp_path, case):
     np.testing.assert_allclose(r0["P"], ref["P"], rtol=1e-6, atol=1e-12)
     np.testing.assert_allclose(r0["E"], ref["E_traj"], rtol=1e-8)
     np.testing.assert_allclose(float(r0["sigma2"]), ref["sigma2"], rtol=1e-8)
+    # the O(N log N) host preprocessing ran on rank 0 only
+    assert int(r0["unique_calls"]) == 1 and int(r1["unique_calls"]) == 0
+
+
+@pytest.mark.parametrize("mode,case", [("root", "plain"), ("sharded", "plain"), ("sharded", "wide"), ("root", "wide")])
+def test_two_rank_gloo_root_gather_and_own_shards(tmp_path, mode, case):
+    """gather="root" (default): rank 0 holds the complete per-cell outputs, rank 1 its own rows; sharded_input=True:
+    every rank passes only its rows (uneven: 401 + 200) - same fit as the single-process oracle either way."""
+    sys.path.insert(0, HERE)
+    from oracle import sparsevfc_oracle as svo
+    from spateo_amd._synthetic import make_config
+
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, case, str(tmp_path), mode), nprocs=2, join=True)
+    X, V, _ = make_config("C2", N=601)
+    if case == "wide":
+        V = np.column_stack([V, np.sin(X[:, 0] / 70), np.cos(X[:, 1] / 50)])
+    ref = svo.SparseVFC(X, V, X[::30], M=25, lambda_=3.0, lstsq_method="scipy", MaxIter=6, seed=0)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    n1 = 200 if mode == "sharded" else 300  # rank 1's rows: its own 200, or the second block of 601
+    assert r0["V"].shape == ref["V"].shape and r1["V"].shape == (n1, V.shape[1]) and r1["P"].shape == (n1, 1)
+    scale = np.abs(ref["V"]).max()
+    assert np.abs(r0["V"] - ref["V"]).max() / scale < 1e-8
+    np.testing.assert_array_equal(r1["V"], r0["V"][-n1:])  # rank 1 kept exactly its slice of the gathered result
+    np.testing.assert_array_equal(r1["P"], r0["P"][-n1:])
+    for k in ("C", "grid_V", "sigma2", "E"):
+        np.testing.assert_array_equal(r0[k], r1[k])  # replicated quantities are identical everywhere
+    assert np.abs(r0["grid_V"] - ref["grid_V"]).max() / scale < 1e-8
+    np.testing.assert_array_equal(r0["valid_ind"], ref["valid_ind"])
+    np.testing.assert_array_equal(r0["vfc"], ref["VFCIndex"])
+    assert int(r0["unique_calls"]) == 1 and int(r1["unique_calls"]) == 0
 
 
 def test_distributed_flag_requires_process_group():
