@@ -205,9 +205,10 @@ def main():
         def timed_solve(ls2):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            inner(ls2)
+            host = inner(ls2)
             e1.record()
             solve_events.append((e0, e1))
+            return host
 
         eng._solve_all = timed_solve
         for _ in range(warmup):

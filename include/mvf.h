@@ -79,16 +79,16 @@ int mvf_apply(const void* x4, int64_t n, const void* ctrl4, int64_t m, double be
  *                   `mins` must hold MVF_ESTEP_MIN_DOUBLES float64 (the tail is block-partial scratch)
  *   mvf_estep_p   : P_out (dtype, n) = max(P, minP) with P = t1/(t1+t2);  stats (float64[5], caller zeroes):
  *                   [0] += sum P_unfloored * r, [1] += sum P_unfloored, [2] += sum P_floored, [3] += #(P_floored > theta),
- *                   [4] += #(t1 == 0), the cells that took t1_zero_fill.  The host runs mvf_estep_p FIRST with
- *                   t1_zero_fill = 0 and only if the (all-reduced) [4] is non-zero - exp(-r / 2 sigma2) underflowed
- *                   for some cell: gross outliers at a small sigma2, rare - repeats the E-step through mvf_estep_min;
- *                   the common path then needs neither the MIN collective nor a host round trip before the Gram.
+ *                   [4] += #(t1 == 0), the cells that took the fill.  The fill is t1_zero_fill_dev[0] when that
+ *                   DEVICE pointer is non-NULL (mins[0] of mvf_estep_min, MIN-all-reduced across ranks by the host; +inf
+ *                   -> 0): the two phases then chain on the stream with no host round trip; else t1_zero_fill.
  *                   scratch: >= mvf_reduce_scratch_doubles(n) float64 (deterministic two-level sums).
  * All arithmetic in float64 regardless of dtype. */
 #define MVF_ESTEP_MIN_DOUBLES 4098
 int mvf_estep_min(const void* r, int64_t n, double sigma2, double* mins, mvf_dtype dtype, void* stream);
 int mvf_estep_p(const void* r, int64_t n, double sigma2, double gamma, double a, int dy, double minP, double theta,
-                double t1_zero_fill, void* P_out, double* stats, double* scratch, mvf_dtype dtype, void* stream);
+                double t1_zero_fill, const double* t1_zero_fill_dev, void* P_out, double* stats, double* scratch,
+                mvf_dtype dtype, void* stream);
 
 /* ---- M-step assembly:  G = U^T diag(P) U (m x m),  R = U^T diag(P) Y (m x 3)  --------------------------------
  * Replaces: `UP = U.T * repmat(P.T, M, 1); lhs = UP.dot(U) ...; rhs = UP.dot(Y)` of SparseVFC (App. A 5c; same

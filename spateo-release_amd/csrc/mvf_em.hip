@@ -147,8 +147,16 @@ __global__ __launch_bounds__(256) void estep_min_finish(const double* __restrict
 
 template <typename T>
 __global__ __launch_bounds__(256) void estep_p_kernel(const T* __restrict__ r, int64_t n, double inv2s2, double t2,
-                                                      double minP, double theta, double zero_fill,
-                                                      T* __restrict__ Pout, double* __restrict__ block_stats) {
+                                                      double minP, double theta, double zero_fill_host,
+                                                      const double* __restrict__ fill_dev, T* __restrict__ Pout,
+                                                      double* __restrict__ block_stats) {
+    // the fill for underflowed t1: a device scalar (mins[0] of mvf_estep_min, possibly MIN-all-reduced across ranks;
+    // +inf = no cell has a non-zero t1) when given - no host round trip between the two E-step phases - else the host's
+    double zero_fill = zero_fill_host;
+    if (fill_dev) {
+        const double f = *fill_dev;
+        zero_fill = (f < INFINITY) ? f : 0.0;
+    }
     double s_pr = 0.0, s_p = 0.0, s_pf = 0.0, s_cnt = 0.0, s_zero = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const double ri = (double)r[i];
@@ -298,8 +306,8 @@ extern "C" int mvf_estep_min(const void* r, int64_t n, double sigma2, double* mi
 }
 
 extern "C" int mvf_estep_p(const void* r, int64_t n, double sigma2, double gamma, double a, int dy, double minP,
-                           double theta, double t1_zero_fill, void* P_out, double* stats, double* scratch,
-                           mvf_dtype dtype, void* stream) {
+                           double theta, double t1_zero_fill, const double* t1_zero_fill_dev, void* P_out,
+                           double* stats, double* scratch, mvf_dtype dtype, void* stream) {
     MVF_REQUIRE(n >= 0 && sigma2 > 0.0 && gamma > 0.0 && gamma < 1.0 && a > 0.0 && dy >= 1,
                 "mvf_estep_p: bad parameters (sigma2=%g gamma=%g a=%g dy=%d)", sigma2, gamma, a, dy);
     if (n == 0) return 0;
@@ -310,10 +318,10 @@ extern "C" int mvf_estep_p(const void* r, int64_t n, double sigma2, double gamma
     int nb = (int)std::min<int64_t>(ESTEP_MAX_BLOCKS, std::max<int64_t>(1, cdiv(n, 256 * 4)));
     if (dtype == MVF_F32)
         hipLaunchKernelGGL(estep_p_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)r, n, inv2s2, t2, minP,
-                           theta, t1_zero_fill, (float*)P_out, scratch);
+                           theta, t1_zero_fill, t1_zero_fill_dev, (float*)P_out, scratch);
     else if (dtype == MVF_F64)
         hipLaunchKernelGGL(estep_p_kernel<double>, dim3(nb), dim3(256), 0, st, (const double*)r, n, inv2s2, t2, minP,
-                           theta, t1_zero_fill, (double*)P_out, scratch);
+                           theta, t1_zero_fill, t1_zero_fill_dev, (double*)P_out, scratch);
     else
         return set_error("mvf_estep_p: bad dtype %d", (int)dtype);
     MVF_LAUNCH_CHECK();

@@ -112,8 +112,12 @@ class HipKernels:
         return self._mins[:2]
 
     def estep_p(self, r, sigma2, gamma, a, dy, minP, theta, zero_fill, P_out, stats):
+        """zero_fill: a host float, or a device float64 tensor whose first element is the fill (estep_min's result,
+        possibly MIN-all-reduced): then the two E-step phases chain on the stream without a host round trip."""
+        fill_dev = zero_fill if torch.is_tensor(zero_fill) else None
         _lib.check(self.lib.mvf_estep_p(_ptr(r), r.shape[0], float(sigma2), float(gamma), float(a), int(dy),
-                                        float(minP), float(theta), float(zero_fill), _ptr(P_out), _ptr(stats),
+                                        float(minP), float(theta), 0.0 if fill_dev is not None else float(zero_fill),
+                                        _ptr(fill_dev), _ptr(P_out), _ptr(stats),
                                         self._red(r.shape[0]), self.cdtype, self._stream()), "mvf_estep_p")
 
     def ublk_bytes(self, n, m):

@@ -30,7 +30,7 @@ SIGNATURES = {
     "mvf_reduce_scratch_doubles": (_sz, [_i64]),
     "mvf_apply": (_i, [_p, _i64, _p, _i64, _d, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "mvf_estep_min": (_i, [_p, _i64, _d, _p, _i, _p]),
-    "mvf_estep_p": (_i, [_p, _i64, _d, _d, _d, _i, _d, _d, _d, _p, _p, _p, _i, _p]),
+    "mvf_estep_p": (_i, [_p, _i64, _d, _d, _d, _i, _d, _d, _d, _p, _p, _p, _p, _i, _p]),
     "mvf_set_gram_mode": (_i, [_i]),
     "mvf_gram_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "mvf_gram": (_i, [_p, _p, _p, _i64, _p, _i64, _d, _p, _p, _p, _sz, _i, _p]),

@@ -329,12 +329,23 @@ class SparseVFCEngine:
             else:
                 self.r += rg
 
-    def _estep_and_assemble(self, a, minP, theta, zero_fill):
-        """E-step with the given fill for underflowed t1, M-step assembly (MFMA Gram + rhs), energy regulariser with
-        the OLD coefficients, and THE collective of the step: one all-reduce of [tri(G) | R | stats]."""
+    def em_step(self, *, a=5.0, lambda_=3.0, minP=1e-5, theta=0.75):
+        """One EM iteration (Appendix A step 5 a-e).  Returns (E, tecr).
+
+        Collectives per step (multi-rank): the 8-byte MIN of the E-step's global min-non-zero rule, THE all-reduce of the
+        sufficient statistics [tri(G) | R | stats] and the 8-byte sum P r; none of them is followed by a host round
+        trip of its own.  Host round trips: one after the solve (its status / pivots, the statistics, the energy - every
+        control-flow decision is taken from all-reduced or replicated deterministic values, so all ranks decide alike)
+        and one for sigma^2; the minimum-norm solve adds its own (one per Jacobi sweep)."""
         k = self.k
+        # ---- E-step: dynamo's `t1[t1 == 0] = min(t1[t1 != 0])` needs the GLOBAL min-non-zero t1; phase 1 leaves it in
+        # device memory, phase 2 reads it from there
+        mins = k.estep_min(self.r, self.sigma2)
+        fill = mins[:1]
+        self._all_reduce(fill, "min")
         self.st.zero_()
-        k.estep_p(self.r, self.sigma2, self.gamma, a, self.Dy, minP, theta, zero_fill, self.P, self.st)
+        k.estep_p(self.r, self.sigma2, self.gamma, a, self.Dy, minP, theta, fill, self.P, self.st)
+        # ---- M-step assembly (MFMA Gram + rhs), energy regulariser with the OLD coefficients, the collective
         k.gram(self.x4, self.P, self.y4[0], self.ctrl4, self.beta, self.G, self.R[0])
         for g in range(1, self.ng):
             k.gram(self.x4, self.P, self.y4[g], self.ctrl4, self.beta, self.G, self.R[g], rhs_only=True)
@@ -344,28 +355,7 @@ class SparseVFCEngine:
             k.sym_pack(self.G, self.tri)
             self._all_reduce(self.red)
             k.sym_unpack(self.tri, self.G)
-
-    def em_step(self, *, a=5.0, lambda_=3.0, minP=1e-5, theta=0.75):
-        """One EM iteration (Appendix A step 5 a-e).  Returns (E, tecr).
-
-        Host round trips: one after the solve (pivots / statistics / energy - every control-flow decision is taken
-        from all-reduced or replicated deterministic values, so all ranks decide alike) and one for sigma^2; the
-        minimum-norm solve adds its own (one per Jacobi sweep).  Collectives: [tri(G) | R | stats] and the scalar
-        sum P r.  dynamo's rule ``t1[t1 == 0] = min(t1[t1 != 0])`` only matters when exp(-r / 2 sigma^2) underflows for
-        some cell: the E-step runs with fill 0 first and counts those cells; a non-zero (all-reduced) count - rare:
-        gross outliers at a small sigma^2 - repeats the step's first half through the two-phase global-min path."""
-        k = self.k
-        self._estep_and_assemble(a, minP, theta, 0.0)
-        ls2 = lambda_ * self.sigma2
-        host = self._solve_all(ls2)
-        if host[4] > 0:
-            mins = k.estep_min(self.r, self.sigma2)
-            m2 = torch.stack([mins[0], -mins[1]])
-            self._all_reduce(m2, "min")
-            mh = m2.cpu()
-            zero_fill = float(mh[0]) if math.isfinite(float(mh[0])) else 0.0
-            self._estep_and_assemble(a, minP, theta, zero_fill)
-            host = self._solve_all(ls2)
+        host = self._solve_all(lambda_ * self.sigma2)
         s_pr, s_p, s_pf, s_cnt = (float(host[i]) for i in range(4))
         quad = float(sum(host[5:]))
         E_old = self.E

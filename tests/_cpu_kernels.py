@@ -73,6 +73,8 @@ class CpuKernels:
 
     def estep_p(self, r, sigma2, gamma, a, dy, minP, theta, zero_fill, P_out, stats):
         rr = _np(r)
+        if torch.is_tensor(zero_fill):
+            zero_fill = float(zero_fill[0]) if np.isfinite(float(zero_fill[0])) else 0.0
         t1 = np.exp(-rr / (2 * sigma2))
         nzero = float((t1 == 0).sum())
         t1[t1 == 0] = zero_fill
