@@ -15,6 +15,6 @@ def rows(path, like=""):
 if __name__ == "__main__":
     print("| kernel | counter | launches | avg raw per launch | raw x 1024 (bytes) |")
     print("|---|---|---|---|---|")
-    for name, ctr, n, tot in rows(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")[:14]:
+    for name, ctr, n, tot in rows(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")[:40]:
         nm = name if len(name) < 70 else name[:67] + "..."
         print(f"| `{nm}` | {ctr} | {n} | {tot / n:.4g} | {tot / n * 1024:.4g} |")
