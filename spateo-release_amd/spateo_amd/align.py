@@ -50,10 +50,7 @@ def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, l
     k = _vf._make_kernels(device, dtype)
     center = ctrl.mean(0)
     x4, c4 = k.to_x4(X, center), k.to_x4(ctrl, center)
-    cc = np.zeros((m, 3))
-    cc[:, : ctrl.shape[1]] = ctrl - center
-    c64 = torch.from_numpy(cc).to(k.device)
-    Gamma = k.con_k(c64, c64, float(beta), dtype="float64")
+    Gamma = _vf._consistent_K(k, ctrl, center, float(beta))  # generated like U (see SparseVFCEngine)
     # rhs = U^T PXB = U^T diag(K_NA) Y with Y = PXB / K_NA (rows with K_NA == 0 have PXB == 0: cells without a partner)
     Y = np.divide(B, w[:, None], out=np.zeros_like(B), where=w[:, None] != 0)
     y4 = k.to_x4(Y)

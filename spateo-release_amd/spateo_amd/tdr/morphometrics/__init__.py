@@ -1,4 +1,10 @@
-from .morphofield import _morphofield_sparsevfc, morphofield_gp, morphofield_sparsevfc, morphopath
+from .morphofield import (
+    _morphofield_sparsevfc,
+    construct_genesis_states,
+    morphofield_gp,
+    morphofield_sparsevfc,
+    morphopath,
+)
 from .morphofield_dg import (
     morphofield_acceleration,
     morphofield_curl,

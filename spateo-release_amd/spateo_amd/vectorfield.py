@@ -25,6 +25,7 @@ from ._kernels import HipKernels
 __all__ = [
     "SparseVFC_many",
     "integrate_field",
+    "genesis_states",
     "GPVectorField",
     "gp_velocity",
     "con_K",
@@ -180,6 +181,14 @@ def shard_bounds(n: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _consistent_K(k, ctrl, center, beta):
+    """con_K(ctrl, ctrl) as float64, its values generated by the kernels' own kernel_value<cell dtype>."""
+    cc = np.zeros((len(ctrl), 3), dtype=np.float32 if k.tdtype == torch.float32 else np.float64)
+    cc[:, : ctrl.shape[1]] = ctrl - np.asarray(center)[None, : ctrl.shape[1]]
+    cd = torch.from_numpy(cc).to(k.device)
+    return k.con_k(cd, cd, beta, dtype=k.dtype_name).to(torch.float64)
+
+
 # =====================================================================================================================
 # the engine
 # =====================================================================================================================
@@ -230,11 +239,11 @@ class SparseVFCEngine:
         self.ctrl4 = k.to_x4(ctrl, self.center)
         f64 = torch.float64
         M = self.M
-        # K = con_K(ctrl, ctrl) always float64 (regulariser + energy)
-        cc = np.zeros((M, 3))
-        cc[:, : self.D] = ctrl - self.center[None, :]
-        ctrl64 = torch.from_numpy(cc).to(k.device)
-        self.K = k.con_k(ctrl64, ctrl64, self.beta, dtype="float64")
+        # K = con_K(ctrl, ctrl) (regulariser + energy), stored float64 but GENERATED IN THE CELL DTYPE: K must be the
+        # same function of the control points as U is of the cells.  With float32 kernel values in U and an exact float64
+        # K the null spaces of U^T P U and of lambda sigma^2 K no longer line up and the field moves by 1e-3 (M = 2000,
+        # lambda = 3); generated consistently it moves by 1.4e-5, the float32 rounding level (measured on the oracle).
+        self.K = _consistent_K(k, ctrl, self.center, self.beta)
         # one contiguous float64 buffer for THE all-reduce of an EM step: [packed upper triangle of G (M (M + 1) / 2;
         # only when there is more than one rank) | R_g (M * 3) per column group | stats (5)]
         ng = self.ng
@@ -896,19 +905,60 @@ def _default_t_end(X, V):
     return float(np.max(X.max(0) - X.min(0)) / np.percentile(V_abs, 1))
 
 
+def _hermite(tq, tk, xk, vk):
+    """Cubic Hermite interpolation of trajectories: samples xk (n, K, d) with velocities vk at uniform times tk (K,),
+    evaluated at per-trajectory times tq (n, Q) -> (n, Q, d).  O(h^4): with the fine RK4 samples this is the ODE's dense
+    output to ~1e-8."""
+    h = tk[1] - tk[0]
+    u = (tq - tk[0]) / h
+    i = np.clip(np.floor(u).astype(np.int64), 0, len(tk) - 2)
+    w = (u - i)[..., None]
+    rows = np.arange(xk.shape[0])[:, None]
+    x0, x1, v0, v1 = xk[rows, i], xk[rows, i + 1], vk[rows, i], vk[rows, i + 1]
+    h00, h10 = (1 + 2 * w) * (1 - w) ** 2, w * (1 - w) ** 2
+    h01, h11 = w * w * (3 - 2 * w), w * w * (w - 1)
+    return h00 * x0 + h10 * h * v0 + h01 * x1 + h11 * h * v1
+
+
+def _arc_length_resample(tk, xk, vk, n_out, stop_tol=1e-5):
+    """dynamo ``fate`` semantics on a finely sampled trajectory (``integrate_vf_ivp(..., sampling="arc_length")``): the
+    integration ends where every |v| component drops below 1e-5 (its terminal event), the path is cut into n_out points
+    EQUALLY SPACED IN ARC LENGTH, the times of those points come from linear interpolation along the polyline, and the
+    states are the ODE solution at those times.  Returns (t (n, n_out), x (n, n_out, d))."""
+    n, K, d = xk.shape
+    slow = np.all(np.abs(vk) < stop_tol, axis=2)
+    end = np.where(slow.any(1), slow.argmax(1), K - 1)  # first sample at rest, else the last one
+    seg = np.linalg.norm(np.diff(xk, axis=1), axis=2)
+    seg[np.arange(K - 1)[None, :] >= end[:, None]] = 0.0  # nothing moves after the terminal event
+    s = np.concatenate([np.zeros((n, 1)), np.cumsum(seg, axis=1)], axis=1)
+    L = s[:, -1]
+    sq = np.linspace(0.0, 1.0, n_out)[None, :] * L[:, None]
+    tq = np.empty((n, n_out))
+    for r in range(n):  # monotone inverse s -> t, row by row (np.interp is 1-D)
+        e = max(int(end[r]), 1)
+        tq[r] = np.interp(sq[r], s[r, : e + 1], tk[: e + 1]) if L[r] > 0 else np.linspace(tk[0], tk[e], n_out)
+    return tq, _hermite(tq, tk, xk, vk)
+
+
 def integrate_field(vf_dict, init_states, t_end=None, interpolation_num=250, direction="forward", average=False,
-                    nonrigid_only=False, substeps=4, dtype=None, device=None, max_cells_per_launch=1 << 20):
+                    nonrigid_only=False, substeps=4, dtype=None, device=None, max_cells_per_launch=1 << 16,
+                    sampling="arc_length"):
     """Integrate dx/dt = v(x) from every row of ``init_states`` on the GPU (fused RK4 kernel).
 
-    Returns ``(t, prediction)``: lists with one entry per trajectory, ``t[i]`` (n_t,), ``prediction[i]`` (n_t, d),
-    sampled at ``interpolation_num`` uniform times over [0, t_end] ("forward"), [-t_end, 0] ("backward") or both.
-    ``average``: False | "origin" (one trajectory from the mean start) | "trajectory" / True (mean over cells per time)."""
+    Returns ``(t, prediction)``: lists with one entry per trajectory, ``t[i]`` (n_t,), ``prediction[i]`` (n_t, d).
+    ``sampling="arc_length"`` (dynamo ``fate``'s default, which ``morphopath`` inherits): ``interpolation_num`` points
+    equally spaced in arc length along each path (twice as many for ``direction="both"``), every trajectory with its own
+    times; the path ends early where the field is at rest (all |v| < 1e-5).  ``"uniform_time"``: ``interpolation_num``
+    uniform times over [0, t_end] ("forward"), [-t_end, 0] ("backward") or both.
+    ``average``: False | "origin" (one trajectory from the mean start) | "trajectory" / True (mean over cells per sample)."""
     dtype = dtype or _DEFAULT_DTYPE
     X0 = np.asarray(init_states, dtype=np.float64)
     if X0.ndim == 1:
         X0 = X0[None, :]
     if direction not in ("forward", "backward", "both"):
         raise ValueError("direction must be one of 'forward', 'backward', 'both'")
+    if sampling not in ("arc_length", "uniform_time"):
+        raise ValueError("sampling must be 'arc_length' or 'uniform_time'")
     method = vf_dict.get("method", "sparsevfc")
     if t_end is None:
         t_end = _default_t_end(np.asarray(vf_dict["X"], dtype=float), vf_dict["V"])
@@ -934,6 +984,7 @@ def integrate_field(vf_dict, init_states, t_end=None, interpolation_num=250, dir
         affine = (sf / 10000.0 / stt, 1.0, A / stt, (b + A @ center) / stt)
         start = (X0 - mean_t) / stt
         to_world = lambda q: q * stt + mean_t  # noqa: E731
+        vscale = stt
     else:
         ctrl = np.asarray(vf_dict["X_ctrl"], dtype=np.float64)
         Cc = np.asarray(vf_dict["C"], dtype=np.float64)
@@ -941,35 +992,89 @@ def integrate_field(vf_dict, init_states, t_end=None, interpolation_num=250, dir
         affine = None
         start = X0
         to_world = lambda q: q  # noqa: E731
+        vscale = 1.0
     if ctrl.shape[1] > 3 or Cc.shape[1] != ctrl.shape[1]:
         raise NotImplementedError("trajectory integration needs a field with Dy == D <= 3")
     C3 = np.zeros((len(ctrl), 3))
     C3[:, : Cc.shape[1]] = Cc
     Cd = torch.from_numpy(C3).to(k.device)
     c4 = k.to_x4(ctrl, center)
-    dt = t_end / (n_t - 1)
     beta = float(vf_dict["beta"])
+    arc = sampling == "arc_length"
+    n_fine = 4 * n_t + 1 if arc else n_t  # dense RK4 samples the arc-length resampling works from
+    dt = t_end / (n_fine - 1)
+    tf = np.linspace(0.0, t_end, n_fine)
 
     def run(sign):
-        parts = []
+        """(times (n, n_t) or (n_fine,), states (n, n_t, d)) in world coordinates for one direction."""
+        ts, xs = [], []
         for lo in range(0, len(start), max_cells_per_launch):
             x4 = k.to_x4(start[lo : lo + max_cells_per_launch], center)
-            tr = k.integrate(x4, c4, beta, Cd, sign * dt, substeps, n_t, affine=affine)
-            parts.append(tr.cpu().numpy()[:, :, :d] + center[None, None, :d])
-        return to_world(np.concatenate(parts, axis=0))
+            tr = k.integrate(x4, c4, beta, Cd, sign * dt, 2 if arc else substeps, n_fine, affine=affine)
+            if not arc:
+                xs.append(tr.cpu().numpy()[:, :, :d] + center[None, None, :d])
+                continue
+            # velocities at the dense samples (fused evaluator; same affine as the integrator), then dynamo's resampling
+            pts = tr.reshape(-1, 3)
+            p4 = torch.zeros(pts.shape[0], 4, dtype=k.tdtype, device=k.device)
+            p4[:, :3] = pts.to(k.tdtype)
+            vel = k.eval(p4, c4, beta, Cd, _lib.EVAL_V, affine=affine)[_lib.EVAL_V].reshape(tr.shape[0], n_fine, 3)
+            xk = tr.cpu().numpy()[:, :, :d]
+            tq, xq = _arc_length_resample(sign * tf, xk, sign * vel.cpu().numpy()[:, :, :d], n_t,
+                                          stop_tol=1e-5 / vscale)
+            ts.append(tq)
+            xs.append(xq + center[None, None, :d])
+        x = to_world(np.concatenate(xs, axis=0))
+        return (np.concatenate(ts, axis=0) if arc else sign * tf), x
 
-    tf = np.linspace(0.0, t_end, n_t)
     if direction == "forward":
-        traj, times = run(+1.0), tf
+        times, traj = run(+1.0)
     elif direction == "backward":
-        traj, times = run(-1.0), -tf
+        times, traj = run(-1.0)
     else:
-        back, fwd = run(-1.0), run(+1.0)
-        traj = np.concatenate([back[:, :0:-1], fwd], axis=1)
-        times = np.concatenate([-tf[:0:-1], tf])
+        (tb, back), (tfw, fwd) = run(-1.0), run(+1.0)
+        if arc:  # dynamo doubles interpolation_num for "both": the backward half reversed, then the forward half
+            traj = np.concatenate([back[:, ::-1], fwd], axis=1)
+            times = np.concatenate([tb[:, ::-1], tfw], axis=1)
+        else:
+            traj = np.concatenate([back[:, :0:-1], fwd], axis=1)
+            times = np.concatenate([tb[:0:-1], tfw])
     if average in ("trajectory", True):
         traj = traj.mean(0, keepdims=True)
+        if arc:
+            times = times.mean(0, keepdims=True)
+    if arc:
+        return [times[i].copy() for i in range(len(traj))], [traj[i] for i in range(len(traj))]
     return [times.copy() for _ in range(len(traj))], [traj[i] for i in range(len(traj))]
+
+
+def genesis_states(vf_dict, init_states, time_vec, substeps=64, dtype=None, device=None):
+    """The numeric core of ``construct_genesis`` (``spateo/tdr/models/models_migration/morphopath_model.py:138-148``):
+    starting from ``init_states`` the cells are displaced step by step, ``pts <- odeint(f, pts, [0, time_vec[i]])[1]``
+    for every entry of ``time_vec`` (each entry is the DURATION of that step, as in the reference's loop), and the
+    positions after every step are returned as a list of (n, d) arrays (the reference's ``stages_X``).  One fused RK4
+    launch per step (``substeps`` RK4 steps each) instead of one SciPy ``odeint`` call per cell and step."""
+    dtype = dtype or _DEFAULT_DTYPE
+    pts = np.asarray(init_states, dtype=np.float64)
+    ctrl = np.asarray(vf_dict["X_ctrl"], dtype=np.float64)
+    Cc = np.asarray(vf_dict["C"], dtype=np.float64)
+    d = ctrl.shape[1]
+    if pts.ndim != 2 or pts.shape[1] != d or d > 3 or Cc.shape[1] != d:
+        raise NotImplementedError("genesis_states needs (n, d) states and a field with Dy == D <= 3")
+    k = _make_kernels(device, dtype)
+    center = ctrl.mean(0)
+    C3 = np.zeros((len(ctrl), 3))
+    C3[:, :d] = Cc
+    Cd = torch.from_numpy(C3).to(k.device)
+    c4 = k.to_x4(ctrl, center)
+    beta = float(vf_dict["beta"])
+    stages = []
+    for dt in np.asarray(time_vec, dtype=np.float64):
+        if dt != 0.0:
+            tr = k.integrate(k.to_x4(pts, center), c4, beta, Cd, float(dt), int(substeps), 2)
+            pts = tr[:, 1, :d].cpu().numpy() + center[None, :d]
+        stages.append(pts.copy())
+    return stages
 
 
 # =====================================================================================================================

@@ -289,7 +289,8 @@ def test_morphopath_fused_rk4_vs_dop853(st, golden, dtype, tol):
     vf.update(X=g["a_X"], beta=float(g["a_vf_beta"]), method="sparsevfc")
     x0 = g["a_X"][:40]
     tq = np.linspace(0, 30, 16)
-    t, pred = integrate_field(vf, x0, t_end=30.0, interpolation_num=16, dtype=dtype, device="cuda:0")
+    t, pred = integrate_field(vf, x0, t_end=30.0, interpolation_num=16, dtype=dtype, device="cuda:0",
+                            sampling="uniform_time")
     ref = tro.integrate(vf, x0, tq)
     assert np.abs(np.stack(pred) - ref).max() / np.abs(ref).max() < tol
     np.testing.assert_allclose(t[0], tq)
@@ -306,7 +307,8 @@ def test_morphopath_fused_rk4_vs_dop853(st, golden, dtype, tol):
 
     np.testing.assert_allclose(gp_field(g["gp_Xq"]), g["gp_vel"], rtol=1e-10)  # the restated field == the twin
     tq2 = np.linspace(0, 2000.0, 11)
-    t2, pred2 = integrate_field(gd, g["gpw_X"][:10], t_end=2000.0, interpolation_num=11, dtype=dtype, device="cuda:0")
+    t2, pred2 = integrate_field(gd, g["gpw_X"][:10], t_end=2000.0, interpolation_num=11, dtype=dtype, device="cuda:0",
+                              sampling="uniform_time")
     ref2 = tro.integrate(gd, g["gpw_X"][:10], tq2, field=gp_field)
     assert np.abs(np.stack(pred2) - ref2).max() / np.abs(ref2).max() < tol
 
@@ -573,3 +575,22 @@ def test_update_nonrigid_against_reference_goldens(st, golden_em, dtype):
 
     errs = check_update_nonrigid(st.align.update_nonrigid, golden_em, dtype, device="cuda:0")
     print(f"update_nonrigid {dtype}: (SigmaInv, VnA) errors vs reference: {errs}")
+
+
+# ------------------------------------------------------------------------------------------- morphopath: fate semantics
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_morphopath_fate_semantics_and_genesis_on_the_gpu(st, golden, dtype):
+    """``st.tdr.morphopath`` with dynamo fate's default arc-length sampling and ``construct_genesis_states`` on the real
+    kernels (mvf_integrate + mvf_eval), against the restated dynamo procedure / SciPy odeint."""
+    from _fate_case import _fate_case, check_fate_semantics
+    from oracle import trajectory_oracle as tro
+
+    if dtype == "float64":
+        check_fate_semantics(golden, dtype=dtype, device="cuda:0")
+    vf = _fate_case(golden)
+    ad = st.AnnDataLite(obsm={"align_spatial": golden["a_X"][:5]}, uns={"VecFld_morpho": vf})
+    st.tdr.morphopath(ad, interpolation_num=12, t_end=40.0, dtype=dtype, device="cuda:0")
+    stages, tv = st.tdr.construct_genesis_states(ad, n_steps=5, dtype=dtype, device="cuda:0")
+    ref = tro.genesis_states(vf, ad.uns["fate_morpho"]["init_states"], tv)
+    for a, b in zip(stages, ref):
+        assert _rel(a, b) < (1e-5 if dtype == "float64" else 1e-3)

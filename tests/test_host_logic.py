@@ -420,7 +420,7 @@ def test_morphopath_slots_and_accuracy(cpu_kernels, golden):
     vf.update(X=g["a_X"][:6], Y=g["a_V"][:6], method="sparsevfc", beta=float(g["a_vf_beta"]))
     vf["V"] = vf["V"][:6]
     ad.uns["VecFld_morpho"] = vf
-    assert st.tdr.morphopath(ad, interpolation_num=21, t_end=40.0, direction="both") is None
+    assert st.tdr.morphopath(ad, interpolation_num=21, t_end=40.0, direction="both", sampling="uniform_time") is None
     fate = ad.uns["fate_morpho"]
     assert set(fate["t"].keys()) == set(range(6)) and fate["prediction"][0].shape == (41, 3)  # (n_t, d) as the reference
     # the reference's consumer (construct_trajectory_X, morphopath_model.py:225) prepends the start point along axis 0
@@ -436,9 +436,10 @@ def test_morphopath_slots_and_accuracy(cpu_kernels, golden):
     gotb = np.stack([fate["prediction"][i][20::-1] for i in range(6)])
     assert np.abs(gotb - refb).max() / np.abs(refb).max() < 1e-7
     # default t_end (dynamo getTend), averaging modes, copies, errors
-    ad2 = st.tdr.morphopath(ad, interpolation_num=5, average="origin", inplace=False, key_added="f2")
+    ad2 = st.tdr.morphopath(ad, interpolation_num=5, average="origin", inplace=False, key_added="f2",
+                            sampling="uniform_time")
     assert "f2" in ad2.uns and "f2" not in ad.uns and len(ad2.uns["f2"]["prediction"]) == 1
-    st.tdr.morphopath(ad, interpolation_num=5, t_end=3.0, average="trajectory", key_added="f3")
+    st.tdr.morphopath(ad, interpolation_num=5, t_end=3.0, average="trajectory", key_added="f3", sampling="uniform_time")
     assert ad.uns["f3"]["prediction"][0].shape == (5, 3)
     ad.uns["bad"] = {"method": "other", "X": g["a_X"][:2]}
     with pytest.raises(Exception, match="not in avaliable"):
@@ -592,3 +593,31 @@ def test_update_nonrigid_host_composition_matches_reference(cpu_kernels, golden_
     with pytest.raises(AssertionError):
         st.align.update_nonrigid(golden_em["a_coordsA"][:, :2], golden_em["a_inducing_variables"], 0.5,
                                  golden_em["a_K_NA"], golden_em["a_PXB_term"], 0.5, 100.0)
+
+
+from _fate_case import _fate_case, check_fate_semantics  # noqa: E402
+
+
+def test_morphopath_default_sampling_is_dynamo_fates_arc_length(cpu_kernels, golden):
+    check_fate_semantics(golden)
+
+
+def test_construct_genesis_states_like_the_reference_loop(cpu_kernels, golden):
+    """construct_genesis' numeric core (morphopath_model.py:123-148): time vector from the fate prediction (integer
+    truncation, reference quirks included) and the step-by-step displacement, against SciPy odeint per cell and step."""
+    from oracle import trajectory_oracle as tro
+
+    vf = _fate_case(golden)
+    ad = st.AnnDataLite(obsm={"align_spatial": golden["a_X"][:5]}, uns={"VecFld_morpho": vf})
+    st.tdr.morphopath(ad, interpolation_num=12, t_end=40.0)
+    stages, tv = st.tdr.construct_genesis_states(ad, fate_key="fate_morpho", n_steps=6)
+    flats = np.sort(np.hstack((0, np.unique([int(v) for t in ad.uns["fate_morpho"]["t"].values() for v in t]))))
+    np.testing.assert_array_equal(tv, flats[np.linspace(0, len(flats) - 1, 6).astype(int)])
+    ref = tro.genesis_states(vf, ad.uns["fate_morpho"]["init_states"], tv)
+    assert len(stages) == 6 and stages[0].shape == (5, 3)
+    for a, b in zip(stages, ref):
+        assert np.abs(a - b).max() / np.abs(b).max() < 1e-5
+    _, tv2 = st.tdr.construct_genesis_states(ad, n_steps=4, logspace=True, t_end=25)
+    np.testing.assert_allclose(tv2, np.logspace(0, np.log10(max(flats[flats <= 25]) + 1), 4) - 1)
+    with pytest.raises(Exception, match="develop_trajectory"):
+        st.tdr.construct_genesis_states(ad, fate_key="nope")
