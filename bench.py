@@ -171,7 +171,19 @@ def main():
     t0 = time.perf_counter()
     X, V, _ = make_config("C4", N=args.cells)
     M = args.ctrl
-    valid, Xv, Yv, idx, ctrl, beta = sparsevfc_preprocess(X, V, M=M, seed=0)
+    if distributed:
+        # as SparseVFC(distributed=True) does: rank 0 alone runs the O(N log N) host preprocessing and broadcasts the
+        # control points; every rank only filters the finite rows and takes its block
+        valid = np.where(np.isfinite(V.sum(1)))[0]
+        Xv, Yv = X[valid], V[valid]
+        box = [None]
+        if rank == 0:
+            _, _, _, idx0, ctrl0, beta0 = sparsevfc_preprocess(X, V, M=M, seed=0)
+            box = [(ctrl0, beta0)]
+        dist.broadcast_object_list(box, src=0)
+        ctrl, beta = box[0]
+    else:
+        valid, Xv, Yv, idx, ctrl, beta = sparsevfc_preprocess(X, V, M=M, seed=0)
     N = len(Xv)
     lo, hi = shard_bounds(N, rank, world)
     if rank == 0:

@@ -65,11 +65,23 @@ __device__ __forceinline__ int64_t pair_row(int bp, int bq, int r) {
 }
 
 // partial Gram tile of one block pair over a K range:  Spart[pair][split] = Y_pair[:, K range] Y_pair[:, K range]^T
+// Convergence bookkeeping (device side): `mod[b]` = stamp of the last round in which block b was rotated, `clean[bp][bq]`
+// = stamp of the last visit of that pair that found nothing to rotate.  A pair whose clean stamp is newer than both
+// blocks' modification stamps is still orthogonal - its Gram tile would come out bit-identical - so its Gram, rotation
+// and update work is skipped: the verification sweep that ends the iteration, and the converged pairs of the sweeps
+// before it, cost next to nothing.
+__device__ __forceinline__ bool pair_is_clean(const int* __restrict__ mod, const int* __restrict__ clean, int nb, int bp,
+                                              int bq) {
+    return clean[bp * nb + bq] > max(mod[bp], mod[bq]);
+}
+
 __global__ __launch_bounds__(256) void jac_gram_kernel(const double* __restrict__ Y, int64_t mp, int nb, int round,
-                                                       int nsplit, int kchunks, double* __restrict__ Spart) {
+                                                       int nsplit, int kchunks, const int* __restrict__ mod,
+                                                       const int* __restrict__ clean, double* __restrict__ Spart) {
     const int pair = blockIdx.x, split = blockIdx.y;
     int bp, bq;
     rr_pair(nb, round, pair, bp, bq);
+    if (pair_is_clean(mod, clean, nb, bp, bq)) return;
     __shared__ double sy[JP * LDR];  // one 64 x 64 tile (33 KB); the next tile waits in registers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
@@ -169,29 +181,39 @@ __device__ __forceinline__ void inner_pair(int r, int l, int& p, int& q) {
 
 // One cyclic two-sided Jacobi sweep on the 64 x 64 Gram tile of a block pair, in LDS.  Rotation (p, q) is applied when
 // |s_pq| > tol sqrt(s_pp s_qq) (the one-sided criterion: the two columns are not yet orthogonal relative to their
-// norms).
-// Thread (l = tid & 31, kq = tid >> 5).  Phase A: EVERY lane computes the rotation of its pair l (redundantly
-// in all four waves: its own (c_l, s_l) then sit in registers and any other pair's come from a wave shuffle - no LDS
-// round trip).  Phase B: the 2 x 2 blocks S_kl <- Rot_k^T S_kl Rot_l for k = kq + 8 j and the column pair l of J for
-// rows kq + 8 j.  Blocks partition S, so phase B is in place; two barriers per round (A -> B and B -> next A).
-// Within a half-wave the 32 lanes touch 32 distinct columns of one row: conflict-free without padding, so S and J take
-// exactly 64 KB of LDS.
+// norms).  1024 threads = 16 waves, four per SIMD: the kernel is a chain of short LDS round trips and dependent f64
+// operations, so it needs several waves per SIMD to hide their latency (the first version ran one wave per SIMD with
+// all of it exposed: 86 us per call against 41 us for the same work here, measured at M = 3000).  Thread (l = tid & 31, k = tid >> 5).
+// Phase A: the 32 lanes of the first half-wave compute the round's 32 rotations and publish (c, s) in LDS.  Phase B:
+// thread (l, k) updates the 2 x 2 block S_kl <- Rot_k^T S_kl Rot_l and the column pair l of J for rows k and k + 32.
+// Blocks partition S, so phase B is in place; two barriers per round.  Within a half-wave the 32 lanes touch 32 distinct
+// columns of one row: conflict-free without padding.
+constexpr int EIG_THREADS = 1024;
 template <bool FULL>
-__global__ __launch_bounds__(256) void jac_eig_kernel(const double* __restrict__ Spart, int nsplit, double tol,
-                                                      double* __restrict__ Jbuf, int* __restrict__ flags,
-                                                      unsigned int* __restrict__ rot_total) {
+__global__ __launch_bounds__(EIG_THREADS) void jac_eig_kernel(const double* __restrict__ Spart, int nsplit, double tol,
+                                                              int nb, int round, int stamp, int* __restrict__ mod,
+                                                              int* __restrict__ clean, double* __restrict__ Jbuf,
+                                                              int* __restrict__ flags,
+                                                              unsigned int* __restrict__ rot_total) {
     __shared__ double S[JP][JP];
     __shared__ double Jm[JP][JP];
+    __shared__ double cs[JB][2];
     const int pair = blockIdx.x, tid = threadIdx.x;
+    int bp, bq;
+    rr_pair(nb, round, pair, bp, bq);
+    if (pair_is_clean(mod, clean, nb, bp, bq)) {  // uniform over the workgroup; nobody writes these stamps this round
+        if (tid == 0) flags[pair] = 0;
+        return;
+    }
     const double* sp = Spart + (int64_t)pair * nsplit * (JP * JP);
-    for (int e = tid; e < JP * JP; e += 256) {
+    for (int e = tid; e < JP * JP; e += EIG_THREADS) {
         double s = 0.0;
         for (int q = 0; q < nsplit; ++q) s += sp[(int64_t)q * (JP * JP) + e];
         S[e >> 6][e & 63] = s;
         Jm[e >> 6][e & 63] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
     }
     __syncthreads();
-    const int l = tid & 31, kq = tid >> 5;
+    const int l = tid & 31, k = tid >> 5;
     const double tol2 = tol * tol;
     int nrot = 0;
     constexpr int NR = FULL ? JP - 1 : JB;
@@ -199,35 +221,35 @@ __global__ __launch_bounds__(256) void jac_eig_kernel(const double* __restrict__
     for (int r = 0; r < NR; ++r) {
         int p, q;
         inner_pair<FULL>(r, l, p, q);
-        double cl = 1.0, sl = 0.0;
-        {
+        if (k == 0) {
+            double c = 1.0, sn = 0.0;
             const double app = S[p][p], aqq = S[q][q], apq = S[p][q];
             const bool act = apq != 0.0 && apq * apq > tol2 * fabs(app * aqq);
             if (act) {
                 const double zeta = (aqq - app) * rcp_nr(2.0 * apq);
                 const double z2 = fma(zeta, zeta, 1.0);
                 const double t = copysign(rcp_nr(fabs(zeta) + z2 * rsq_nr(z2)), zeta);
-                cl = rsq_nr2(fma(t, t, 1.0));
-                sl = cl * t;
-                if (!(fabs(sl) <= 1.0)) {  // overflow / NaN in the estimate chain (|zeta| astronomically large): no rotation
-                    cl = 1.0;
-                    sl = 0.0;
+                c = rsq_nr2(fma(t, t, 1.0));
+                sn = c * t;
+                if (!(fabs(sn) <= 1.0)) {  // overflow / NaN in the estimate chain (|zeta| astronomically large): no rotation
+                    c = 1.0;
+                    sn = 0.0;
                 }
             }
-            nrot += __popcll(__ballot(act) & 0xffffffffULL);  // lanes 0..31 = the 32 pairs (32..63 duplicate them)
+            cs[l][0] = c;
+            cs[l][1] = sn;
+            nrot += __popcll(__ballot(act));  // the 32 lanes of this half-wave = the round's 32 pairs
         }
-        __syncthreads();  // every wave has read the diagonal blocks before any wave rewrites them
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = kq + 8 * j;
+        __syncthreads();
+        const double cl = cs[l][0], sl = cs[l][1], ck = cs[k][0], sk = cs[k][1];
+        {
             int pk, qk;
             inner_pair<FULL>(r, k, pk, qk);
-            const double ck = __shfl(cl, k, 64), sk = __shfl(sl, k, 64);
             const double m00 = S[pk][p], m01 = S[pk][q], m10 = S[qk][p], m11 = S[qk][q];
-            const double r00 = ck * m00 - sk * m10, r01 = ck * m01 - sk * m11;
-            const double r10 = sk * m00 + ck * m10, r11 = sk * m01 + ck * m11;
-            double n00 = cl * r00 - sl * r01, n01 = sl * r00 + cl * r01;
-            double n10 = cl * r10 - sl * r11, n11 = sl * r10 + cl * r11;
+            const double r00 = fma(ck, m00, -(sk * m10)), r01 = fma(ck, m01, -(sk * m11));
+            const double r10 = fma(sk, m00, ck * m10), r11 = fma(sk, m01, ck * m11);
+            double n00 = fma(cl, r00, -(sl * r01)), n01 = fma(sl, r00, cl * r01);
+            double n10 = fma(cl, r10, -(sl * r11)), n11 = fma(sl, r10, cl * r11);
             if (k == l && sl != 0.0) {
                 n01 = 0.0;
                 n10 = 0.0;
@@ -238,19 +260,25 @@ __global__ __launch_bounds__(256) void jac_eig_kernel(const double* __restrict__
             S[qk][q] = n11;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int i = kq + 8 * j;
+        for (int j = 0; j < 2; ++j) {
+            const int i = k + 32 * j;
             const double a = Jm[i][p], b = Jm[i][q];
-            Jm[i][p] = cl * a - sl * b;
-            Jm[i][q] = sl * a + cl * b;
+            Jm[i][p] = fma(cl, a, -(sl * b));
+            Jm[i][q] = fma(sl, a, cl * b);
         }
         __syncthreads();
     }
     double* jo = Jbuf + (int64_t)pair * (JP * JP);
-    for (int e = tid; e < JP * JP; e += 256) jo[e] = Jm[e >> 6][e & 63];
+    for (int e = tid; e < JP * JP; e += EIG_THREADS) jo[e] = Jm[e >> 6][e & 63];
     if (tid == 0) {
         flags[pair] = nrot > 0;
-        if (nrot > 0) atomicAdd(rot_total, (unsigned int)nrot);
+        if (nrot > 0) {
+            atomicAdd(rot_total, (unsigned int)nrot);
+            mod[bp] = stamp;  // each block is in exactly one pair per round: single writer
+            mod[bq] = stamp;
+        } else {
+            clean[bp * nb + bq] = stamp;
+        }
     }
 }
 
@@ -523,7 +551,7 @@ __global__ __launch_bounds__(256) void basis_extract_kernel(const double* __rest
 struct JacPlan {
     int64_t mp;
     int nb, npairs, nsplit, kchunks, bsplit, rows_per_split;
-    size_t off_y, off_aux, off_spart, off_j, off_flags, off_sig2, off_t, off_part, off_rot, total;
+    size_t off_y, off_aux, off_spart, off_j, off_flags, off_stamps, off_sig2, off_t, off_part, off_rot, total;
 };
 
 static JacPlan jac_plan(int64_t m, int nrhs) {
@@ -549,6 +577,8 @@ static JacPlan jac_plan(int64_t m, int nrhs) {
     o += align_up((size_t)p.npairs * JP * JP * sizeof(double), 256);
     p.off_flags = o;
     o += align_up((size_t)p.npairs * sizeof(int), 256);
+    p.off_stamps = o;  // mod[nb] | clean[nb * nb]
+    o += align_up((size_t)(p.nb + (size_t)p.nb * p.nb) * sizeof(int), 256);
     p.off_sig2 = o;
     o += align_up((size_t)p.mp * sizeof(double), 256);
     p.off_t = o;
@@ -645,19 +675,23 @@ extern "C" int mvf_solve_minnorm(const double* G, const double* K, double lambda
     hipLaunchKernelGGL(jac_init_kernel, dim3((unsigned)(mp / 64), (unsigned)(mp / 64)), dim3(256), 0, st, cp.W, m, mp, Y);
     MVF_LAUNCH_CHECK();
     const double tol = std::sqrt((double)m) * 2.220446049250313e-16;
+    int* mod = (int*)(ws + p.off_stamps);
+    int* clean = mod + p.nb;
+    MVF_CHECK_HIP(hipMemsetAsync(mod, 0, (size_t)(p.nb + (size_t)p.nb * p.nb) * sizeof(int), st));  // all pairs dirty
     int sweeps = 0;
     unsigned int hrot = 1;
     while (sweeps < max_sweeps) {
         MVF_CHECK_HIP(hipMemsetAsync(rot, 0, sizeof(unsigned int), st));
         for (int r = 0; r < p.nb - 1; ++r) {
+            const int stamp = 1 + sweeps * (p.nb - 1) + r;
             hipLaunchKernelGGL(jac_gram_kernel, dim3((unsigned)p.npairs, (unsigned)p.nsplit), dim3(256), 0, st, Y, mp,
-                               p.nb, r, p.nsplit, p.kchunks, Spart);
+                               p.nb, r, p.nsplit, p.kchunks, mod, clean, Spart);
             if (r == 0)
-                hipLaunchKernelGGL(jac_eig_kernel<true>, dim3((unsigned)p.npairs), dim3(256), 0, st, Spart, p.nsplit, tol,
-                                   Jbuf, flags, rot);
+                hipLaunchKernelGGL(jac_eig_kernel<true>, dim3((unsigned)p.npairs), dim3(EIG_THREADS), 0, st, Spart, p.nsplit, tol,
+                                   p.nb, r, stamp, mod, clean, Jbuf, flags, rot);
             else
-                hipLaunchKernelGGL(jac_eig_kernel<false>, dim3((unsigned)p.npairs), dim3(256), 0, st, Spart, p.nsplit,
-                                   tol, Jbuf, flags, rot);
+                hipLaunchKernelGGL(jac_eig_kernel<false>, dim3((unsigned)p.npairs), dim3(EIG_THREADS), 0, st, Spart, p.nsplit,
+                                   tol, p.nb, r, stamp, mod, clean, Jbuf, flags, rot);
             hipLaunchKernelGGL(jac_update_kernel, dim3((unsigned)p.npairs, (unsigned)(mp / 64)), dim3(256), 0, st, Y, mp,
                                p.nb, r, Jbuf, flags);
         }
