@@ -560,7 +560,11 @@ static JacPlan jac_plan(int64_t m, int nrhs) {
     p.nb = (int)(p.mp / JB);
     p.npairs = p.nb / 2;
     const int nk = (int)(p.mp / 64);
-    int want = std::max(1, 512 / p.npairs);
+    static const int target = [] {
+        const char* e = std::getenv("MVF_JAC_GRAM_WGS");  // developer knob: workgroups per Gram launch (default 512)
+        return e ? std::max(64, atoi(e)) : 512;
+    }();
+    int want = std::max(1, target / p.npairs);
     p.nsplit = std::min(nk, want);
     p.kchunks = (int)cdiv(nk, p.nsplit);
     p.nsplit = (int)cdiv(nk, p.kchunks);

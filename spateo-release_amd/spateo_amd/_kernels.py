@@ -17,6 +17,20 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _on_device(fn):
+    """Run a kernel method with the instance's GPU as the thread's current HIP device: libmvf launches on the stream it
+    is handed, but hipFuncSetAttribute / hipMemsetAsync / occupancy queries inside it act on the CURRENT device, which
+    need not be `self.device` (SparseVFC(device="cuda:1") without set_device, SparseVFC_many threads)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **kw)
+
+    return wrapped
+
+
 class HipKernels:
     """libmvf kernels bound to one GPU and one cell dtype ("float32" | "float64")."""
 
@@ -54,6 +68,7 @@ class HipKernels:
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    @_on_device
     def to_x4(self, arr, center=None):
         """Host (n, d<=3) float64 array -> device (n, 4) tensor of the cell dtype (zero padded), optionally centred."""
         a = np.asarray(arr, dtype=np.float64)
@@ -78,6 +93,7 @@ class HipKernels:
         return torch.zeros(*shape, dtype=dtype or self.tdtype, device=self.device)
 
     # ------------------------------------------------------------------ kernels
+    @_on_device
     def con_k(self, x, y, beta, return_d=False, dtype=None):
         """x: (n, d), y: (m, d) device tensors (cell dtype, or `dtype`) -> K (n, m) [and D (n, d, m)]."""
         tdtype, cdtype = _DT[dtype] if dtype is not None else (self.tdtype, self.cdtype)
@@ -89,13 +105,16 @@ class HipKernels:
         K = self.empty(n, m, dtype=tdtype)
         if return_d:
             D = self.empty(n, d, m, dtype=tdtype)
-            _lib.check(self.lib.mvf_con_k_d(_ptr(x), n, _ptr(y), m, d, float(beta), _ptr(K), _ptr(D), cdtype,
-                                            self._stream()), "mvf_con_k_d")
+            for lo in range(0, n, 65535):  # mvf_con_k_d takes at most 65535 rows per call: chunk (rows are contiguous)
+                nn = min(65535, n - lo)
+                _lib.check(self.lib.mvf_con_k_d(_ptr(x[lo:]), nn, _ptr(y), m, d, float(beta), _ptr(K[lo:]), _ptr(D[lo:]),
+                                                cdtype, self._stream()), "mvf_con_k_d")
             return K, D
         _lib.check(self.lib.mvf_con_k(_ptr(x), n, _ptr(y), m, d, float(beta), _ptr(K), cdtype, self._stream()),
                    "mvf_con_k")
         return K
 
+    @_on_device
     def apply(self, x4, ctrl4, beta, C, y4=None, P=None, stats=None):
         """V4 = con_K(x, ctrl) @ C; with y4 also r = ||y - V||^2 and stats[0] += sum P r.  Returns (V4, r)."""
         n, m = x4.shape[0], ctrl4.shape[0]
@@ -105,12 +124,14 @@ class HipKernels:
                                       _ptr(r), _ptr(stats), self._red(n), self.cdtype, self._stream()), "mvf_apply")
         return V4, r
 
+    @_on_device
     def estep_min(self, r, sigma2):
         """Returns a device float64 view (2,): [min non-zero t1, #zeros]."""
         _lib.check(self.lib.mvf_estep_min(_ptr(r), r.shape[0], float(sigma2), _ptr(self._mins), self.cdtype,
                                           self._stream()), "mvf_estep_min")
         return self._mins[:2]
 
+    @_on_device
     def estep_p(self, r, sigma2, gamma, a, dy, minP, theta, zero_fill, P_out, stats):
         """zero_fill: a host float, or a device float64 tensor whose first element is the fill (estep_min's result,
         possibly MIN-all-reduced): then the two E-step phases chain on the stream without a host round trip."""
@@ -123,6 +144,7 @@ class HipKernels:
     def ublk_bytes(self, n, m):
         return int(self.lib.mvf_ublk_bytes(n, m, self.cdtype))
 
+    @_on_device
     def build_ublk(self, x4, ctrl4, beta):
         """Materialise the float32 kernel values once per fit (U is constant across EM iterations); later `gram`
         calls with the same (x4, ctrl4, beta) stream them instead of regenerating them."""
@@ -141,6 +163,7 @@ class HipKernels:
         self._ublk = None
         self._ublk_key = None
 
+    @_on_device
     def gram(self, x4, P, y4, ctrl4, beta, G, R, rhs_only=False):
         """G = U^T P U (m x m), R = U^T P Y (m x 3).  rhs_only: only R for this y4 (G unchanged) - for Y wider than 3."""
         n, m = x4.shape[0], ctrl4.shape[0]
@@ -171,6 +194,7 @@ class HipKernels:
         self.gram_events.append((e0, e1))
         run(_lib.GRAM_RHS | _lib.GRAM_REDUCE | _lib.GRAM_REDUCE_RHS)
 
+    @_on_device
     def solve(self, G, K, lambda_sigma2, jitter, R, C_out, info, pivots=None):
         """Cholesky solve of (G + ls2 K + jitter mean(diag) I) C = R.  info[0] != 0: non-positive pivot.
         pivots (float64[2], optional): [min L_jj^2, max L_jj^2] - the host's numerical-rank certificate."""
@@ -182,6 +206,7 @@ class HipKernels:
                                       _ptr(C_out), _ptr(info), _ptr(pivots), _ptr(self._solve_ws),
                                       self._solve_ws.numel(), self._stream()), "mvf_solve")
 
+    @_on_device
     def solve_minnorm(self, G, K, lambda_sigma2, shift, R, C_out, info, einfo, rcond=None, reuse=False, max_sweeps=60,
                       basis=None, warm=False):
         """Minimum-norm solve with the gelsd cut-off (eigenvalues below rcond * max|lambda| dropped; rcond = float64
@@ -202,18 +227,22 @@ class HipKernels:
                                               1 if reuse else 0, _ptr(basis), 1 if warm else 0, _ptr(self._mn_ws),
                                               self._mn_ws.numel(), self._stream()), "mvf_solve_minnorm")
 
+    @_on_device
     def minnorm_basis(self, m):
         """Uninitialised eigenvector-basis buffer for solve_minnorm's warm start (m x m padded to multiples of 64)."""
         return torch.empty(int(self.lib.mvf_solve_minnorm_basis_bytes(m)) // 8, dtype=torch.float64, device=self.device)
 
+    @_on_device
     def quadform(self, K, C, out):
         _lib.check(self.lib.mvf_quadform(_ptr(K), _ptr(C), K.shape[0], C.shape[1], _ptr(out), self._red(K.shape[0]),
                                          self._stream()), "mvf_quadform")
 
+    @_on_device
     def sym_pack(self, G, tri):
         """Packed upper triangle of the symmetric G (what the multi-GPU host all-reduces)."""
         _lib.check(self.lib.mvf_sym_pack(_ptr(G), G.shape[0], _ptr(tri), self._stream()), "mvf_sym_pack")
 
+    @_on_device
     def sym_unpack(self, tri, G):
         _lib.check(self.lib.mvf_sym_unpack(_ptr(tri), G.shape[0], _ptr(G), self._stream()), "mvf_sym_unpack")
 
@@ -228,6 +257,7 @@ class HipKernels:
                [float(x) for x in np.asarray(b, dtype=np.float64).reshape(3)]
         return (ctypes.c_double * 14)(*vals)
 
+    @_on_device
     def integrate(self, x4, ctrl4, beta, C, dt, substeps, n_out, affine=None):
         """RK4 trajectories of dx/dt = v(x): returns a float64 device tensor (n, n_out, 3)."""
         n, m = x4.shape[0], ctrl4.shape[0]
@@ -237,6 +267,7 @@ class HipKernels:
                                           self._stream()), "mvf_integrate")
         return traj
 
+    @_on_device
     def eval(self, x4, ctrl4, beta, C, flags, affine=None):
         """Fused evaluator.  Returns a dict of float64 device tensors for the requested MVF_EVAL_* flags.
         `affine` = (alpha, jmul, A (3x3), b (3)) applies v = alpha K@C + A q + b, J = jmul J (GP variant)."""

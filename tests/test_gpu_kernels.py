@@ -471,3 +471,13 @@ def test_evaluators_large_vs_oracle(st):
     assert _relmax(J, Jr) < 1e-10
     div = vf.compute_divergence(X)
     assert _relmax(div, np.trace(Jr)) < 1e-10
+
+
+def test_con_k_return_d_beyond_65535_rows(st):
+    """return_d=True for more rows than one mvf_con_k_d launch takes (the reference signature has no such limit)."""
+    rng = np.random.default_rng(9)
+    x, y = rng.standard_normal((70001, 3)), rng.standard_normal((3, 3))
+    K, D = st.con_K(x, y, 0.2, return_d=True, dtype="float64")
+    Kr, Dr = svo.con_K(x, y, 0.2, return_d=True)
+    assert K.shape == (70001, 3) and D.shape == (70001, 3, 3)
+    assert _relmax(K, Kr) < 1e-11 and np.abs(D - Dr).max() < 1e-12
