@@ -48,6 +48,16 @@ const char* mvf_last_error(void);
 int mvf_version(void);                 /* ABI version, currently 2 */
 int mvf_device_count(int* count);      /* number of visible HIP devices (0 without a GPU) */
 
+/* ---- preprocessing: sorted unique rows -------------------------------------------------------------------------------
+ * Replaces: `tmp_X, uid = np.unique(X, axis=0, return_index=True)` of dynamo SparseVFC (same
+ * call in-tree: spateo/alignment/methods/morpho_class.py:845).  X: n x d float64 row-major (finite).  Outputs (device,
+ * caller-allocated for n rows): uid[0..count) = index of the FIRST occurrence of each distinct row, in lexicographic row
+ * order; rows[0..count) = those rows; count[0] = number of distinct rows.  Stable LSD radix sort over the columns
+ * (rocPRIM device primitives) + run flags + compaction; bit-identical to NumPy for finite input. */
+size_t mvf_unique_rows_workspace_bytes(int64_t n, int d);
+int mvf_unique_rows(const double* X, int64_t n, int d, int64_t* uid, double* rows, int64_t* count, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
 /* ---- con_K ----------------------------------------------------------------------------------------------------
  * K[i, j] = exp(-beta * ||x_i - y_j||^2), materialised n x m row-major.
  * Replaces: dynamo `con_K` / in-tree twin `_con_K` spateo/tdr/morphometrics/morphofield/gaussian_process.py:16-36

@@ -1,0 +1,132 @@
+// Preprocessing on the device: lexicographically sorted unique rows of the cell coordinates.
+//
+// Reference: dynamo SparseVFC step 2, `tmp_X, uid = np.unique(X, axis=0, return_index=True)` (SURVEY.md Appendix A;
+// the same call in-tree: `self.nx.unique(self.coordsA, return_index=True, axis=0)`, spateo/alignment/methods/
+// morpho_class.py:845).  NumPy sorts the rows lexicographically and returns, per distinct row, the index of its FIRST
+// occurrence; at 8 M cells that is 2-5 s of single-threaded host time.  Here: an LSD pass over the d columns (last
+// column first), each a stable device radix sort of (order-preserving 64-bit image of the double, row index) - stable,
+// so equal rows stay in ascending index order and the first of each run is the first occurrence - then run-start flags
+// and a stream compaction.  The radix sort and the compaction are rocPRIM's device primitives (header-only part of
+// ROCm; this is a one-off O(N) preprocessing step, not a kernel of the EM loop); the key transform, gather, flag and
+// row-gather kernels are this file's.  Bit-identical to np.unique for finite input (-0.0 and +0.0 compare equal there
+// and are given the same key here; the host routes non-finite input to NumPy).
+#include <cstring>
+
+#include "mvf_common.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+
+namespace mvf {
+
+__device__ __forceinline__ unsigned long long ordered_key(double x) {
+    if (x == 0.0) x = 0.0;  // -0.0 -> +0.0: they are equal for np.unique
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+}
+
+__global__ __launch_bounds__(256) void prep_iota_kernel(long long* __restrict__ idx, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) idx[i] = i;
+}
+
+__global__ __launch_bounds__(256) void prep_keys_kernel(const double* __restrict__ X, int64_t n, int d, int c,
+                                                        const long long* __restrict__ idx,
+                                                        unsigned long long* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keys[i] = ordered_key(X[idx[i] * d + c]);
+}
+
+// flag[i] = 1 when sorted row i starts a run (differs from sorted row i - 1 in some column; value comparison, so that
+// -0.0 == 0.0 like NumPy)
+__global__ __launch_bounds__(256) void prep_flags_kernel(const double* __restrict__ X, int64_t n, int d,
+                                                         const long long* __restrict__ idx,
+                                                         unsigned char* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned char f = (i == 0);
+    if (i > 0) {
+        const double* a = X + idx[i] * d;
+        const double* b = X + idx[i - 1] * d;
+        for (int c = 0; c < d; ++c) f |= (a[c] != b[c]);
+    }
+    flag[i] = f;
+}
+
+__global__ __launch_bounds__(256) void prep_gather_rows_kernel(const double* __restrict__ X, int d,
+                                                               const long long* __restrict__ uid,
+                                                               const long long* __restrict__ count,
+                                                               double* __restrict__ rows) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= *count) return;
+    for (int c = 0; c < d; ++c) rows[i * d + c] = X[uid[i] * d + c];
+}
+
+struct PrepPlan {
+    size_t off_keys_a, off_keys_b, off_idx_a, off_idx_b, off_flag, off_tmp, tmp_bytes, total;
+};
+
+static PrepPlan prep_plan(int64_t n) {
+    PrepPlan p;
+    size_t sort_bytes = 0, sel_bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                    (const long long*)nullptr, (long long*)nullptr, (size_t)n, 0, 64, (hipStream_t)0);
+    (void)rocprim::select(nullptr, sel_bytes, (const long long*)nullptr, (const unsigned char*)nullptr, (long long*)nullptr,
+                          (long long*)nullptr, (size_t)n, (hipStream_t)0);
+    p.tmp_bytes = std::max(sort_bytes, sel_bytes);
+    size_t o = 0;
+    p.off_keys_a = o, o += align_up((size_t)n * 8, 256);
+    p.off_keys_b = o, o += align_up((size_t)n * 8, 256);
+    p.off_idx_a = o, o += align_up((size_t)n * 8, 256);
+    p.off_idx_b = o, o += align_up((size_t)n * 8, 256);
+    p.off_flag = o, o += align_up((size_t)n, 256);
+    p.off_tmp = o, o += align_up(p.tmp_bytes, 256);
+    p.total = o + 256;
+    return p;
+}
+
+}  // namespace mvf
+
+using namespace mvf;
+
+extern "C" size_t mvf_unique_rows_workspace_bytes(int64_t n, int d) {
+    if (n <= 0 || d < 1) return 0;
+    return prep_plan(n).total;
+}
+
+extern "C" int mvf_unique_rows(const double* X, int64_t n, int d, int64_t* uid, double* rows, int64_t* count,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    MVF_REQUIRE(n >= 0 && d >= 1 && d <= 16, "mvf_unique_rows: bad shape (n=%lld d=%d)", (long long)n, d);
+    MVF_REQUIRE(count, "mvf_unique_rows: null count");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        MVF_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int64_t), st));
+        return 0;
+    }
+    MVF_REQUIRE(X && uid && rows, "mvf_unique_rows: null pointer");
+    const PrepPlan p = prep_plan(n);
+    MVF_REQUIRE(workspace && workspace_bytes >= p.total, "mvf_unique_rows: workspace too small (%zu < %zu)",
+                workspace_bytes, p.total);
+    char* ws = (char*)workspace;
+    unsigned long long* ka = (unsigned long long*)(ws + p.off_keys_a);
+    unsigned long long* kb = (unsigned long long*)(ws + p.off_keys_b);
+    long long* ia = (long long*)(ws + p.off_idx_a);
+    long long* ib = (long long*)(ws + p.off_idx_b);
+    unsigned char* flag = (unsigned char*)(ws + p.off_flag);
+    void* tmp = ws + p.off_tmp;
+    const dim3 grid((unsigned)cdiv(n, 256));
+    hipLaunchKernelGGL(prep_iota_kernel, grid, dim3(256), 0, st, ia, n);
+    for (int c = d - 1; c >= 0; --c) {  // LSD over the columns: the first column is the primary key
+        hipLaunchKernelGGL(prep_keys_kernel, grid, dim3(256), 0, st, X, n, d, c, ia, ka);
+        size_t bytes = p.tmp_bytes;
+        MVF_CHECK_HIP(rocprim::radix_sort_pairs(tmp, bytes, ka, kb, ia, ib, (size_t)n, 0, 64, st));
+        std::swap(ia, ib);
+    }
+    hipLaunchKernelGGL(prep_flags_kernel, grid, dim3(256), 0, st, X, n, d, ia, flag);
+    size_t bytes = p.tmp_bytes;
+    MVF_CHECK_HIP(rocprim::select(tmp, bytes, ia, flag, (long long*)uid, (long long*)count, (size_t)n, st));
+    hipLaunchKernelGGL(prep_gather_rows_kernel, grid, dim3(256), 0, st, X, d, (const long long*)uid,
+                       (const long long*)count, rows);
+    MVF_LAUNCH_CHECK();
+    return 0;
+}

@@ -94,6 +94,23 @@ class HipKernels:
 
     # ------------------------------------------------------------------ kernels
     @_on_device
+    def unique_rows(self, X):
+        """np.unique(X, axis=0, return_index=True) for a finite host float64 (n, d) array, on the device:
+        returns host (unique rows sorted lexicographically, index of the first occurrence of each)."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        n, d = X.shape
+        xd = torch.from_numpy(X).to(self.device)
+        uid = torch.empty(n, dtype=torch.int64, device=self.device)
+        rows = torch.empty(n, d, dtype=torch.float64, device=self.device)
+        cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
+        need = int(self.lib.mvf_unique_rows_workspace_bytes(n, d))
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.mvf_unique_rows(_ptr(xd), n, d, _ptr(uid), _ptr(rows), _ptr(cnt), _ptr(ws), ws.numel(),
+                                            self._stream()), "mvf_unique_rows")
+        k = int(cnt.cpu()[0])
+        return rows[:k].cpu().numpy(), uid[:k].cpu().numpy()
+
+    @_on_device
     def con_k(self, x, y, beta, return_d=False, dtype=None):
         """x: (n, d), y: (m, d) device tensors (cell dtype, or `dtype`) -> K (n, m) [and D (n, d, m)]."""
         tdtype, cdtype = _DT[dtype] if dtype is not None else (self.tdtype, self.cdtype)

@@ -108,15 +108,24 @@ def sample_by_velocity(V: np.ndarray, n: int, seed: int = 19491001) -> np.ndarra
     return idx
 
 
-def unique_rows(X: np.ndarray):
+_DEVICE_UNIQUE_MIN_ROWS = 200_000
+
+
+def unique_rows(X: np.ndarray, device=None):
     """``np.unique(X, axis=0, return_index=True)`` (lexicographically sorted unique rows + index of the FIRST
     occurrence of each) without NumPy's structured-view sort, which is the slowest host step at millions of cells
-    (12 s at 8 M): stable argsort on the first coordinate, then a stable lexsort only inside runs of equal first
-    coordinates.  Bit-identical to np.unique for finite input; anything else takes the NumPy route."""
+    (12 s at 8 M).  From 200 k rows on, with a GPU: ``mvf_unique_rows`` (stable LSD radix sort over the columns +
+    compaction on the device, ~0.1 s at 8 M).  Otherwise on the host: stable argsort on the first coordinate, then a
+    stable lexsort only inside runs of equal first coordinates (2-5 s at 8 M).  Both are bit-identical to np.unique for
+    finite input; anything else takes the NumPy route."""
     X = np.ascontiguousarray(X)
     n, d = X.shape if X.ndim == 2 else (0, 0)
     if n < 2 or d < 1 or X.dtype.kind != "f" or not np.isfinite(X).all():
         return np.unique(X, axis=0, return_index=True)
+    if n >= _DEVICE_UNIQUE_MIN_ROWS and X.dtype == np.float64 and d <= 16 and torch.cuda.is_available():
+        k = _make_kernels(device, "float64")
+        if hasattr(k, "unique_rows"):
+            return k.unique_rows(X)
     order = np.argsort(X[:, 0], kind="stable")
     x0 = X[order, 0]
     eq = x0[1:] == x0[:-1]
@@ -135,17 +144,17 @@ def unique_rows(X: np.ndarray):
     return S[keep], order[keep]
 
 
-def sparsevfc_preprocess(X, Y, M=100, beta=None, velocity_based_sampling=True, seed=0):
+def sparsevfc_preprocess(X, Y, M=100, beta=None, velocity_based_sampling=True, seed=0, device=None):
     """valid rows, unique rows, control points and beta exactly as dynamo's SparseVFC picks them."""
-    return _sparsevfc_preprocess(X, Y, M, beta, velocity_based_sampling, seed)
+    return _sparsevfc_preprocess(X, Y, M, beta, velocity_based_sampling, seed, device)
 
 
-def _sparsevfc_preprocess(X, Y, M, beta, velocity_based_sampling, seed):
+def _sparsevfc_preprocess(X, Y, M, beta, velocity_based_sampling, seed, device=None):
     valid_ind = np.where(np.isfinite(Y.sum(1)))[0]
     Xv, Yv = X[valid_ind], Y[valid_ind]
     if len(Xv) == 0:
         raise ValueError("SparseVFC: no row of Y is finite - nothing to fit.")
-    tmp_X, uid = unique_rows(Xv)
+    tmp_X, uid = unique_rows(Xv, device)
     M = min(M, tmp_X.shape[0])
     if velocity_based_sampling:
         # (dynamo seeds the global RNG with `seed` here and sample_by_velocity immediately re-seeds it with its own
@@ -631,7 +640,7 @@ def SparseVFC(
     shard_sizes = None
     if world == 1:
         valid_ind, Xv, Yv, idx, ctrl_pts, beta = sparsevfc_preprocess(
-            X, Y, M=M, beta=beta, velocity_based_sampling=velocity_based_sampling, seed=seed
+            X, Y, M=M, beta=beta, velocity_based_sampling=velocity_based_sampling, seed=seed, device=device
         )
         N, lo, hi = len(Xv), 0, len(Xv)
     else:
@@ -669,7 +678,8 @@ def SparseVFC(
         if rank == 0:
             try:
                 _, _, _, idx0, ctrl0, beta0 = sparsevfc_preprocess(Xall, Yall, M=M, beta=beta,
-                                                                   velocity_based_sampling=velocity_based_sampling, seed=seed)
+                                                                   velocity_based_sampling=velocity_based_sampling, seed=seed,
+                                                                   device=device)
                 box = [(idx0, ctrl0, beta0)]
             except Exception as exc:  # every rank must leave the collective: ship the error
                 box = [exc]

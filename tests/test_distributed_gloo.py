@@ -54,9 +54,9 @@ def _worker(rank, world, port, case, out_dir, mode="all"):
 
         orig_unique = vfm.unique_rows
 
-        def counting_unique(a):
+        def counting_unique(a, device=None):
             calls["unique"] += 1
-            return orig_unique(a)
+            return orig_unique(a, device)
 
         vfm.unique_rows = counting_unique
         if mode == "sharded":  # every rank brings ITS OWN rows: 401 + 200, not the block split

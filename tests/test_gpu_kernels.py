@@ -481,3 +481,39 @@ def test_con_k_return_d_beyond_65535_rows(st):
     Kr, Dr = svo.con_K(x, y, 0.2, return_d=True)
     assert K.shape == (70001, 3) and D.shape == (70001, 3, 3)
     assert _relmax(K, Kr) < 1e-11 and np.abs(D - Dr).max() < 1e-12
+
+
+@pytest.mark.parametrize("n,d", [(1, 3), (2, 3), (1000, 3), (300_000, 3), (250_000, 2), (5000, 1)])
+def test_unique_rows_on_the_device_is_numpy_unique(st, n, d):
+    """mvf_unique_rows == np.unique(X, axis=0, return_index=True) bit for bit: lexicographic order, FIRST occurrence of
+    every duplicated row, -0.0 == 0.0, ties in leading columns."""
+    rng = np.random.default_rng(n + d)
+    X = rng.standard_normal((n, d))
+    if n > 10:
+        X[:, 0] = np.round(X[:, 0], 1)                 # many ties in the primary column
+        dup = rng.integers(0, n, n // 5)
+        X[rng.integers(0, n, n // 5)] = X[dup]          # exact duplicate rows
+        X[3] = 0.0
+        X[7] = -0.0                                     # equal to row 3 for NumPy
+    S, idx = _k("float64").unique_rows(X)
+    Sr, ir = np.unique(X, axis=0, return_index=True)
+    assert S.shape == Sr.shape
+    np.testing.assert_array_equal(idx, ir)
+    np.testing.assert_array_equal(S, X[ir])
+
+
+def test_preprocess_uses_the_device_unique_and_matches_the_host(st):
+    from spateo_amd import vectorfield as vfm
+    from spateo_amd._synthetic import make_config
+
+    X, V, _ = make_config("C3", N=400_000)
+    X[1000] = X[5]
+    a = vfm.sparsevfc_preprocess(X, V, M=300, seed=0, device="cuda:0")
+    old = vfm._DEVICE_UNIQUE_MIN_ROWS
+    vfm._DEVICE_UNIQUE_MIN_ROWS = 10**12  # force the host route
+    try:
+        b = vfm.sparsevfc_preprocess(X, V, M=300, seed=0)
+    finally:
+        vfm._DEVICE_UNIQUE_MIN_ROWS = old
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
