@@ -16,7 +16,8 @@ reference's own result moves when its LAPACK driver is swapped for a mathematica
 deviation is the reference noise floor, computed here for every case, and the GPU result (hand-written eigensolver with
 the same cut-off, no jitter knob) must sit within 2x of it or inside the mode's tolerance, whichever is larger.
 Float32 mode additionally carries the unavoidable effect of the data type itself: the same oracle run on kernel values
-rounded to float32 (U, K) gives the "float32 floor" used for that mode.
+computed in float32 arithmetic from float32 coordinates (U and K alike, as the float32 mode generates them) gives the
+"float32 floor" used for that mode.
 """
 import functools
 import os
@@ -51,6 +52,27 @@ def _eigh_solver(lhs, rhs, method=None):
     return (q[:, keep] / w[keep]) @ (q[:, keep].T @ rhs)
 
 
+def _con_K_float32_arithmetic(x, y, beta, *a, **k):
+    """con_K as the float32 mode computes it: coordinates centred on the control points and cast to float32, scaled by
+    sqrt(beta log2 e) in float32, squared distance accumulated in float32, exp2 in float32 (the arithmetic of
+    csrc/mvf_common.h::kernel_value<float>); returned as float64.  Used for the 'float32 floor': what the reference
+    algorithm itself yields when it is fed these kernel values."""
+    f32 = np.float32
+    x, y = np.atleast_2d(np.asarray(x, dtype=np.float64)), np.asarray(y, dtype=np.float64)
+    c = y.mean(0)
+    s = f32(np.sqrt(beta * 1.4426950408889634))
+    cy = (y - c).astype(f32) * s
+    out = np.empty((len(x), len(y)))
+    for lo in range(0, len(x), 16384):
+        px = (x[lo : lo + 16384] - c).astype(f32) * s
+        e = np.zeros((len(px), len(y)), dtype=f32)
+        for j in range(x.shape[1]):
+            d = px[:, j : j + 1] - cy[None, :, j]
+            e += d * d
+        out[lo : lo + 16384] = np.exp2(-e).astype(f32)
+    return out
+
+
 def _oracle_fit(X, V, Grid, solver=None, f32_kernel=False, **kw):
     """The oracle, optionally with its LAPACK driver swapped (noise floor) and / or with the kernel values rounded to
     float32 as the float32 mode generates them (float32 floor)."""
@@ -58,7 +80,7 @@ def _oracle_fit(X, V, Grid, solver=None, f32_kernel=False, **kw):
     if solver is not None:
         svo.lstsq_solver = solver
     if f32_kernel:
-        svo.con_K = lambda *a, **k: orig_conk(*a, **k).astype(np.float32).astype(np.float64)
+        svo.con_K = _con_K_float32_arithmetic
     try:
         return svo.SparseVFC(X, V, Grid, **kw)
     finally:
