@@ -275,12 +275,15 @@ def main():
             },
             "solve": {
                 "lstsq_method": eng.lstsq_method,
-                "path": "minimum-norm (Cholesky + one-sided block Jacobi eigensolver, eps*lambda_max cut-off)"
+                "path": (("minimum-norm (pivoted-Cholesky factor of rank r + one-sided block Jacobi on its r columns, "
+                          "eps*lambda_max cut-off)") if eng.mn_method == "lowrank" else
+                         "minimum-norm (Cholesky + one-sided block Jacobi eigensolver, eps*lambda_max cut-off)")
                         if eng.rank_deficient else "Cholesky (pivots certify full numerical rank)",
                 "avg_ms": float(np.mean(solve_ms)),
                 "share_of_step": float(np.mean(solve_ms)) / ms_per_step,
                 "jacobi_sweeps": eng.solver_stats["sweeps"][n_sweeps0:],
                 "kept_rank": eng.solver_stats["rank"][-1] if eng.solver_stats["rank"] else Mc,
+                "factor_rank": (eng.solver_stats.get("factor_rank") or [None])[-1],
                 "warm_start": bool(eng.warm_start),
                 "jitter": eng.jitter,
             },

@@ -179,6 +179,23 @@ int mvf_solve_minnorm(const double* G, const double* K, double lambda_sigma2, do
                       int reuse, double* basis, int warm, void* workspace, size_t workspace_bytes, void* stream);
 size_t mvf_solve_minnorm_basis_bytes(int64_t m);
 
+/* mvf_solve_minnorm_lr: the same truncated minimum-norm solve (same reference semantics: scipy.linalg.lstsq = gelsd,
+ * spateo/tdr/morphometrics/morphofield/sparsevfc.py:110,194,250; `_pinv`, spateo/alignment/methods/morpho_class.py:1287)
+ * through a RANK-REVEALING factor: greedy diagonally pivoted Cholesky  A = L L^T + E  (L m x r), stopped when every
+ * remaining diagonal entry is <= tolf * DBL_EPSILON * lambda_max (lambda_max from 8 power-iteration steps; trace(E)
+ * bounds ||E|| and sits at the rounding level of A), then one-sided block Jacobi on the r columns of L only, then
+ * C = sum over sigma_i^2 > rcond max sigma^2 of u_i (u_i^T R) / sigma_i^2.  In the EM's steady state r ~ 0.3 m at
+ * m = 3000 and the graded pivoted factor halves the sweep count; no shift, no retry ladder: info[0] != 0 only for
+ * non-finite input.  einfo (12 float64, device): [0] = sweeps (x.5 if max_sweeps was hit first), [1] = kept rank,
+ * [2] = max lambda, [3] = min kept lambda, [4] = 0, [5] = min lambda of the factor, [6] = r (columns of L).
+ * rank_hint (0 = none): the r of a nearby matrix (the previous EM iteration's) - that many pivot steps are enqueued
+ * before the first status read.  reuse != 0: apply the decomposition of the previous call on this workspace to another
+ * R (einfo[7..11] = this call's).  NOT asynchronous (status reads during the factorisation, one per Jacobi sweep). */
+size_t mvf_solve_minnorm_lr_workspace_bytes(int64_t m, int nrhs);
+int mvf_solve_minnorm_lr(const double* G, const double* K, double lambda_sigma2, double tolf, double rcond,
+                         const double* R, int64_t m, int nrhs, double* C, int* info, double* einfo, int max_sweeps,
+                         int reuse, int rank_hint, void* workspace, size_t workspace_bytes, void* stream);
+
 /* trace(C^T K C) -> out[0] (float64), the regulariser of the energy (App. A 5b). K: m x m, C: m x nrhs;
  * scratch >= m float64 (row partials, summed in row order). */
 int mvf_quadform(const double* K, const double* C, int64_t m, int nrhs, double* out, double* scratch, void* stream);

@@ -343,12 +343,12 @@ __global__ __launch_bounds__(256) void jac_update_kernel(double* __restrict__ Y,
 }
 
 // sig2[i] = ||Y_i||^2 and T[i][d] = Y_i . R[:, d]   (one wave per row of Y)
-__global__ __launch_bounds__(256) void jac_rowstat_kernel(const double* __restrict__ Y, int64_t mp, int64_t m,
-                                                          const double* __restrict__ R, int nrhs,
+__global__ __launch_bounds__(256) void jac_rowstat_kernel(const double* __restrict__ Y, int64_t nrows, int64_t mp,
+                                                          int64_t m, const double* __restrict__ R, int nrhs,
                                                           double* __restrict__ sig2, double* __restrict__ T) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
-    if (row >= mp) return;
+    if (row >= nrows) return;
     double s = 0.0, t[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) t[d] = 0.0;
@@ -411,13 +411,13 @@ __global__ __launch_bounds__(256) void jac_scale_kernel(const double* __restrict
 }
 
 // part[split][n][d] = sum over this split's rows i of Y[i][n] T[i][d]   (64 columns n per workgroup)
-__global__ __launch_bounds__(256) void jac_back_kernel(const double* __restrict__ Y, int64_t mp, int64_t m,
-                                                       const double* __restrict__ T, int rows_per_split,
+__global__ __launch_bounds__(256) void jac_back_kernel(const double* __restrict__ Y, int64_t nrows, int64_t mp,
+                                                       int64_t m, const double* __restrict__ T, int rows_per_split,
                                                        double* __restrict__ part) {
     __shared__ double red[4][64][8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n = (int64_t)blockIdx.x * 64 + lane;
-    const int64_t i0 = (int64_t)blockIdx.y * rows_per_split, i1 = min(mp, i0 + rows_per_split);
+    const int64_t i0 = (int64_t)blockIdx.y * rows_per_split, i1 = min(nrows, i0 + rows_per_split);
     double acc[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) acc[d] = 0.0;
@@ -548,6 +548,328 @@ __global__ __launch_bounds__(256) void basis_extract_kernel(const double* __rest
     Wt[i * mp + n] = s2 > 0.0 ? Y[i * mp + n] * (1.0 / sqrt(s2)) : (n == i ? 1.0 : 0.0);
 }
 
+
+// ================= rank-revealing path: diagonally pivoted Cholesky + one-sided Jacobi on the r kept columns ===========
+// A (numerically rank r << m: r ~ 0.3 m at m = 3000 in the EM's steady state) = L L^T + E with L m x r from the greedy
+// (largest remaining diagonal) pivoted Cholesky, stopped when every remaining diagonal is <= tol = tolf eps lambda_max:
+// trace(E) bounds ||E|| and sits at the rounding level of A itself, below the eps lambda_max cut-off the truncated solve
+// applies anyway.  The Jacobi iteration then orthogonalises r columns instead of m - and the pivoted factor is graded
+// (column norms fall with the pivots), which is the Veselic-Hari / Drmac preconditioner: 13 cold sweeps at m = 3000 where
+// the unpivoted shifted factor needs 26 - and no shift delta, no retry ladder.
+// Y (row j = column j of L, row length mp) is produced row by row: coalesced stores, and exactly the layout the Jacobi
+// kernels want.
+struct PcholState {
+    int done, r, pad0, pad1;
+    double tol, lmax_est, maxdiag, pad2;
+};
+
+// y = A x, one wave per row (the power iteration that estimates lambda_max for the stopping tolerance)
+__global__ __launch_bounds__(256) void lr_symv_kernel(const double* __restrict__ A, int64_t mp,
+                                                      const double* __restrict__ x, double* __restrict__ y) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= mp) return;
+    const double* a = A + row * mp;
+    double s = 0.0;
+    for (int64_t n = lane; n < mp; n += 64) s = fma(a[n], x[n], s);
+    s = wave_sum(s);
+    if (lane == 0) y[row] = s;
+}
+
+// first = 1: x = 1 / sqrt(m) on the live entries.  Else: est = x^T y (x has unit norm: the Rayleigh quotient, a lower
+// bound of lambda_max that converges from below), x = y / ||y||.
+__global__ __launch_bounds__(256) void lr_power_kernel(double* __restrict__ x, const double* __restrict__ y, int64_t m,
+                                                       int64_t mp, int first, PcholState* __restrict__ stt) {
+    __shared__ double red[4];
+    __shared__ double bc[2];
+    if (first) {
+        const double v = 1.0 / sqrt((double)m);
+        for (int64_t i = threadIdx.x; i < mp; i += 256) x[i] = i < m ? v : 0.0;
+        if (threadIdx.x == 0) stt->lmax_est = 0.0;
+        return;
+    }
+    double xy = 0.0, yy = 0.0;
+    for (int64_t i = threadIdx.x; i < mp; i += 256) {
+        xy = fma(x[i], y[i], xy);
+        yy = fma(y[i], y[i], yy);
+    }
+    const double t0 = block_sum<256>(xy, red);
+    const double t1 = block_sum<256>(yy, red);
+    if (threadIdx.x == 0) {
+        bc[0] = t0;
+        bc[1] = t1;
+    }
+    __syncthreads();
+    const double inv = bc[1] > 0.0 ? 1.0 / sqrt(bc[1]) : 0.0;
+    for (int64_t i = threadIdx.x; i < mp; i += 256) x[i] = y[i] * inv;
+    if (threadIdx.x == 0) stt->lmax_est = bc[0];
+}
+
+constexpr int PC_T = 128;  // threads (= columns of A) per workgroup of the pivot step
+
+// dg[i] = A_ii (-inf on the padding: never a pivot), per-workgroup (max, argmax) partials, the tolerance, the state
+__global__ __launch_bounds__(256) void pchol_init_kernel(const double* __restrict__ S, int64_t m, int64_t mp, double tolf,
+                                                         double* __restrict__ dg, double* __restrict__ pm, int nwg,
+                                                         PcholState* __restrict__ stt, int* __restrict__ info) {
+    __shared__ double red[4];
+    __shared__ double bc[2];
+    double mx = 0.0;
+    bool finite = true;
+    for (int64_t i = threadIdx.x; i < mp; i += 256) {
+        const double d = i < m ? S[i * mp + i] : -INFINITY;
+        dg[i] = d;
+        if (i < m) {
+            finite = finite && (fabs(d) <= 1.79e308);
+            mx = fmax(mx, d);
+        }
+    }
+    const double bad = block_sum<256>(finite ? 0.0 : 1.0, red);
+    const double t = -block_min<256>(-mx, red);
+    if (threadIdx.x == 0) {
+        bc[0] = bad;
+        bc[1] = t;
+    }
+    __syncthreads();
+    // partials: workgroup w of the step kernel owns columns [w PC_T, (w + 1) PC_T)
+    for (int w = threadIdx.x; w < nwg; w += 256) {
+        double bv = -INFINITY;
+        int bi = w * PC_T;
+        for (int q = 0; q < PC_T; ++q) {
+            const int64_t i = (int64_t)w * PC_T + q;
+            const double d = (i < m) ? S[i * mp + i] : -INFINITY;
+            if (d > bv) {
+                bv = d;
+                bi = (int)i;
+            }
+        }
+        pm[2 * w] = bv;
+        pm[2 * w + 1] = (double)bi;
+    }
+    if (threadIdx.x == 0) {
+        const double est = stt->lmax_est;
+        const bool ok = bc[0] == 0.0 && (fabs(est) <= 1.79e308);
+        const double lmax = fmax(ok ? est : 0.0, bc[1]);
+        stt->done = 0;
+        stt->r = 0;
+        stt->maxdiag = bc[1];
+        stt->lmax_est = lmax;
+        stt->tol = tolf * 2.220446049250313e-16 * lmax;
+        info[0] = ok ? 0 : 1;
+    }
+}
+
+// One pivot step (launch j): p = argmax of the remaining diagonal (from the per-workgroup partials the previous launch
+// left; ties -> lowest index); row j of Y = (S[p, :] - sum over this block's earlier rows k of Y[k, :] Y[k, p]) / sqrt(pivot)
+// (S carries the trailing updates of all earlier blocks: LAPACK pstrf's lazy scheme); dg -= y^2.  Every thread
+// accumulates the pivot value itself (same scalars, same order: bit-identical across the grid), so there is no second
+// pass and no communication between workgroups inside a step.  dg / pm are double-buffered between launches.
+__global__ __launch_bounds__(PC_T) void pchol_step_kernel(const double* __restrict__ S, double* __restrict__ Y, int64_t mp,
+                                                          int jb, int j, const double* __restrict__ dg_in,
+                                                          double* __restrict__ dg_out, const double* __restrict__ pm_in,
+                                                          double* __restrict__ pm_out, int nwg,
+                                                          PcholState* __restrict__ stt, int* __restrict__ order,
+                                                          double* __restrict__ piv) {
+    if (stt->done) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    double bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int q = lane; q < nwg; q += 64) {
+        const double v = pm_in[2 * q];
+        const int ix = (int)pm_in[2 * q + 1];
+        if (v > bv || (v == bv && ix < bi)) {
+            bv = v;
+            bi = ix;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double v = __shfl_xor(bv, o, 64);
+        const int ix = __shfl_xor(bi, o, 64);
+        if (v > bv || (v == bv && ix < bi)) {
+            bv = v;
+            bi = ix;
+        }
+    }
+    const double tol = stt->tol;
+    if (!(bv > tol)) {
+        if (blockIdx.x == 0 && tid == 0) stt->done = 1;
+        return;
+    }
+    const int64_t p = bi;
+    const int64_t i = (int64_t)blockIdx.x * PC_T + tid;
+    const bool live = i < mp;
+    const int64_t ic = live ? i : 0;
+    double acc = S[p * mp + ic], accp = S[p * mp + p];
+    const double* yk = Y + (int64_t)jb * mp;
+    int k = jb;
+    for (; k + 4 <= j; k += 4, yk += 4 * mp) {
+        const double p0 = yk[p], p1 = yk[mp + p], p2 = yk[2 * mp + p], p3 = yk[3 * mp + p];
+        const double a0 = yk[ic], a1 = yk[mp + ic], a2 = yk[2 * mp + ic], a3 = yk[3 * mp + ic];
+        acc = fma(-a0, p0, acc);
+        accp = fma(-p0, p0, accp);
+        acc = fma(-a1, p1, acc);
+        accp = fma(-p1, p1, accp);
+        acc = fma(-a2, p2, acc);
+        accp = fma(-p2, p2, accp);
+        acc = fma(-a3, p3, acc);
+        accp = fma(-p3, p3, accp);
+    }
+    for (; k < j; ++k, yk += mp) {
+        const double p0 = yk[p], a0 = yk[ic];
+        acc = fma(-a0, p0, acc);
+        accp = fma(-p0, p0, accp);
+    }
+    const double di = dg_in[ic];
+    const bool used = !live || di == -INFINITY;
+    // a pivot the fresh evaluation does not confirm (dg drifted): retire p with an all-zero row
+    const bool badp = !(accp > 0.25 * tol);
+    const double inv = badp ? 0.0 : 1.0 / sqrt(accp);
+    const double y = (used || badp) ? 0.0 : acc * inv;
+    const double dn = (used || i == p) ? -INFINITY : di - y * y;
+    if (live) {
+        Y[(int64_t)j * mp + i] = y;
+        dg_out[i] = dn;
+    }
+    // this workgroup's (max, argmax) of the new diagonal for the next launch
+    __shared__ double sv[PC_T / 64];
+    __shared__ int si[PC_T / 64];
+    double wv = live ? dn : -INFINITY;
+    int wi = live ? (int)i : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double v = __shfl_xor(wv, o, 64);
+        const int ix = __shfl_xor(wi, o, 64);
+        if (v > wv || (v == wv && ix < wi)) {
+            wv = v;
+            wi = ix;
+        }
+    }
+    if (lane == 0) {
+        sv[tid >> 6] = wv;
+        si[tid >> 6] = wi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double v = sv[0];
+        int ix = si[0];
+#pragma unroll
+        for (int w = 1; w < PC_T / 64; ++w)
+            if (sv[w] > v || (sv[w] == v && si[w] < ix)) {
+                v = sv[w];
+                ix = si[w];
+            }
+        pm_out[2 * blockIdx.x] = v;
+        pm_out[2 * blockIdx.x + 1] = (double)ix;
+        if (blockIdx.x == 0) {
+            order[j] = (int)p;
+            piv[j] = accp;
+            stt->r = j + 1;
+        }
+    }
+}
+
+// trailing update after a block of 64 pivot steps:  S -= Yb^T Yb,  Yb = rows jb .. jb + 63 of Y (64 x 64 tile per
+// workgroup, f64 MFMA, both operand tiles staged k-major in LDS)
+__global__ __launch_bounds__(256) void pchol_update_kernel(double* __restrict__ S, const double* __restrict__ Y,
+                                                           int64_t mp, int jb, const PcholState* __restrict__ stt) {
+    if (stt->done) return;
+    __shared__ double sa[JP * LDK];
+    __shared__ double sb[JP * LDK];
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        double va[16], vb[16];
+        const double* ya = Y + (int64_t)jb * mp + (int64_t)ti * 64 + lane;
+        const double* yb = Y + (int64_t)jb * mp + (int64_t)tj * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            va[q] = ya[(int64_t)(wave + 4 * q) * mp];
+            vb[q] = yb[(int64_t)(wave + 4 * q) * mp];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            sa[(wave + 4 * q) * LDK + lane] = va[q];
+            sb[(wave + 4 * q) * LDK + lane] = vb[q];
+        }
+    }
+    __syncthreads();
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    const int li = lane & 15, lk = lane >> 4;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int kk = 0; kk < 64; kk += 4) {
+        double fa[2], fb[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            fa[a] = sa[(kk + lk) * LDK + wr + a * 16 + li];  // A[i][k] = Yb[k][ti 64 + i]
+            fb[a] = sb[(kk + lk) * LDK + wc + a * 16 + li];  // B[k][j] = Yb[k][tj 64 + j]
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+    double* pc = S + ((int64_t)ti * 64) * mp + (int64_t)tj * 64;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr + a * 16 + lk + 4 * r;
+                const int col = wc + b * 16 + li;
+                pc[(int64_t)row * mp + col] -= acc[a][b][r];
+            }
+}
+
+struct LrPlan {
+    int64_t mp;
+    int nbmax, npmax, nwg, spart_tiles;
+    size_t off_s, off_y, off_dg, off_pm, off_x, off_state, off_order, off_piv, off_spart, off_j, off_flags, off_stamps,
+        off_sig2, off_t, off_part, off_rot, off_scal, total;
+};
+
+constexpr int LR_GRAM_WGS = 512;  // workgroups per Jacobi Gram launch (pairs x K splits)
+
+static LrPlan lr_plan(int64_t m) {
+    LrPlan p;
+    p.mp = cdiv(m, 64) * 64;
+    p.nbmax = (int)(p.mp / JB);
+    p.npmax = p.nbmax / 2;
+    p.nwg = (int)cdiv(p.mp, PC_T);
+    p.spart_tiles = LR_GRAM_WGS + p.npmax;  // >= npairs * nsplit for every rank
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o += align_up(bytes, 256);
+        return at;
+    };
+    p.off_s = take((size_t)p.mp * p.mp * sizeof(double));
+    p.off_y = take((size_t)p.mp * p.mp * sizeof(double));
+    p.off_dg = take((size_t)2 * p.mp * sizeof(double));
+    p.off_pm = take((size_t)4 * p.nwg * sizeof(double));
+    p.off_x = take((size_t)2 * p.mp * sizeof(double));
+    p.off_state = take(sizeof(PcholState));
+    p.off_order = take((size_t)p.mp * sizeof(int));
+    p.off_piv = take((size_t)p.mp * sizeof(double));
+    p.off_spart = take((size_t)p.spart_tiles * JP * JP * sizeof(double));
+    p.off_j = take((size_t)p.npmax * JP * JP * sizeof(double));
+    p.off_flags = take((size_t)p.npmax * sizeof(int));
+    p.off_stamps = take((size_t)(p.nbmax + (size_t)p.nbmax * p.nbmax) * sizeof(int));
+    p.off_sig2 = take((size_t)p.mp * sizeof(double));
+    p.off_t = take((size_t)p.mp * 8 * sizeof(double));
+    p.off_part = take((size_t)16 * m * 8 * sizeof(double));
+    p.off_rot = take(256);
+    p.off_scal = take(256);
+    p.total = o;
+    return p;
+}
+
 struct JacPlan {
     int64_t mp;
     int nb, npairs, nsplit, kchunks, bsplit, rows_per_split;
@@ -644,9 +966,9 @@ extern "C" int mvf_solve_minnorm(const double* G, const double* K, double lambda
         // the workspace still holds the orthogonalised factor (Y, sig2) and delta of the previous call for this matrix
         CholPlan cq;
         chol_layout(m, 0, workspace, &cq);
-        hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(mp, 4)), dim3(256), 0, st, Y, mp, m, R, nrhs, sig2, T);
+        hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(mp, 4)), dim3(256), 0, st, Y, mp, mp, m, R, nrhs, sig2, T);
         hipLaunchKernelGGL(jac_scale_kernel, dim3(1), dim3(256), 0, st, sig2, mp, cq.scal, rcond, T, einfo + 6);
-        hipLaunchKernelGGL(jac_back_kernel, dim3((unsigned)cdiv(mp, 64), (unsigned)p.bsplit), dim3(256), 0, st, Y, mp, m,
+        hipLaunchKernelGGL(jac_back_kernel, dim3((unsigned)cdiv(mp, 64), (unsigned)p.bsplit), dim3(256), 0, st, Y, mp, mp, m,
                            T, p.rows_per_split, part);
         hipLaunchKernelGGL(jac_back_reduce_kernel, dim3((unsigned)cdiv(m * nrhs, 256)), dim3(256), 0, st, part,
                            p.bsplit, m, nrhs, C);
@@ -714,9 +1036,9 @@ extern "C" int mvf_solve_minnorm(const double* G, const double* K, double lambda
     }
 
     // 3. truncated minimum-norm solve
-    hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(mp, 4)), dim3(256), 0, st, Y, mp, m, R, nrhs, sig2, T);
+    hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(mp, 4)), dim3(256), 0, st, Y, mp, mp, m, R, nrhs, sig2, T);
     hipLaunchKernelGGL(jac_scale_kernel, dim3(1), dim3(256), 0, st, sig2, mp, cp.scal, rcond, T, einfo);
-    hipLaunchKernelGGL(jac_back_kernel, dim3((unsigned)cdiv(mp, 64), (unsigned)p.bsplit), dim3(256), 0, st, Y, mp, m, T,
+    hipLaunchKernelGGL(jac_back_kernel, dim3((unsigned)cdiv(mp, 64), (unsigned)p.bsplit), dim3(256), 0, st, Y, mp, mp, m, T,
                        p.rows_per_split, part);
     hipLaunchKernelGGL(jac_back_reduce_kernel, dim3((unsigned)cdiv(m * nrhs, 256)), dim3(256), 0, st, part, p.bsplit, m,
                        nrhs, C);
@@ -726,6 +1048,169 @@ extern "C" int mvf_solve_minnorm(const double* G, const double* K, double lambda
     MVF_LAUNCH_CHECK();
     const double hs[1] = {(double)sweeps + (hrot != 0 ? 0.5 : 0.0)};  // x.5 = sweep cap hit before convergence
     MVF_CHECK_HIP(hipMemcpyAsync(einfo, hs, sizeof(double), hipMemcpyHostToDevice, st));
+    MVF_CHECK_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" size_t mvf_solve_minnorm_lr_workspace_bytes(int64_t m, int nrhs) {
+    (void)nrhs;
+    if (m <= 0) return 0;
+    return lr_plan(m).total;
+}
+
+extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lambda_sigma2, double tolf, double rcond,
+                                    const double* R, int64_t m, int nrhs, double* C, int* info, double* einfo,
+                                    int max_sweeps, int reuse, int rank_hint, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    MVF_REQUIRE(m >= 0 && nrhs >= 1 && nrhs <= 8,
+                "mvf_solve_minnorm_lr: need m >= 0 and 1 <= nrhs <= 8 (got m=%lld nrhs=%d)", (long long)m, nrhs);
+    MVF_REQUIRE(info && einfo, "mvf_solve_minnorm_lr: null info / einfo");
+    hipStream_t st = (hipStream_t)stream;
+    if (m == 0) {
+        MVF_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+        return 0;
+    }
+    MVF_REQUIRE(G && K && R && C, "mvf_solve_minnorm_lr: null pointer");
+    MVF_REQUIRE(std::isfinite(lambda_sigma2) && lambda_sigma2 >= 0.0 && tolf > 0.0 && tolf <= 1.0 && rcond >= 0.0,
+                "mvf_solve_minnorm_lr: bad regularisation / tolerance factor / rcond");
+    MVF_REQUIRE(m <= 65535 - 64, "mvf_solve_minnorm_lr: m too large (%lld)", (long long)m);
+    if (max_sweeps <= 0) max_sweeps = 60;
+    const LrPlan p = lr_plan(m);
+    MVF_REQUIRE(workspace && workspace_bytes >= p.total, "mvf_solve_minnorm_lr: workspace too small (%zu < %zu)",
+                workspace_bytes, p.total);
+    char* ws = (char*)workspace;
+    double* S = (double*)(ws + p.off_s);
+    double* Y = (double*)(ws + p.off_y);
+    double* dg = (double*)(ws + p.off_dg);
+    double* pm = (double*)(ws + p.off_pm);
+    double* xv = (double*)(ws + p.off_x);
+    PcholState* stt = (PcholState*)(ws + p.off_state);
+    int* order = (int*)(ws + p.off_order);
+    double* piv = (double*)(ws + p.off_piv);
+    double* Spart = (double*)(ws + p.off_spart);
+    double* Jbuf = (double*)(ws + p.off_j);
+    int* flags = (int*)(ws + p.off_flags);
+    int* mod = (int*)(ws + p.off_stamps);
+    double* sig2 = (double*)(ws + p.off_sig2);
+    double* T = (double*)(ws + p.off_t);
+    double* part = (double*)(ws + p.off_part);
+    unsigned int* rot = (unsigned int*)(ws + p.off_rot);
+    double* scal = (double*)(ws + p.off_scal);
+    const int64_t mp = p.mp;
+    PcholState hs;
+
+    // the truncated solve from the orthogonalised factor (rows of Y = sigma_i u_i^T): C = Y^T (g .* (Y R))
+    auto backsolve = [&](int64_t rp, double* ei) -> int {
+        const int bsplit = (int)std::min<int64_t>(16, rp / 64);
+        const int rows_per_split = (int)cdiv(rp, bsplit);
+        hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(rp, 4)), dim3(256), 0, st, Y, rp, mp, m, R, nrhs, sig2, T);
+        hipLaunchKernelGGL(jac_scale_kernel, dim3(1), dim3(256), 0, st, sig2, rp, scal, rcond, T, ei);
+        hipLaunchKernelGGL(jac_back_kernel, dim3((unsigned)cdiv(mp, 64), (unsigned)bsplit), dim3(256), 0, st, Y, rp, mp, m,
+                           T, rows_per_split, part);
+        hipLaunchKernelGGL(jac_back_reduce_kernel, dim3((unsigned)cdiv(m * nrhs, 256)), dim3(256), 0, st, part, bsplit, m,
+                           nrhs, C);
+        MVF_LAUNCH_CHECK();
+        return 0;
+    };
+
+    if (reuse) {
+        // the workspace still holds the orthogonalised factor of the previous call for this matrix
+        MVF_CHECK_HIP(hipMemcpyAsync(&hs, stt, sizeof(hs), hipMemcpyDeviceToHost, st));
+        MVF_CHECK_HIP(hipStreamSynchronize(st));
+        MVF_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+        if (hs.r <= 0) {
+            MVF_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)m * nrhs * sizeof(double), st));
+            return 0;
+        }
+        return backsolve(cdiv(hs.r, 64) * 64, einfo + 6);
+    }
+
+    // 1. S = G + ls2 K (zero padding), lambda_max estimate, pivoted Cholesky -> rows 0 .. r-1 of Y
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)cdiv(mp, 256), (unsigned)mp), dim3(256), 0, st, G, K, lambda_sigma2,
+                       m, mp, S);
+    MVF_CHECK_HIP(hipMemsetAsync(scal, 0, 256, st));
+    hipLaunchKernelGGL(lr_power_kernel, dim3(1), dim3(256), 0, st, xv, xv + mp, m, mp, 1, stt);
+    for (int it = 0; it < 8; ++it) {
+        hipLaunchKernelGGL(lr_symv_kernel, dim3((unsigned)cdiv(mp, 4)), dim3(256), 0, st, S, mp, xv, xv + mp);
+        hipLaunchKernelGGL(lr_power_kernel, dim3(1), dim3(256), 0, st, xv, xv + mp, m, mp, 0, stt);
+    }
+    hipLaunchKernelGGL(pchol_init_kernel, dim3(1), dim3(256), 0, st, S, m, mp, tolf, dg, pm, p.nwg, stt, info);
+    MVF_LAUNCH_CHECK();
+    int j = 0, cur = 0;
+    const int msteps = (int)m;
+    const dim3 ugrid((unsigned)(mp / 64), (unsigned)(mp / 64));
+    auto enqueue = [&](int upto) {
+        while (j < upto) {
+            const int jb = j & ~63;
+            hipLaunchKernelGGL(pchol_step_kernel, dim3((unsigned)p.nwg), dim3(PC_T), 0, st, S, Y, mp, jb, j,
+                               dg + (size_t)cur * mp, dg + (size_t)(cur ^ 1) * mp, pm + (size_t)cur * 2 * p.nwg,
+                               pm + (size_t)(cur ^ 1) * 2 * p.nwg, p.nwg, stt, order, piv);
+            cur ^= 1;
+            ++j;
+            if ((j & 63) == 0 && j < msteps)
+                hipLaunchKernelGGL(pchol_update_kernel, ugrid, dim3(256), 0, st, S, Y, mp, jb, stt);
+        }
+    };
+    int upto = rank_hint > 0 ? (int)std::min<int64_t>(msteps, cdiv(rank_hint + 8, 64) * 64) : std::min(msteps, 256);
+    int hinfo = 0;
+    while (true) {
+        enqueue(upto);
+        MVF_LAUNCH_CHECK();
+        MVF_CHECK_HIP(hipMemcpyAsync(&hs, stt, sizeof(hs), hipMemcpyDeviceToHost, st));
+        MVF_CHECK_HIP(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, st));
+        MVF_CHECK_HIP(hipStreamSynchronize(st));
+        if (hinfo != 0) return 0;  // non-finite input: info[0] tells the caller
+        if (hs.done || j >= msteps) break;
+        upto = std::min(msteps, upto + 128);
+    }
+    const int64_t r = hs.r;
+    const double hr[1] = {(double)r};
+    MVF_CHECK_HIP(hipMemcpyAsync(einfo + 6, hr, sizeof(double), hipMemcpyHostToDevice, st));
+    if (r == 0) {  // the zero matrix: minimum-norm solution 0
+        MVF_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)m * nrhs * sizeof(double), st));
+        MVF_CHECK_HIP(hipMemsetAsync(einfo, 0, 6 * sizeof(double), st));
+        MVF_CHECK_HIP(hipStreamSynchronize(st));
+        return 0;
+    }
+    const int64_t rp = cdiv(r, 64) * 64;
+    if (rp > r) MVF_CHECK_HIP(hipMemsetAsync(Y + r * mp, 0, (size_t)(rp - r) * mp * sizeof(double), st));
+
+    // 2. one-sided block Jacobi on the r rows of Y
+    const int nb = (int)(rp / JB), npairs = nb / 2, nk = (int)(mp / 64);
+    int nsplit = std::min(nk, std::max(1, LR_GRAM_WGS / npairs));
+    const int kchunks = (int)cdiv(nk, nsplit);
+    nsplit = (int)cdiv(nk, kchunks);
+    const double tol = std::sqrt((double)m) * 2.220446049250313e-16;
+    int* clean = mod + nb;
+    MVF_CHECK_HIP(hipMemsetAsync(mod, 0, (size_t)(nb + (size_t)nb * nb) * sizeof(int), st));  // all pairs dirty
+    int sweeps = 0;
+    unsigned int hrot = 1;
+    while (sweeps < max_sweeps) {
+        MVF_CHECK_HIP(hipMemsetAsync(rot, 0, sizeof(unsigned int), st));
+        for (int rd = 0; rd < nb - 1; ++rd) {
+            const int stamp = 1 + sweeps * (nb - 1) + rd;
+            hipLaunchKernelGGL(jac_gram_kernel, dim3((unsigned)npairs, (unsigned)nsplit), dim3(256), 0, st, Y, mp, nb, rd,
+                               nsplit, kchunks, mod, clean, Spart);
+            if (rd == 0)
+                hipLaunchKernelGGL(jac_eig_kernel<true>, dim3((unsigned)npairs), dim3(EIG_THREADS), 0, st, Spart, nsplit,
+                                   tol, nb, rd, stamp, mod, clean, Jbuf, flags, rot);
+            else
+                hipLaunchKernelGGL(jac_eig_kernel<false>, dim3((unsigned)npairs), dim3(EIG_THREADS), 0, st, Spart, nsplit,
+                                   tol, nb, rd, stamp, mod, clean, Jbuf, flags, rot);
+            hipLaunchKernelGGL(jac_update_kernel, dim3((unsigned)npairs, (unsigned)(mp / 64)), dim3(256), 0, st, Y, mp, nb,
+                               rd, Jbuf, flags);
+        }
+        MVF_LAUNCH_CHECK();
+        ++sweeps;
+        MVF_CHECK_HIP(hipMemcpyAsync(&hrot, rot, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        MVF_CHECK_HIP(hipStreamSynchronize(st));
+        if (hrot == 0) break;
+    }
+
+    // 3. truncated minimum-norm solve
+    if (int rc = backsolve(rp, einfo)) return rc;
+    const double hsw[1] = {(double)sweeps + (hrot != 0 ? 0.5 : 0.0)};  // x.5 = sweep cap hit before convergence
+    MVF_CHECK_HIP(hipMemcpyAsync(einfo, hsw, sizeof(double), hipMemcpyHostToDevice, st));
     MVF_CHECK_HIP(hipStreamSynchronize(st));
     return 0;
 }

@@ -49,6 +49,7 @@ class HipKernels:
         self._gram_ws = None
         self._solve_ws = None
         self._mn_ws = None
+        self._lr_ws = None
         self._mins = torch.empty(_lib.MVF_ESTEP_MIN_DOUBLES, dtype=torch.float64, device=self.device)
         self._scratch = None  # per-workgroup partials of the deterministic reductions (apply / estep_p / quadform)
         # optional per-launch timing of the dominant (Gram MFMA) kernel: list of (start, end) torch events recorded
@@ -243,6 +244,25 @@ class HipKernels:
                                               nrhs, _ptr(C_out), _ptr(info), _ptr(einfo), int(max_sweeps),
                                               1 if reuse else 0, _ptr(basis), 1 if warm else 0, _ptr(self._mn_ws),
                                               self._mn_ws.numel(), self._stream()), "mvf_solve_minnorm")
+
+    @_on_device
+    def solve_minnorm_lr(self, G, K, lambda_sigma2, R, C_out, info, einfo, rcond=None, reuse=False, max_sweeps=60,
+                         rank_hint=0, tolf=0.25):
+        """The same truncated minimum-norm solve through the rank-revealing factor (pivoted Cholesky stopped at
+        tolf * eps * lambda_max, Jacobi on the r kept columns only).  einfo[6] = r; pass it back as ``rank_hint`` for
+        the next, nearby matrix.  Synchronises the stream."""
+        m, nrhs = R.shape
+        need = self.lib.mvf_solve_minnorm_lr_workspace_bytes(m, nrhs)
+        if self._lr_ws is None or self._lr_ws.numel() < need:
+            if reuse:
+                raise RuntimeError("solve_minnorm_lr(reuse=True) without a previous decomposition")
+            self._lr_ws = None
+            self._lr_ws = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
+        rc = float(np.finfo(np.float64).eps) if rcond is None else float(rcond)
+        _lib.check(self.lib.mvf_solve_minnorm_lr(_ptr(G), _ptr(K), float(lambda_sigma2), float(tolf), rc, _ptr(R), m,
+                                                 nrhs, _ptr(C_out), _ptr(info), _ptr(einfo), int(max_sweeps),
+                                                 1 if reuse else 0, int(rank_hint), _ptr(self._lr_ws),
+                                                 self._lr_ws.numel(), self._stream()), "mvf_solve_minnorm_lr")
 
     @_on_device
     def minnorm_basis(self, m):

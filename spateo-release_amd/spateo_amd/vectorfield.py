@@ -15,6 +15,7 @@ of ``[G | R | scalars]`` per EM step.
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -296,6 +297,10 @@ class SparseVFCEngine:
         self.pivots = k.zeros(2, dtype=f64)
         self.einfo = k.zeros(12, dtype=f64)
         self.basis, self.basis_valid, self.warm_start = None, False, True
+        # "lowrank": pivoted-Cholesky factor + Jacobi on its r columns (mvf_solve_minnorm_lr); "full": Jacobi on all M
+        # columns of the shifted factor, warm-started (mvf_solve_minnorm)
+        self.mn_method = os.environ.get("MVF_MINNORM", "lowrank")
+        self.rank_hint = 0
         # lstsq_method="cholesky" (extension, not a reference mode): jitter-escalated Cholesky, the round-1 solver
         self.jitter = 0.0
         self.jitter_first = 1e-15
@@ -336,6 +341,7 @@ class SparseVFCEngine:
         self.E, self.tecr, self.iteration = 1.0, 1.0, 0
         self.rank_deficient = False
         self.basis_valid = False
+        self.rank_hint = 0
 
     def _apply_all(self, ctrl4):
         """V_g = U C_g for every column group; r = sum_g ||Y_g - V_g||^2; spr += sum P r."""
@@ -441,7 +447,25 @@ class SparseVFCEngine:
                 self.solver_stats["cholesky"] += 1
                 return h[3:]
             self.rank_deficient = True
-        # truncated minimum-norm solve (gelsd cut-off eps * max|lambda|); the shift only has to make the Cholesky
+        # truncated minimum-norm solve (gelsd cut-off eps * max|lambda|)
+        if self.mn_method == "lowrank" and hasattr(k, "solve_minnorm_lr"):
+            # rank-revealing factor (pivoted Cholesky) + Jacobi on the kept columns only; the previous iteration's factor
+            # rank tells how many pivot steps to enqueue before the first status read
+            self._solve_batch(batches[0], lambda R, C: k.solve_minnorm_lr(self.G, self.K, ls2, R, C, self.info, self.einfo,
+                                                                          rank_hint=self.rank_hint))
+            h = self._host_stats(self.info, self.einfo)
+            if int(h[0]) != 0:
+                raise _lib.MVFError("coefficient solve failed: G + lambda sigma^2 K has non-finite entries")
+            self.rank_hint = int(h[1 + 6])
+            for gs in batches[1:]:
+                self._solve_batch(gs, lambda R, C: k.solve_minnorm_lr(self.G, self.K, ls2, R, C, self.info, self.einfo,
+                                                                      reuse=True))
+            self.solver_stats["minnorm"] += 1
+            self.solver_stats["sweeps"].append(float(h[1]))
+            self.solver_stats["rank"].append(int(h[2]))
+            self.solver_stats.setdefault("factor_rank", []).append(self.rank_hint)
+            return h[1 + 12:]
+        # mn_method = "full": Jacobi on all M columns of the shifted Cholesky factor; the shift only has to make the
         # factorisation inside the eigensolver exist, it is subtracted from the eigenvalues again.
         # warm start: the previous EM iteration's eigenvectors pre-diagonalise this iteration's matrix
         if self.basis is None and hasattr(k, "minnorm_basis"):

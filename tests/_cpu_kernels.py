@@ -121,6 +121,54 @@ class CpuKernels:
         einfo[:6] = torch.tensor([1.0, keep.sum(), np.abs(w).max(), np.abs(w[keep]).min(), shift * np.trace(_np(G)) / len(w),
                                   w.min()], dtype=torch.float64)
 
+    def solve_minnorm_lr(self, G, K, lambda_sigma2, R, C_out, info, einfo, rcond=None, reuse=False, max_sweeps=60,
+                         rank_hint=0, tolf=0.25):
+        """The device algorithm restated: greedy diagonally pivoted Cholesky stopped at tolf * eps * lambda_max, then the
+        SVD of the m x r factor (what the one-sided Jacobi iteration converges to), truncated at rcond * sigma_max^2."""
+        rc = np.finfo(float).eps if rcond is None else rcond
+        if not reuse:
+            A = _np(G) + lambda_sigma2 * _np(K)
+            A = (A + A.T) / 2
+            m = len(A)
+            if not np.isfinite(A).all():
+                info.fill_(1)
+                return
+            lmax = max(float(np.linalg.eigvalsh(A)[-1]), float(np.diag(A).max()), 0.0)
+            tol = tolf * np.finfo(float).eps * lmax
+            dg = np.diag(A).copy()
+            L = np.zeros((m, m))
+            used = np.zeros(m, bool)
+            r = 0
+            while r < m:
+                dm = np.where(used, -np.inf, dg)
+                p = int(np.argmax(dm))
+                if not dm[p] > tol:
+                    break
+                c = A[:, p] - L[:, :r] @ L[p, :r]
+                c[used] = 0.0
+                if c[p] > 0.25 * tol:
+                    c /= np.sqrt(c[p])
+                    L[:, r] = c
+                    dg -= c * c
+                used[p] = True
+                r += 1
+            u, s, _ = np.linalg.svd(L[:, :r], full_matrices=False) if r else (np.zeros((m, 0)), np.zeros(0), None)
+            self._lr = (u, s * s, r)
+        u, lam, r = self._lr
+        info.zero_()
+        if r == 0:
+            C_out.zero_()
+            einfo[:7] = 0.0
+            return
+        keep = lam > rc * lam.max()
+        c = (u[:, keep] / lam[keep]) @ (u[:, keep].T @ _np(R))
+        C_out.copy_(torch.from_numpy(c))
+        o = 6 if reuse else 0
+        einfo[o + 1 : o + 6] = torch.tensor([keep.sum(), lam.max(), lam[keep].min(), 0.0, lam.min()], dtype=torch.float64)
+        if not reuse:
+            einfo[0] = 1.0
+            einfo[6] = float(r)
+
     def sym_pack(self, G, tri):
         g = _np(G)
         tri.copy_(torch.from_numpy(g[np.triu_indices(len(g))]))

@@ -269,25 +269,35 @@ def _minnorm_ref(A, R, rcond=np.finfo(float).eps):
     return (q[:, keep] / w[keep]) @ (q[:, keep].T @ R), w, keep
 
 
-def _run_minnorm(k, G, K, ls2, R, shift=2.0 ** -36, reuse_R=None, rcond=None):
+METHODS = ["lowrank", "full"]  # mvf_solve_minnorm_lr (pivoted-Cholesky factor) / mvf_solve_minnorm (all m columns)
+
+
+def _run_minnorm(k, G, K, ls2, R, shift=2.0 ** -36, reuse_R=None, rcond=None, method="full", rank_hint=0):
     dev = "cuda:0"
     m, nrhs = R.shape
     Gd, Kd, Rd = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (G, K, R))
     C = torch.empty(m, nrhs, dtype=torch.float64, device=dev)
     info = torch.zeros(1, dtype=torch.int32, device=dev)
     einfo = torch.zeros(12, dtype=torch.float64, device=dev)
-    k.solve_minnorm(Gd, Kd, ls2, shift, Rd, C, info, einfo, rcond=rcond)
+    if method == "lowrank":
+        def run(Rt, Ct, **kw):
+            k.solve_minnorm_lr(Gd, Kd, ls2, Rt, Ct, info, einfo, rcond=rcond, rank_hint=rank_hint, **kw)
+    else:
+        def run(Rt, Ct, **kw):
+            k.solve_minnorm(Gd, Kd, ls2, shift, Rt, Ct, info, einfo, rcond=rcond, **kw)
+    run(Rd, C)
     out = [C.cpu().numpy(), int(info.cpu()[0]), einfo.cpu().numpy()]
     if reuse_R is not None:
         R2 = torch.from_numpy(np.ascontiguousarray(reuse_R)).to(dev)
         C2 = torch.empty_like(R2)
-        k.solve_minnorm(Gd, Kd, ls2, shift, R2, C2, info, einfo, reuse=True)
+        run(R2, C2, reuse=True)
         out.append(C2.cpu().numpy())
     return out
 
 
+@pytest.mark.parametrize("method", METHODS)
 @pytest.mark.parametrize("m,nrhs", [(2, 1), (33, 3), (64, 3), (100, 6), (300, 2), (517, 8)])
-def test_solve_minnorm_full_rank_equals_the_inverse(st, m, nrhs):
+def test_solve_minnorm_full_rank_equals_the_inverse(st, m, nrhs, method):
     """Well conditioned SPD system: nothing is truncated, the minimum-norm solve is the ordinary solve; the reported
     extreme eigenvalues are LAPACK's."""
     rng = np.random.default_rng(m)
@@ -297,25 +307,30 @@ def test_solve_minnorm_full_rank_equals_the_inverse(st, m, nrhs):
     K = Kc @ Kc.T / m
     R = rng.standard_normal((m, nrhs))
     ls2 = 0.37
-    C, info, e, C2 = _run_minnorm(_k("float64"), G, K, ls2, R, reuse_R=R[:, :1] * 2.0)
+    C, info, e, C2 = _run_minnorm(_k("float64"), G, K, ls2, R, reuse_R=R[:, :1] * 2.0, method=method)
     assert info == 0 and e[0] == np.floor(e[0]) and e[0] < 40, e  # converged (x.5 would mean the sweep cap was hit)
     w = np.linalg.eigvalsh(G + ls2 * K)
     assert int(e[1]) == m
+    if method == "lowrank":
+        assert int(e[6]) == m  # the factor keeps every column of a well-conditioned matrix
     np.testing.assert_allclose([e[2], e[3]], [w.max(), w.min()], rtol=1e-10)
     assert _relmax(C, np.linalg.solve(G + ls2 * K, R)) < 1e-9
     assert _relmax(C2, 2.0 * C[:, :1]) < 1e-12  # reuse applies the same decomposition to another right-hand side
 
 
+@pytest.mark.parametrize("method", METHODS)
 @pytest.mark.parametrize("m,rank", [(96, 40), (200, 1), (257, 130)])
-def test_solve_minnorm_exactly_rank_deficient(st, m, rank):
+def test_solve_minnorm_exactly_rank_deficient(st, m, rank, method):
     """A = B B^T with B m x rank: with a cut-off above the rounding level of the null-space eigenvalues (rcond = 1e-12;
     at the default eps some of them land above it, for LAPACK just the same) the result is pinv(A) R."""
     rng = np.random.default_rng(rank)
     B = rng.standard_normal((m, rank))
     G = B @ B.T
     R = G @ rng.standard_normal((m, 3))  # consistent right-hand sides, as U^T P Y is for U^T P U
-    C, info, e = _run_minnorm(_k("float64"), G, np.zeros((m, m)), 0.0, R, rcond=1e-12)
+    C, info, e = _run_minnorm(_k("float64"), G, np.zeros((m, m)), 0.0, R, rcond=1e-12, method=method)
     assert info == 0 and int(e[1]) == rank
+    if method == "lowrank":
+        assert rank <= int(e[6]) <= rank + 8  # the pivoted factor stops at the rounding level of the matrix
     Cr = np.linalg.pinv(G, rcond=1e-13, hermitian=True) @ R
     assert _relmax(C, Cr) < 1e-8
     assert _relmax(G @ C, R) < 1e-10
@@ -334,8 +349,9 @@ def _kernel_system(n, m, seed=0, lambda_=0.02, s2=1e-3):
     return U, UP @ U, K, UP @ Yv, lambda_ * s2
 
 
+@pytest.mark.parametrize("method", METHODS)
 @pytest.mark.parametrize("n,m", [(4000, 300), (6000, 1000)])
-def test_solve_minnorm_kernel_gram_vs_scipy_lstsq(st, n, m):
+def test_solve_minnorm_kernel_gram_vs_scipy_lstsq(st, n, m, method):
     """The regime Spateo's default lambda_ puts the solve in: U^T P U + lambda sigma^2 K numerically rank deficient.
     Parity quantity = the FIELD U C (C lives in the numerical null space).  The reference noise floor is the deviation
     between scipy.linalg.lstsq (gelsd) and the mathematically identical truncated eigh solve, both on the CPU."""
@@ -348,18 +364,19 @@ def test_solve_minnorm_kernel_gram_vs_scipy_lstsq(st, n, m):
     F = U @ C_ls
     sc = np.abs(F).max()
     floor = np.abs(U @ C_eh - F).max() / sc
-    C, info, e = _run_minnorm(_k("float64"), G, K, ls2, R)
+    C, info, e = _run_minnorm(_k("float64"), G, K, ls2, R, method=method)
     dev = np.abs(U @ C - F).max() / sc
-    print(f"m={m}: cond {w.max() / np.abs(w).min():.1e} kept {keep.sum()} gpu kept {int(e[1])} sweeps {e[0]} "
-          f"floor(lstsq vs eigh) {floor:.2e}  gpu vs lstsq {dev:.2e}")
+    print(f"m={m} {method}: cond {w.max() / np.abs(w).min():.1e} kept {keep.sum()} gpu kept {int(e[1])} (factor rank "
+          f"{int(e[6])}) sweeps {e[0]} floor(lstsq vs eigh) {floor:.2e}  gpu vs lstsq {dev:.2e}")
     assert info == 0
     assert dev < max(2.0 * floor, 1e-9)
     assert abs(int(e[1]) - int(keep.sum())) <= max(2, m // 50)  # eigenvalues at the cut-off may fall either side
     np.testing.assert_allclose(e[2], w.max(), rtol=1e-9)
 
 
+@pytest.mark.parametrize("method", METHODS)
 @pytest.mark.parametrize("m", [2000, 3000])
-def test_solve_large_rank_deficient_vs_scipy_lstsq(st, m):
+def test_solve_large_rank_deficient_vs_scipy_lstsq(st, m, method):
     """the coefficient solve at the headline size against scipy.linalg.lstsq on a genuinely
     rank-deficient U^T P U + lambda sigma^2 K, asserting on the field U C; the jitter-Cholesky mode is measured
     beside it (deviation as a function of the jitter it needed)."""
@@ -375,10 +392,10 @@ def test_solve_large_rank_deficient_vs_scipy_lstsq(st, m):
     sc = np.abs(F).max()
     floor = np.abs(U @ C_eh - F).max() / sc
     k = _k("float64")
-    _run_minnorm(k, G, K, ls2, R)  # warm-up (workspace allocation)
+    _, _, e0 = _run_minnorm(k, G, K, ls2, R, method=method)  # warm-up (workspace allocation)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    C, info, e = _run_minnorm(k, G, K, ls2, R)
+    C, info, e = _run_minnorm(k, G, K, ls2, R, method=method, rank_hint=int(e0[6]))
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0)
     dev = np.abs(U @ C - F).max() / sc
@@ -395,7 +412,8 @@ def test_solve_large_rank_deficient_vs_scipy_lstsq(st, m):
             if len(devs) == 3:
                 break
         jit = max(jit * 10, 1e-15)
-    print(f"m={m}: kept {keep.sum()}/{m} (gpu {int(e[1])}), sweeps {e[0]}, {ms:.1f} ms incl. H2D; floor {floor:.2e}; "
+    print(f"m={m} {method}: kept {keep.sum()}/{m} (gpu {int(e[1])}, factor rank {int(e[6])}), sweeps {e[0]}, {ms:.1f} ms "
+          f"incl. H2D; floor {floor:.2e}; "
           f"min-norm vs lstsq {dev:.2e}; jitter-Cholesky vs lstsq: " + ", ".join(f"{j:g}: {v:.2e}" for j, v in devs))
     assert info == 0 and e[0] == np.floor(e[0])
     assert dev < max(2.0 * floor, 1e-9)

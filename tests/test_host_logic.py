@@ -107,7 +107,8 @@ def test_em_driver_stops_like_the_reference(cpu_kernels):
 
 def test_solve_policy_cholesky_while_certified_then_minimum_norm(cpu_kernels):
     """lstsq_method="scipy": un-regularised Cholesky while the pivots certify full numerical rank, the truncated
-    minimum-norm solve once they do not (sticky within a fit); the eigensolver's shift escalates only on failure."""
+    minimum-norm solve once they do not (sticky within a fit): the rank-revealing one by default (the factor rank of one
+    step is the next step's hint), the full-width one (mn_method = "full") with a shift that escalates only on failure."""
     from spateo_amd.vectorfield import SparseVFCEngine
 
     X, V = _data(400)
@@ -130,15 +131,25 @@ def test_solve_policy_cholesky_while_certified_then_minimum_norm(cpu_kernels):
             TinyPivot.mn += 1
             super().solve_minnorm(*a, **kw)
 
-    eng2 = SparseVFCEngine(Xv, Yv, ctrl, beta, kernels=TinyPivot())
-    eng2.init_state()
-    eng2.em_step(lambda_=3.0)
-    assert eng2.rank_deficient and (TinyPivot.chol, TinyPivot.mn) == (1, 1)
-    eng2.em_step(lambda_=3.0)
-    assert (TinyPivot.chol, TinyPivot.mn) == (1, 2)  # sticky: no more Cholesky attempts in this fit
-    assert eng2.solver_stats["minnorm"] == 2 and eng2.solver_stats["rank"] == [30, 30]
-    # well conditioned system: both paths give the same field
-    np.testing.assert_allclose(eng2.results()[0], _two_steps(Xv, Yv, ctrl, beta, cpu_kernels), rtol=1e-9, atol=1e-12)
+        def solve_minnorm_lr(self, *a, **kw):
+            TinyPivot.mn += 1
+            TinyPivot.hints.append(kw.get("rank_hint"))
+            super().solve_minnorm_lr(*a, **kw)
+
+    for method in ("lowrank", "full"):
+        TinyPivot.chol = TinyPivot.mn = 0
+        TinyPivot.hints = []
+        eng2 = SparseVFCEngine(Xv, Yv, ctrl, beta, kernels=TinyPivot())
+        eng2.mn_method = method
+        eng2.init_state()
+        eng2.em_step(lambda_=3.0)
+        assert eng2.rank_deficient and (TinyPivot.chol, TinyPivot.mn) == (1, 1)
+        eng2.em_step(lambda_=3.0)
+        assert (TinyPivot.chol, TinyPivot.mn) == (1, 2)  # sticky: no more Cholesky attempts in this fit
+        assert eng2.solver_stats["minnorm"] == 2 and eng2.solver_stats["rank"] == [30, 30]
+        assert TinyPivot.hints == ([0, 30] if method == "lowrank" else [])
+        # well conditioned system: every path gives the same field
+        np.testing.assert_allclose(eng2.results()[0], _two_steps(Xv, Yv, ctrl, beta, cpu_kernels), rtol=1e-9, atol=1e-12)
 
     class ShiftTooSmall(CpuKernels):
         shifts = []
@@ -154,6 +165,7 @@ def test_solve_policy_cholesky_while_certified_then_minimum_norm(cpu_kernels):
             super().solve_minnorm(G, K, ls2, shift, R, C_out, info, einfo, **kw)
 
     eng3 = SparseVFCEngine(Xv, Yv, ctrl, beta, kernels=ShiftTooSmall())
+    eng3.mn_method = "full"
     eng3.init_state()
     eng3.em_step(lambda_=3.0)
     assert ShiftTooSmall.shifts == [2.0 ** -36, 2.0 ** -32, 2.0 ** -28] and eng3.mn_shift == 2.0 ** -28
@@ -165,10 +177,15 @@ def test_solve_policy_cholesky_while_certified_then_minimum_norm(cpu_kernels):
         def solve_minnorm(self, G, K, ls2, shift, R, C_out, info, einfo, **kw):
             info.fill_(1)
 
-    eng4 = SparseVFCEngine(Xv, Yv, ctrl, beta, kernels=AlwaysFail())
-    eng4.init_state()
-    with pytest.raises(RuntimeError, match="not numerically positive semi-definite"):
-        eng4.em_step(lambda_=3.0)
+        def solve_minnorm_lr(self, G, K, ls2, R, C_out, info, einfo, **kw):
+            info.fill_(1)
+
+    for method, msg in (("full", "not numerically positive semi-definite"), ("lowrank", "non-finite")):
+        eng4 = SparseVFCEngine(Xv, Yv, ctrl, beta, kernels=AlwaysFail())
+        eng4.mn_method = method
+        eng4.init_state()
+        with pytest.raises(RuntimeError, match=msg):
+            eng4.em_step(lambda_=3.0)
 
 
 def _two_steps(Xv, Yv, ctrl, beta, kernels):
