@@ -197,7 +197,7 @@ __global__ __launch_bounds__(EIG_THREADS) void jac_eig_kernel(const double* __re
                                                               unsigned int* __restrict__ rot_total) {
     __shared__ double S[JP][JP];
     __shared__ double Jm[JP][JP];
-    __shared__ double cs[JB][2];
+    __shared__ double cs[2][JB][2];
     const int pair = blockIdx.x, tid = threadIdx.x;
     int bp, bq;
     rr_pair(nb, round, pair, bp, bq);
@@ -205,43 +205,75 @@ __global__ __launch_bounds__(EIG_THREADS) void jac_eig_kernel(const double* __re
         if (tid == 0) flags[pair] = 0;
         return;
     }
+#ifdef MVF_EIG_CLOCKS
+    const unsigned long long c0 = wall_clock64();
+#endif
     const double* sp = Spart + (int64_t)pair * nsplit * (JP * JP);
-    for (int e = tid; e < JP * JP; e += EIG_THREADS) {
-        double s = 0.0;
-        for (int q = 0; q < nsplit; ++q) s += sp[(int64_t)q * (JP * JP) + e];
-        S[e >> 6][e & 63] = s;
-        Jm[e >> 6][e & 63] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
+    // sum of the K-split partial tiles in split order; the loads of 8 splits x 4 elements are in flight together (the
+    // partials were written by other compute units a moment ago: every dependent load is a trip beyond this XCD's L2 -
+    // the plain loop spent 25 us here at 24 splits, as long as the 32 rotation rounds)
+    {
+        double acc4[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int q0 = 0; q0 < nsplit; q0 += 8) {
+            double v[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    v[u][w] = (q0 + u < nsplit) ? sp[(int64_t)(q0 + u) * (JP * JP) + tid + w * EIG_THREADS] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) acc4[w] += v[u][w];
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int e = tid + w * EIG_THREADS;
+            S[e >> 6][e & 63] = acc4[w];
+            Jm[e >> 6][e & 63] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
+        }
     }
     __syncthreads();
     const int l = tid & 31, k = tid >> 5;
     const double tol2 = tol * tol;
     int nrot = 0;
     constexpr int NR = FULL ? JP - 1 : JB;
+    // rotation of pair l of inner round r from the current S (the 32 lanes of the first half-wave)
+    auto rotation = [&](int r, double (*csb)[2]) {
+        int p, q;
+        inner_pair<FULL>(r, l, p, q);
+        double c = 1.0, sn = 0.0;
+        const double app = S[p][p], aqq = S[q][q], apq = S[p][q];
+        const bool act = apq != 0.0 && apq * apq > tol2 * fabs(app * aqq);
+        if (act) {
+            const double zeta = (aqq - app) * rcp_nr(2.0 * apq);
+            const double z2 = fma(zeta, zeta, 1.0);
+            const double t = copysign(rcp_nr(fabs(zeta) + z2 * rsq_nr(z2)), zeta);
+            c = rsq_nr2(fma(t, t, 1.0));
+            sn = c * t;
+            if (!(fabs(sn) <= 1.0)) {  // overflow / NaN in the estimate chain (|zeta| astronomically large): no rotation
+                c = 1.0;
+                sn = 0.0;
+            }
+        }
+        csb[l][0] = c;
+        csb[l][1] = sn;
+        nrot += __popcll(__ballot(act));  // the 32 lanes of this half-wave = the round's 32 pairs
+    };
+#ifdef MVF_EIG_CLOCKS
+    const unsigned long long c1 = wall_clock64();
+#endif
+    if (k == 0) rotation(0, cs[0]);
+    __syncthreads();
+    // Per round: (1) every thread rotates its 2 x 2 block of S; barrier; (2) the first half-wave computes the NEXT round's
+    // rotations from the updated S while all threads rotate their column pair of J (J is not needed for the rotations:
+    // the dependent f64 chain of (2) hides behind the LDS traffic of the J update); barrier.
 #pragma unroll 1
     for (int r = 0; r < NR; ++r) {
         int p, q;
         inner_pair<FULL>(r, l, p, q);
-        if (k == 0) {
-            double c = 1.0, sn = 0.0;
-            const double app = S[p][p], aqq = S[q][q], apq = S[p][q];
-            const bool act = apq != 0.0 && apq * apq > tol2 * fabs(app * aqq);
-            if (act) {
-                const double zeta = (aqq - app) * rcp_nr(2.0 * apq);
-                const double z2 = fma(zeta, zeta, 1.0);
-                const double t = copysign(rcp_nr(fabs(zeta) + z2 * rsq_nr(z2)), zeta);
-                c = rsq_nr2(fma(t, t, 1.0));
-                sn = c * t;
-                if (!(fabs(sn) <= 1.0)) {  // overflow / NaN in the estimate chain (|zeta| astronomically large): no rotation
-                    c = 1.0;
-                    sn = 0.0;
-                }
-            }
-            cs[l][0] = c;
-            cs[l][1] = sn;
-            nrot += __popcll(__ballot(act));  // the 32 lanes of this half-wave = the round's 32 pairs
-        }
-        __syncthreads();
-        const double cl = cs[l][0], sl = cs[l][1], ck = cs[k][0], sk = cs[k][1];
+        const double(*csr)[2] = cs[r & 1];
+        const double cl = csr[l][0], sl = csr[l][1], ck = csr[k][0], sk = csr[k][1];
         {
             int pk, qk;
             inner_pair<FULL>(r, k, pk, qk);
@@ -259,6 +291,8 @@ __global__ __launch_bounds__(EIG_THREADS) void jac_eig_kernel(const double* __re
             S[qk][p] = n10;
             S[qk][q] = n11;
         }
+        __syncthreads();
+        if (k == 0 && r + 1 < NR) rotation(r + 1, cs[(r + 1) & 1]);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int i = k + 32 * j;
@@ -268,8 +302,18 @@ __global__ __launch_bounds__(EIG_THREADS) void jac_eig_kernel(const double* __re
         }
         __syncthreads();
     }
+#ifdef MVF_EIG_CLOCKS
+    const unsigned long long c2 = wall_clock64();
+#endif
     double* jo = Jbuf + (int64_t)pair * (JP * JP);
     for (int e = tid; e < JP * JP; e += EIG_THREADS) jo[e] = Jm[e >> 6][e & 63];
+#ifdef MVF_EIG_CLOCKS
+    if (tid == 0 && !FULL) {
+        rot_total[4] = (unsigned int)(c1 - c0);
+        rot_total[5] = (unsigned int)(c2 - c1);
+        rot_total[6] = (unsigned int)(wall_clock64() - c2);
+    }
+#endif
     if (tid == 0) {
         flags[pair] = nrot > 0;
         if (nrot > 0) {
@@ -700,8 +744,11 @@ __global__ __launch_bounds__(PC_T) void pchol_step_kernel(const double* __restri
     const bool live = i < mp;
     const int64_t ic = live ? i : 0;
     double acc = S[p * mp + ic], accp = S[p * mp + p];
+    const double di = dg_in[ic];
     const double* yk = Y + (int64_t)jb * mp;
     int k = jb;
+    // (measured: a step costs ~7 us whatever its size - at m = 500 as at m = 3000, with 4- or 16-row load batches: it is
+    // the dependent-launch latency of the stream, not this loop)
     for (; k + 4 <= j; k += 4, yk += 4 * mp) {
         const double p0 = yk[p], p1 = yk[mp + p], p2 = yk[2 * mp + p], p3 = yk[3 * mp + p];
         const double a0 = yk[ic], a1 = yk[mp + ic], a2 = yk[2 * mp + ic], a3 = yk[3 * mp + ic];
@@ -719,7 +766,6 @@ __global__ __launch_bounds__(PC_T) void pchol_step_kernel(const double* __restri
         acc = fma(-a0, p0, acc);
         accp = fma(-p0, p0, accp);
     }
-    const double di = dg_in[ic];
     const bool used = !live || di == -INFINITY;
     // a pivot the fresh evaluation does not confirm (dg drifted): retire p with an all-zero row
     const bool badp = !(accp > 0.25 * tol);
@@ -834,7 +880,8 @@ struct LrPlan {
         off_sig2, off_t, off_part, off_rot, off_scal, total;
 };
 
-constexpr int LR_GRAM_WGS = 512;  // workgroups per Jacobi Gram launch (pairs x K splits)
+constexpr int LR_GRAM_WGS = 512;  // upper bound of the workgroups per Jacobi Gram launch (pairs x K splits)
+constexpr int LR_GRAM_WGS_DEFAULT = 256;  // measured at m = 3000, r = 860: 512 -> 21.3, 256 -> 19.9, 128 -> 21.5 ms of Jacobi
 
 static LrPlan lr_plan(int64_t m) {
     LrPlan p;
@@ -1098,6 +1145,12 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
     double* scal = (double*)(ws + p.off_scal);
     const int64_t mp = p.mp;
     PcholState hs;
+    static const bool timing = std::getenv("MVF_LR_TIMING") != nullptr;  // developer knob: phase times on stderr
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (timing && !reuse) {
+        for (auto& e : ev) MVF_CHECK_HIP(hipEventCreate(&e));
+        MVF_CHECK_HIP(hipEventRecord(ev[0], st));
+    }
 
     // the truncated solve from the orthogonalised factor (rows of Y = sigma_i u_i^T): C = Y^T (g .* (Y R))
     auto backsolve = [&](int64_t rp, double* ei) -> int {
@@ -1164,6 +1217,7 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
         upto = std::min(msteps, upto + 128);
     }
     const int64_t r = hs.r;
+    if (timing) MVF_CHECK_HIP(hipEventRecord(ev[1], st));
     const double hr[1] = {(double)r};
     MVF_CHECK_HIP(hipMemcpyAsync(einfo + 6, hr, sizeof(double), hipMemcpyHostToDevice, st));
     if (r == 0) {  // the zero matrix: minimum-norm solution 0
@@ -1177,7 +1231,11 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
 
     // 2. one-sided block Jacobi on the r rows of Y
     const int nb = (int)(rp / JB), npairs = nb / 2, nk = (int)(mp / 64);
-    int nsplit = std::min(nk, std::max(1, LR_GRAM_WGS / npairs));
+    static const int gram_wgs = [] {
+        const char* e = std::getenv("MVF_JAC_GRAM_WGS");  // developer knob: workgroups per Gram launch
+        return e ? std::min(LR_GRAM_WGS, std::max(64, atoi(e))) : LR_GRAM_WGS_DEFAULT;
+    }();
+    int nsplit = std::min(nk, std::max(1, gram_wgs / npairs));
     const int kchunks = (int)cdiv(nk, nsplit);
     nsplit = (int)cdiv(nk, kchunks);
     const double tol = std::sqrt((double)m) * 2.220446049250313e-16;
@@ -1208,7 +1266,24 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
     }
 
     // 3. truncated minimum-norm solve
+    if (timing) MVF_CHECK_HIP(hipEventRecord(ev[2], st));
     if (int rc = backsolve(rp, einfo)) return rc;
+    if (timing) {
+        MVF_CHECK_HIP(hipEventRecord(ev[3], st));
+        MVF_CHECK_HIP(hipEventSynchronize(ev[3]));
+        float t01 = 0, t12 = 0, t23 = 0;
+        (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
+        (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
+        (void)hipEventElapsedTime(&t23, ev[2], ev[3]);
+        fprintf(stderr, "[mvf_solve_minnorm_lr] m %lld r %lld launches %d: factor %.2f ms, jacobi %.2f ms (%d sweeps), solve %.2f ms\n",
+                (long long)m, (long long)r, j, t01, t12, sweeps, t23);
+#ifdef MVF_EIG_CLOCKS
+        unsigned int hc[8];
+        (void)hipMemcpy(hc, rot, sizeof(hc), hipMemcpyDeviceToHost);
+        fprintf(stderr, "    eig kernel sections (100 MHz ticks): load %u, rounds %u, store %u\n", hc[4], hc[5], hc[6]);
+#endif
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
     const double hsw[1] = {(double)sweeps + (hrot != 0 ? 0.5 : 0.0)};  // x.5 = sweep cap hit before convergence
     MVF_CHECK_HIP(hipMemcpyAsync(einfo, hsw, sizeof(double), hipMemcpyHostToDevice, st));
     MVF_CHECK_HIP(hipStreamSynchronize(st));
