@@ -29,7 +29,6 @@ for _p in (ROOT, os.path.join(ROOT, "spateo-release_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (spec; 155 measured)
 PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X datasheet: FP64 matrix (v_mfma_f64_16x16x4_f64) dense peak
 PEAK_HBM_GBPS = 8000.0
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
@@ -125,9 +124,6 @@ def main():
     ap.add_argument("--lstsq", default="scipy", choices=["scipy", "cholesky"],
                     help="coefficient solve: scipy = the reference's minimum-norm gelsd semantics (default); cholesky = "
                          "jitter-escalated Cholesky (non-reference fast mode)")
-    ap.add_argument("--gram-mode", default="f64acc", choices=["f64acc", "f32mfma"],
-                    help="float32 Gram kernel: f64acc = float32 operands + float64 MFMA accumulation (default, meets "
-                         "the 1e-3 field tolerance); f32mfma = all-float32 MFMA (2x peak, noisier)")
     ap.add_argument("--cache-u", default="auto", choices=["auto", "on", "off"],
                     help="materialise the float32 kernel values once (96 GB at 8M x 3000) and stream them in the Gram "
                          "kernel instead of regenerating them every EM iteration")
@@ -201,10 +197,8 @@ def main():
 
     def run_mode(dtype, steps, warmup):
         """W warm-up + K timed EM iterations of the whole workload in one cell dtype; returns the timing record."""
-        kern = HipKernels(device, dtype, gram_mode=args.gram_mode)
+        kern = HipKernels(device, dtype)
         cache_u = {"auto": "auto", "on": True, "off": False}[args.cache_u]
-        if args.gram_mode == "f32mfma":
-            cache_u = False
         eng = SparseVFCEngine(Xv[lo:hi], Yv[lo:hi], ctrl, beta, dtype=dtype, device=device, distributed=distributed,
                               n_total=N, kernels=kern, cache_u=cache_u)
         eng.lstsq_method = args.lstsq
@@ -246,18 +240,16 @@ def main():
         gram_avg_ms = float(np.mean(gram_ms))
         alg_flops = float(n_loc) * Mc * (Mc + 1)  # symmetric Gram: n m (m+1) flops
         achieved = alg_flops / (gram_avg_ms * 1e-3) / 1e12
-        f32mfma = dtype == "float32" and args.gram_mode == "f32mfma"
-        peak = PEAK_F32_MFMA_TFLOPS if f32mfma else PEAK_F64_MFMA_TFLOPS
+        peak = PEAK_F64_MFMA_TFLOPS  # both cell dtypes accumulate with v_mfma_f64_16x16x4_f64
         ctype = "float" if dtype == "float32" else "double"
-        traffic, traffic_src = pmc_traffic(dtype, args.gram_mode, eng.cached_u, world, n_loc, Mc)
+        traffic, traffic_src = pmc_traffic(dtype, "f64acc", eng.cached_u, world, n_loc, Mc)
         rec = {
             "value": N * steps / elapsed,
             "ms_per_step": ms_per_step,
             "steps": steps,
             "warmup": warmup,
             "roofline": {
-                "kernel": "gram_f32_kernel (v_mfma_f32_32x32x2_f32)" if f32mfma else
-                          (f"gram_cached_kernel<{ctype}> (v_mfma_f64_16x16x4_f64, cached {dtype} U streamed from HBM)"
+                "kernel": (f"gram_cached_kernel<{ctype}> (v_mfma_f64_16x16x4_f64, cached {dtype} U streamed from HBM)"
                            if eng.cached_u else f"gram_f64acc_kernel<{ctype}> (v_mfma_f64_16x16x4_f64)"),
                 "bound": "mfma",
                 "achieved": achieved,
@@ -337,7 +329,7 @@ def main():
             "ctrl_points": Mc,
             "parallelism": f"cells block-sharded over {world} GPU(s), one all-reduce of [G|R|stats] per EM step",
             "sigma2_after": main_rec["sigma2_after"],
-            "gram_mode": args.gram_mode,
+            "gram_mode": "f64acc",
             "cached_u": main_rec["cached_u"],
             "step_effective_GBps": main_rec["step_effective_GBps"],
             "step_TFLOPs_2NM2": main_rec["step_TFLOPs_2NM2"],

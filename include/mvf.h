@@ -103,19 +103,13 @@ int mvf_estep_p(const void* r, int64_t n, double sigma2, double gamma, double a,
 /* ---- M-step assembly:  G = U^T diag(P) U (m x m),  R = U^T diag(P) Y (m x 3)  --------------------------------
  * Replaces: `UP = U.T * repmat(P.T, M, 1); lhs = UP.dot(U) ...; rhs = UP.dot(Y)` of SparseVFC (App. A 5c; same
  * shape in-tree at spateo/alignment/methods/morpho_class.py:1266-1293).  MFMA kernel; the kernel values (cell dtype)
- * are regenerated from x4/ctrl4 in registers and accumulated with v_mfma_f64_16x16x4_f64, so G is the exact Gram
- * matrix of those values; per-slice partial tiles are summed in a fixed order (deterministic).
+ * are regenerated from x4/ctrl4 in registers and accumulated with v_mfma_f64_16x16x4_f64 in both dtypes, so G is the
+ * exact Gram matrix of those values; per-slice partial tiles are summed in a fixed order (deterministic).  No
+ * process-global state: the library's behaviour depends on its arguments only.
  * Outputs are float64: G (m x m, full symmetric), R (m x 3).  They hold THIS rank's partial sums.  The collective is
  * the CALLER's: the library holds no communicator; the host all-reduces the contiguous [G | R | scalars] buffer with
  * torch.distributed (RCCL over xGMI) - one all-reduce per EM step. */
 size_t mvf_gram_workspace_bytes(int64_t n, int64_t m, mvf_dtype dtype);
-/* How the MVF_F32 Gram kernel accumulates (process-wide; MVF_F64 is unaffected):
- *   MVF_GRAM_MODE_F64_ACC  (default) float32 operand generation, v_mfma_f64_16x16x4_f64 accumulation: G is the exact
- *                          Gram matrix of the float32 kernel values; meets the 1e-3 field tolerance.
- *   MVF_GRAM_MODE_F32_MFMA v_mfma_f32_32x32x2_f32 in 256-cell chains folded into float64: 2x the MFMA peak, but
- *                          ~1e-9 relative noise in G which weakly regularised solves amplify to percent level. */
-enum { MVF_GRAM_MODE_F64_ACC = 0, MVF_GRAM_MODE_F32_MFMA = 1 };
-int mvf_set_gram_mode(int mode);
 int mvf_gram(const void* x4, const void* P, const void* y4, int64_t n, const void* ctrl4, int64_t m, double beta,
              double* G, double* R, void* workspace, size_t workspace_bytes, mvf_dtype dtype, void* stream);
 /* Same, one stage at a time (mask of MVF_GRAM_STAGE_*): TILES = the MFMA kernel writing per-slice partial tiles into

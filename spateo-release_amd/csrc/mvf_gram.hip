@@ -4,16 +4,17 @@
 // (call sites spateo/tdr/morphometrics/morphofield/sparsevfc.py:189-198).
 //
 // Design (MI355X first, not a GEMM on a materialised U):
-//   * G is an n-long reduction SYRK; at m >= 500 it is MFMA-bound (2 n m^2 flops vs 16 n bytes of input).  U is never
-//     read from HBM: each lane REGENERATES its own MFMA operand element.  For v_mfma_f32_32x32x2_f32 lane l holds
-//     A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; with A[i][k] = P_n K(x_n, c_i), B[k][j] = K(x_n, c_j) and n the
-//     cell k of the step, a lane needs only ITS control point (registers, loaded once) and the step's two cells
-//     (one broadcast ds_read_b128 from a 4 KiB LDS stage).  6 VALU + 1 v_exp per operand, 4 operands per 4 MFMAs.
+//   * G is an n-long reduction SYRK; at m >= 500 it is MFMA-bound (2 n m^2 flops vs 16 n bytes of input).  The kernel
+//     values are either regenerated per lane (gram_f64acc_kernel: the lane keeps ITS control points in registers and
+//     reads the step's cells with one broadcast ds_read_b128 from a 4 KiB LDS stage; 6 VALU + 1 v_exp per operand) or
+//     streamed from a cache in MFMA-operand layout built once per fit (gram_cached_kernel, the default: U is constant
+//     across EM iterations).  A[i][k] = P_n K(x_n, c_i), B[k][j] = K(x_n, c_j), n = the cell k of the step.
 //   * Only tile pairs ti <= tj of the symmetric G are computed (algorithmic flops n m (m+1)).
-//   * Precision: float32 MFMA chains are kept short (GCHUNK = 256 cells), then folded into float64 accumulators in
-//     registers; per-slice float64 partial tiles go to a workspace and are summed in a fixed order -> deterministic,
-//     and the rounding noise of G is ~1e-9 relative instead of ~1e-5 for one long float32 chain.
-//   * The float64 mode uses v_mfma_f64_16x16x4_f64 with float64 operand generation.
+//   * Precision: v_mfma_f64_16x16x4_f64 accumulation in BOTH modes - float32 mode generates / stores the kernel values
+//     in float32 and widens them (a product of two float32 values is exact in float64: G is the exact Gram matrix of
+//     the float32 kernel values); per-slice float64 partial tiles go to a workspace and are summed in a fixed order
+//     -> deterministic.  (An all-float32 MFMA arm, 256-cell chains folded into float64, was measured in round 1 -
+//     87 TF, ~1e-9 relative noise in G that the solve amplifies to percent level - and removed in round 2.)
 //   * Work decomposition: job = (tile pair, cell slice); blockIdx = slice * npairs + pair so that concurrently
 //     resident workgroups stream the same cell slice (L2 / MALL hits on the only global input).
 #include "mvf_common.h"
@@ -22,10 +23,8 @@
 namespace mvf {
 
 constexpr int GT = 128;      // Gram tile edge per workgroup (4 waves, 64 x 64 per wave)
-constexpr int GCHUNK = 256;  // cells per LDS stage == length of a float32 MFMA accumulation chain
-constexpr float PAD_COORD = 1.0e18f;  // padded control points sit "at infinity": K == exp2(-3e36) == 0 exactly
+constexpr int GCHUNK = 256;  // cells per LDS stage
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 struct GramPlan {
@@ -111,122 +110,12 @@ __device__ __forceinline__ void decode_pair(int pair, int nt, int& ti, int& tj) 
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// float32 MFMA Gram kernel
-// ----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void gram_f32_kernel(const float4* __restrict__ x4, const float* __restrict__ P,
-                                                          int64_t n, const float4* __restrict__ ctrl4, int64_t m,
-                                                          float s, int nt, int npairs, int64_t slice_len,
-                                                          double* __restrict__ partial) {
-    __shared__ float4 cells[2][GCHUNK];  // (s*x, s*y, s*z, P)
-
-    const int pair = blockIdx.x % npairs;
-    const int64_t slice = blockIdx.x / npairs;
-    int ti, tj;
-    decode_pair(pair, nt, ti, tj);
-    const int64_t n0 = slice * slice_len;
-    const int64_t n1 = min(n, n0 + slice_len);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave >> 1, wj = wave & 1;
-
-    // this lane's control points (scaled), 2 row blocks (A side) + 2 column blocks (B side)
-    float ax[2], ay[2], az[2], bx[2], by[2], bz[2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int64_t ia = (int64_t)ti * GT + wi * 64 + a * 32 + (lane & 31);
-        const int64_t ib = (int64_t)tj * GT + wj * 64 + a * 32 + (lane & 31);
-        if (ia < m) {
-            const float4 c = ctrl4[ia];
-            ax[a] = c.x * s, ay[a] = c.y * s, az[a] = c.z * s;
-        } else {
-            ax[a] = ay[a] = az[a] = PAD_COORD;
-        }
-        if (ib < m) {
-            const float4 c = ctrl4[ib];
-            bx[a] = c.x * s, by[a] = c.y * s, bz[a] = c.z * s;
-        } else {
-            bx[a] = by[a] = bz[a] = PAD_COORD;
-        }
-    }
-
-    f32x16 acc[2][2];
-    double acc2[2][2][16];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[a][b][r] = 0.f;
-                acc2[a][b][r] = 0.0;
-            }
-        }
-
-    auto load_cell = [&](int64_t i) -> float4 {
-        if (i < n1) {
-            const float4 xv = x4[i];
-            return float4{xv.x * s, xv.y * s, xv.z * s, P[i]};
-        }
-        return float4{0.f, 0.f, 0.f, 0.f};  // P = 0: the A operand vanishes
-    };
-
-    const int nchunks = (int)((n1 - n0 + GCHUNK - 1) / GCHUNK);
-    float4 stage = load_cell(n0 + tid);
-    cells[0][tid] = stage;
-    const int half = lane >> 5;
-
-    for (int c = 0; c < nchunks; ++c) {
-        __syncthreads();
-        if (c + 1 < nchunks) stage = load_cell(n0 + (int64_t)(c + 1) * GCHUNK + tid);
-        const float4* cb = cells[c & 1];
-#pragma unroll 4
-        for (int st = 0; st < GCHUNK / 2; ++st) {
-            const float4 cell = cb[2 * st + half];
-            float fa[2], fb[2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                fa[a] = kernel_value(cell.x, cell.y, cell.z, ax[a], ay[a], az[a]) * cell.w;
-                fb[a] = kernel_value(cell.x, cell.y, cell.z, bx[a], by[a], bz[a]);
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
-        }
-        // fold the short float32 chain into float64
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    acc2[a][b][r] += (double)acc[a][b][r];
-                    acc[a][b][r] = 0.f;
-                }
-        if (c + 1 < nchunks) cells[(c + 1) & 1][tid] = stage;
-    }
-
-    // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    double* out = partial + ((size_t)slice * npairs + pair) * (size_t)(GT * GT);
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wi * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int col = wj * 64 + b * 32 + (lane & 31);
-                out[row * GT + col] = acc2[a][b][r];
-            }
-}
-
-// ----------------------------------------------------------------------------------------------------------------
 // float64-ACCUMULATE MFMA Gram kernel (v_mfma_f64_16x16x4_f64: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15];
 // C/D: col = l & 15, row = (l >> 4) + 4 * reg).  TIn = double: the float64 mode.  TIn = float: the default float32
 // mode - operands are generated in float32 (6 VALU + v_exp_f32) and widened; a product of two float32 values is exact
-// in float64, so G is the EXACT Gram matrix of the float32-rounded kernel values (error ~1e-16 sqrt(n)), whereas the
-// all-float32 MFMA kernel above leaves ~1e-9 relative noise that the ill-conditioned solve amplifies to percent level
-// (DESIGN.md "Why the float32 mode accumulates in float64").
+// in float64, so G is the EXACT Gram matrix of the float32-rounded kernel values (error ~1e-16 sqrt(n)), whereas an
+// all-float32 MFMA kernel (v_mfma_f32_32x32x2_f32, measured in round 1 at 87 TF and removed) leaves ~1e-9 relative noise
+// that the ill-conditioned solve amplifies to percent level (DESIGN.md "Why the float32 mode accumulates in float64").
 // ----------------------------------------------------------------------------------------------------------------
 template <typename TIn>
 __global__ __launch_bounds__(256, 2) void gram_f64acc_kernel(const typename Vec4<TIn>::type* __restrict__ x4,
@@ -236,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void gram_f64acc_kernel(const typename Vec4
                                                              double* __restrict__ partial) {
     using V4 = typename Vec4<TIn>::type;
     __shared__ V4 cells[2][GCHUNK];
-    const TIn PAD = sizeof(TIn) == 4 ? (TIn)1.0e18f : (TIn)1.0e150;
+    const TIn PAD = sizeof(TIn) == 4 ? (TIn)1.0e18f : (TIn)1.0e150;  // padded control points sit "at infinity": K == 0 exactly
 
     const int pair = blockIdx.x % npairs;
     const int64_t slice = blockIdx.x / npairs;
@@ -695,14 +584,6 @@ __global__ __launch_bounds__(256) void rhs_reduce_kernel(const double* __restric
 
 using namespace mvf;
 
-static int g_gram_mode = MVF_GRAM_MODE_F64_ACC;
-
-extern "C" int mvf_set_gram_mode(int mode) {
-    MVF_REQUIRE(mode == MVF_GRAM_MODE_F64_ACC || mode == MVF_GRAM_MODE_F32_MFMA, "mvf_set_gram_mode: bad mode %d", mode);
-    g_gram_mode = mode;
-    return 0;
-}
-
 extern "C" size_t mvf_gram_workspace_bytes(int64_t n, int64_t m, mvf_dtype dtype) {
     (void)dtype;
     if (n <= 0 || m <= 0) return 0;
@@ -739,10 +620,7 @@ extern "C" int mvf_gram_stages(int stages, const void* x4, const void* P, const 
     const unsigned njobs = (unsigned)(p.nslices * p.npairs);
     dim3 rgrid((unsigned)p.rcolblocks, (unsigned)p.rslices);
     if (stages & MVF_GRAM_STAGE_TILES) {
-        if (dtype == MVF_F32 && g_gram_mode == MVF_GRAM_MODE_F32_MFMA)
-            hipLaunchKernelGGL(gram_f32_kernel, dim3(njobs), dim3(256), 0, st, (const float4*)x4, (const float*)P, n,
-                               (const float4*)ctrl4, m, (float)s, p.nt, p.npairs, p.slice_len, gpart);
-        else if (dtype == MVF_F32)
+        if (dtype == MVF_F32)
             hipLaunchKernelGGL(gram_f64acc_kernel<float>, dim3(njobs), dim3(256), 0, st, (const float4*)x4,
                                (const float*)P, n, (const float4*)ctrl4, m, (float)s, p.nt, p.npairs, p.slice_len,
                                gpart);

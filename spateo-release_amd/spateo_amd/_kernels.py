@@ -34,7 +34,7 @@ def _on_device(fn):
 class HipKernels:
     """libmvf kernels bound to one GPU and one cell dtype ("float32" | "float64")."""
 
-    def __init__(self, device=None, dtype="float32", gram_mode=None):
+    def __init__(self, device=None, dtype="float32"):
         if not torch.cuda.is_available():
             raise RuntimeError(
                 "spateo_amd needs an AMD GPU (HIP device) - torch.cuda.is_available() is False and there is no "
@@ -57,14 +57,6 @@ class HipKernels:
         self.gram_events = None
         self._ublk = None       # cached float32 kernel values (layout Ublk[m/16][n][16]) for the Gram kernel
         self._ublk_key = None
-        if gram_mode is not None:
-            self.set_gram_mode(gram_mode)
-
-    def set_gram_mode(self, mode):
-        """"f64acc" (default: float32 operands, float64 MFMA accumulation) or "f32mfma" (fast, noisier G).  Process-wide."""
-        code = {"f64acc": _lib.GRAM_MODE_F64_ACC, "f32mfma": _lib.GRAM_MODE_F32_MFMA}[mode]
-        _lib.check(self.lib.mvf_set_gram_mode(code), "mvf_set_gram_mode")
-
     # ------------------------------------------------------------------ helpers
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream

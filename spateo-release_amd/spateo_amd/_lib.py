@@ -14,7 +14,6 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmvf.so")
 MVF_F32, MVF_F64 = 0, 1
 MVF_ESTEP_MIN_DOUBLES = 4098
 
-GRAM_MODE_F64_ACC, GRAM_MODE_F32_MFMA = 0, 1
 GRAM_TILES, GRAM_RHS, GRAM_REDUCE, GRAM_REDUCE_RHS = 1, 2, 4, 8
 EVAL_V, EVAL_JAC, EVAL_DIV, EVAL_CURL, EVAL_ACC, EVAL_CURV, EVAL_TORS, EVAL_JDET = 1, 2, 4, 8, 16, 32, 64, 128
 
@@ -33,7 +32,6 @@ SIGNATURES = {
     "mvf_apply": (_i, [_p, _i64, _p, _i64, _d, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "mvf_estep_min": (_i, [_p, _i64, _d, _p, _i, _p]),
     "mvf_estep_p": (_i, [_p, _i64, _d, _d, _d, _i, _d, _d, _d, _p, _p, _p, _p, _i, _p]),
-    "mvf_set_gram_mode": (_i, [_i]),
     "mvf_gram_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "mvf_gram": (_i, [_p, _p, _p, _i64, _p, _i64, _d, _p, _p, _p, _sz, _i, _p]),
     "mvf_gram_stages": (_i, [_i, _p, _p, _p, _i64, _p, _i64, _d, _p, _p, _p, _sz, _i, _p]),

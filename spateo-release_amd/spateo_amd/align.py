@@ -29,7 +29,7 @@ def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, l
     ``_construct_kernel`` builds them, ``:825-875``):
 
     * ``U^T diag(K_NA) U`` and ``U^T PXB_term``  -> ``mvf_gram`` (f64 MFMA; U is never materialised),
-    * ``pinv(SigmaInv) @ rhs``                   -> ``mvf_solve_minnorm`` with scipy.linalg.pinv's default cut-off
+    * ``pinv(SigmaInv) @ rhs``                   -> ``mvf_solve_minnorm`` / ``_lr`` with scipy.linalg.pinv's default cut-off
       ``max(M, M) * eps * s_max`` (what ``_pinv`` resolves to on the NumPy backend, ``methods/utils.py:11,1435``),
     * ``U @ Coff``                               -> ``mvf_apply``.
 
@@ -60,14 +60,21 @@ def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, l
     k.gram(x4, Pw, y4, c4, float(beta), G, R)
     ls2 = float(sigma2) * float(lambdaVF)
     C, info, einfo = k.zeros(m, 3, dtype=f64), k.zeros(1, dtype=torch.int32), k.zeros(12, dtype=f64)
-    shift = 2.0 ** -36
-    while True:
-        k.solve_minnorm(G, Gamma, ls2, shift, R, C, info, einfo, rcond=m * float(np.finfo(np.float64).eps))
-        if int(info.cpu()[0]) == 0:
-            break
-        shift *= 16.0
-        if shift > 2.0 ** -12:
-            raise _lib.MVFError("update_nonrigid: SigmaInv is not numerically positive semi-definite")
+    rcond = m * float(np.finfo(np.float64).eps)
+    if m >= 1280 and hasattr(k, "solve_minnorm_lr"):
+        # rank-revealing factor + Jacobi on its columns (the faster path once the factor drops most columns)
+        k.solve_minnorm_lr(G, Gamma, ls2, R, C, info, einfo, rcond=rcond)
+        if int(info.cpu()[0]) != 0:
+            raise _lib.MVFError("update_nonrigid: SigmaInv has non-finite entries")
+    else:
+        shift = 2.0 ** -36
+        while True:
+            k.solve_minnorm(G, Gamma, ls2, shift, R, C, info, einfo, rcond=rcond)
+            if int(info.cpu()[0]) == 0:
+                break
+            shift *= 16.0
+            if shift > 2.0 ** -12:
+                raise _lib.MVFError("update_nonrigid: SigmaInv is not numerically positive semi-definite")
     V4, _ = k.apply(x4, c4, float(beta), C)
     SigmaInv = G.cpu().numpy() + ls2 * Gamma.cpu().numpy()
     return {"SigmaInv": SigmaInv, "Coff": C.cpu().numpy()[:, :D].copy(),

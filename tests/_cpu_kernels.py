@@ -22,7 +22,7 @@ def _np(t):
 
 
 class CpuKernels:
-    def __init__(self, device=None, dtype="float64", gram_mode=None):
+    def __init__(self, device=None, dtype="float64"):
         self.device = torch.device("cpu")
         self.dtype_name = "float64"
         self.tdtype = torch.float64

@@ -68,8 +68,12 @@ def test_error_channel_without_launching_anything():
                                0, None)
     assert rc != 0 and b"mvf_solve_minnorm" in lib.mvf_last_error()
     assert lib.mvf_solve_minnorm_workspace_bytes(3000, 3) >= 2 * 3008 * 3008 * 8
-    with pytest.raises(_lib.MVFError, match="mvf_set_gram_mode"):
-        _lib.check(lib.mvf_set_gram_mode(7), "mvf_set_gram_mode")
+    rc = lib.mvf_solve_minnorm_lr(None, None, 0.0, 0.25, 2.2e-16, None, 5, 9, None, ctypes.byref(info), None, 0, 0, 0, None,
+                                  0, None)
+    assert rc != 0 and b"mvf_solve_minnorm_lr" in lib.mvf_last_error()
+    assert lib.mvf_solve_minnorm_lr_workspace_bytes(3000, 3) >= 2 * 3008 * 3008 * 8
+    with pytest.raises(_lib.MVFError, match="mvf_solve_minnorm_lr"):
+        _lib.check(rc, "mvf_solve_minnorm_lr")
     # empty problems are fine and launch nothing
     assert lib.mvf_con_k(None, 0, None, 5, 3, 0.1, None, _lib.MVF_F32, None) == 0
     assert lib.mvf_gram_workspace_bytes(0, 10, _lib.MVF_F32) == 0

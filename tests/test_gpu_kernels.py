@@ -201,30 +201,6 @@ def test_gram_cached_u_is_bit_identical_to_recompute(st, n, m, dtype):
     assert _relmax(G1.cpu().numpy(), Gr) < (3e-6 if dtype == "float32" else 1e-11)
 
 
-def test_gram_f32_mfma_fast_mode(st):
-    """The optional all-float32 MFMA Gram kernel (mvf_set_gram_mode): 256-cell float32 chains folded into float64."""
-    n, m = 4000, 260
-    rng, X, ctrl = _cloud(9, n, m)
-    beta = 0.003
-    Y = rng.standard_normal((n, 3))
-    P = rng.uniform(1e-5, 1.0, n).astype(np.float32)
-    k = _k("float32")
-    try:
-        k.set_gram_mode("f32mfma")
-        center = ctrl.mean(0)
-        x4, c4, y4 = k.to_x4(X, center), k.to_x4(ctrl, center), k.to_x4(Y)
-        G = torch.empty(m, m, dtype=torch.float64, device="cuda:0")
-        R = torch.empty(m, 3, dtype=torch.float64, device="cuda:0")
-        k.gram(x4, torch.from_numpy(P).to("cuda:0"), y4, c4, beta, G, R)
-    finally:
-        k.set_gram_mode("f64acc")
-    U = svo.con_K(X, ctrl, beta)
-    Gr = (U.T * P.astype(np.float64)[None, :]) @ U
-    Gd = G.cpu().numpy()
-    assert np.array_equal(Gd, Gd.T)
-    assert _relmax(Gd, Gr) < 3e-6
-
-
 # ------------------------------------------------------------------------------------------------- solve
 @pytest.mark.parametrize("m,nrhs", [(64, 3), (100, 3), (300, 2), (517, 1)])
 def test_solve_spd_vs_numpy(st, m, nrhs):
