@@ -182,8 +182,13 @@ size_t mvf_solve_minnorm_basis_bytes(int64_t m);
  * m = 3000 and the graded pivoted factor halves the sweep count; no shift, no retry ladder: info[0] != 0 only for
  * non-finite input.  einfo (12 float64, device): [0] = sweeps (x.5 if max_sweeps was hit first), [1] = kept rank,
  * [2] = max lambda, [3] = min kept lambda, [4] = 0, [5] = min lambda of the factor, [6] = r (columns of L).
- * rank_hint (0 = none): the r of a nearby matrix (the previous EM iteration's) - that many pivot steps are enqueued
- * before the first status read.  reuse != 0: apply the decomposition of the previous call on this workspace to another
+ * rank_hint (0 = none): einfo[6] of the previous call ON THIS WORKSPACE for a nearby matrix (the previous EM iteration):
+ * the factorisation then first follows the pivot order that call left in the workspace, 64 columns per three launches
+ * (64 x 64 Cholesky of the gathered block, forward substitution of the gathered rows, trailing update) instead of one
+ * launch per pivot, accepting a pivot only while it exceeds max(2^-10 x the largest remaining diagonal entry, the
+ * stopping tolerance); the first rejected column ends the use of the hint and the greedy steps finish.  The result does
+ * not depend on the hint being good: a stale or foreign order is rejected column by column, a workspace without a
+ * finished order ignores the hint.  reuse != 0: apply the decomposition of the previous call on this workspace to another
  * R (einfo[7..11] = this call's).  NOT asynchronous (status reads during the factorisation, one per Jacobi sweep). */
 size_t mvf_solve_minnorm_lr_workspace_bytes(int64_t m, int nrhs);
 int mvf_solve_minnorm_lr(const double* G, const double* K, double lambda_sigma2, double tolf, double rcond,

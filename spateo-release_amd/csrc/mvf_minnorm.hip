@@ -603,8 +603,9 @@ __global__ __launch_bounds__(256) void basis_extract_kernel(const double* __rest
 // Y (row j = column j of L, row length mp) is produced row by row: coalesced stores, and exactly the layout the Jacobi
 // kernels want.
 struct PcholState {
-    int done, r, pad0, pad1;
+    int done, r, panels, hint_broken;  // panels = hint panels accepted so far (the next panel's index)
     double tol, lmax_est, maxdiag, pad2;
+    int panel_nvalid, magic, order_len, pad3;  // magic / order_len: the workspace holds the pivot order of a finished call
 };
 
 // y = A x, one wave per row (the power iteration that estimates lambda_max for the stopping tolerance)
@@ -650,11 +651,14 @@ __global__ __launch_bounds__(256) void lr_power_kernel(double* __restrict__ x, c
 }
 
 constexpr int PC_T = 128;  // threads (= columns of A) per workgroup of the pivot step
+constexpr int PCHOL_MAGIC = 0x6d766c72;
+constexpr double PCHOL_THETA = 0.0009765625;  // 2^-10, see pchol_panel_factor_kernel
 
 // dg[i] = A_ii (-inf on the padding: never a pivot), per-workgroup (max, argmax) partials, the tolerance, the state
 __global__ __launch_bounds__(256) void pchol_init_kernel(const double* __restrict__ S, int64_t m, int64_t mp, double tolf,
                                                          double* __restrict__ dg, double* __restrict__ pm, int nwg,
-                                                         PcholState* __restrict__ stt, int* __restrict__ info) {
+                                                         PcholState* __restrict__ stt, int* __restrict__ info, int use_hint,
+                                                         int hint_len) {
     __shared__ double red[4];
     __shared__ double bc[2];
     double mx = 0.0;
@@ -695,6 +699,11 @@ __global__ __launch_bounds__(256) void pchol_init_kernel(const double* __restric
         const double lmax = fmax(ok ? est : 0.0, bc[1]);
         stt->done = 0;
         stt->r = 0;
+        stt->panels = 0;
+        // the hint is usable only if this workspace really holds the order of a finished factorisation of that length
+        stt->hint_broken = !(use_hint && stt->magic == PCHOL_MAGIC && stt->order_len == hint_len);
+        stt->magic = 0;
+        stt->panel_nvalid = 0;
         stt->maxdiag = bc[1];
         stt->lmax_est = lmax;
         stt->tol = tolf * 2.220446049250313e-16 * lmax;
@@ -817,8 +826,10 @@ __global__ __launch_bounds__(PC_T) void pchol_step_kernel(const double* __restri
 // trailing update after a block of 64 pivot steps:  S -= Yb^T Yb,  Yb = rows jb .. jb + 63 of Y (64 x 64 tile per
 // workgroup, f64 MFMA, both operand tiles staged k-major in LDS)
 __global__ __launch_bounds__(256) void pchol_update_kernel(double* __restrict__ S, const double* __restrict__ Y,
-                                                           int64_t mp, int jb, const PcholState* __restrict__ stt) {
-    if (stt->done) return;
+                                                           int64_t mp, int jb, const PcholState* __restrict__ stt,
+                                                           int need_panels) {
+    // greedy blocks (need_panels < 0): skipped once the factorisation is finished; hint panels: run iff accepted
+    if (need_panels < 0 ? stt->done != 0 : stt->panels != need_panels) return;
     __shared__ double sa[JP * LDK];
     __shared__ double sb[JP * LDK];
     const int ti = blockIdx.y, tj = blockIdx.x;
@@ -873,11 +884,188 @@ __global__ __launch_bounds__(256) void pchol_update_kernel(double* __restrict__ 
             }
 }
 
+// ---- pivot order of a NEARBY matrix as a hint: 64 pivots per 3 launches instead of 65 --------------------------------
+// Between EM iterations the greedy pivot order barely moves (CPU prototype: 955 of 960 pivots of one iteration are
+// acceptable, in order, for the next).  Any pivot order gives a valid factor A = L L^T + E with the same stopping rule;
+// what pivoting must guarantee is only that no pivot is tiny against the diagonal entries still outside (rounding noise
+// in a column is amplified by 1 / sqrt(pivot)).  So a panel of the previous order's next 64 columns is factored as a
+// block - 64 x 64 Cholesky of the gathered Schur block (one workgroup), forward substitution of the 64 gathered rows of S
+// (one lane per column of A), MFMA trailing update - and accepted column by column while pivot > max(theta dmax, tol),
+// dmax = the largest remaining diagonal entry when the panel starts (theta = 2^-10: noise amplification <= 32).  The
+// first rejected column ends the use of the hint; the greedy steps above finish the factorisation (and find any column
+// the hint does not know).
+
+__global__ __launch_bounds__(256) void pchol_panel_factor_kernel(const double* __restrict__ S, int64_t m, int64_t mp,
+                                                                 const int* __restrict__ hint, int nh, int b,
+                                                                 const double* __restrict__ dg, PcholState* __restrict__ stt,
+                                                                 int* __restrict__ order, double* __restrict__ piv,
+                                                                 double* __restrict__ Lcc, int* __restrict__ cand_out) {
+    __shared__ double A[64][65];
+    __shared__ int cand[64];
+    __shared__ double red[4];
+    __shared__ double s_dmax;
+    __shared__ int s_n, s_ok;
+    if (stt->done || stt->hint_broken || stt->panels != b) return;  // uniform
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const int idx = 64 * b + tid;
+        const int c = idx < nh ? hint[idx] : -1;
+        cand[tid] = (c >= 0 && c < m && dg[c] != -INFINITY) ? c : -1;
+    }
+    double mx = -INFINITY;
+    for (int64_t i = tid; i < mp; i += 256) mx = fmax(mx, dg[i]);
+    const double t = -block_min<256>(-mx, red);  // has barriers: cand[] is visible afterwards
+    if (tid == 0) {
+        int n = 0;
+        for (int j = 0; j < 64; ++j)
+            if (cand[j] >= 0) cand[n++] = cand[j];
+        for (int j = n; j < 64; ++j) cand[j] = -1;
+        s_n = n;
+        s_dmax = t;
+    }
+    __syncthreads();
+    const int n = s_n;
+    const double dmax = s_dmax, tol = stt->tol;
+    if (n == 0 || !(dmax > tol)) {
+        if (tid == 0) {
+            if (!(dmax > tol))
+                stt->done = 1;
+            else
+                stt->hint_broken = 1;
+        }
+        return;
+    }
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int j = e >> 6, k = e & 63;
+        A[j][k] = (j < n && k < n) ? S[(int64_t)cand[j] * mp + cand[k]] : (j == k ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    const double thr = fmax(PCHOL_THETA * dmax, tol);
+    int nvalid = n;
+    for (int j = 0; j < n; ++j) {
+        if (tid == 0) {
+            const double pv = A[j][j];
+            const int ok = pv > thr && pv <= 1.79e308;
+            s_ok = ok;
+            if (ok) {
+                piv[64 * b + j] = pv;
+                A[j][j] = sqrt(pv);
+            }
+        }
+        __syncthreads();
+        if (!s_ok) {
+            nvalid = j;
+            break;
+        }
+        const double d = A[j][j];
+        if (tid > j && tid < n) A[tid][j] = A[tid][j] / d;
+        __syncthreads();
+        const int cnt = n - 1 - j;
+        for (int e = tid; e < cnt * cnt; e += 256) {
+            const int i = j + 1 + e / cnt, k = j + 1 + e % cnt;
+            if (k <= i) A[i][k] = fma(-A[i][j], A[k][j], A[i][k]);
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int j = e >> 6, k = e & 63;
+        Lcc[e] = (j < nvalid && k <= j) ? A[j][k] : 0.0;
+    }
+    if (tid < 64) {
+        cand_out[tid] = tid < nvalid ? cand[tid] : -1;
+        order[64 * b + tid] = tid < nvalid ? cand[tid] : -1;
+    }
+    if (tid == 0) {
+        stt->panel_nvalid = nvalid;
+        if (nvalid < n) stt->hint_broken = 1;
+        if (nvalid > 0) stt->panels = b + 1;
+    }
+}
+
+// rows 64 b .. 64 b + 63 of Y from the accepted panel: Y[64 b + j][i] = (S[c_j][i] - sum_{k < j} L[j][k] Y[64 b + k][i]) / L[j][j]
+// (one lane per column i; the panel's own pivot columns come out as L's columns and are forced to exact zeros behind
+// their pivot), dg -= sum_j y_j^2, the workgroup's (max, argmax) for the greedy steps that may follow.
+__global__ __launch_bounds__(PC_T) void pchol_panel_rows_kernel(const double* __restrict__ S, double* __restrict__ Y, int64_t mp,
+                                                                int b, double* __restrict__ dg, double* __restrict__ pm,
+                                                                PcholState* __restrict__ stt, const double* __restrict__ Lcc,
+                                                                const int* __restrict__ cand_in) {
+    if (stt->panels != b + 1) return;
+    __shared__ double L[64][65];
+    __shared__ double rd[64];
+    __shared__ int cand[64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nvalid = stt->panel_nvalid;
+    for (int e = tid; e < 64 * 64; e += PC_T) L[e >> 6][e & 63] = Lcc[e];
+    if (tid < 64) cand[tid] = cand_in[tid];
+    __syncthreads();
+    if (tid < 64) rd[tid] = tid < nvalid ? 1.0 / L[tid][tid] : 0.0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * PC_T + tid;
+    const bool live = i < mp;
+    const int64_t ic = live ? i : 0;
+    const double di = dg[ic];
+    const bool used = !live || di == -INFINITY;
+    int pos = -1;
+    for (int k = 0; k < nvalid; ++k)
+        if (cand[k] == (int)ic) pos = k;
+    double y[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) y[j] = (j < nvalid && !used) ? S[(int64_t)max(cand[j], 0) * mp + ic] : 0.0;
+    double ss = 0.0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        double s = y[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s = fma(-L[j][k], y[k], s);
+        s *= rd[j];
+        if (pos >= 0 && j > pos) s = 0.0;
+        y[j] = s;
+        ss = fma(s, s, ss);
+    }
+    const double dn = (used || pos >= 0) ? -INFINITY : di - ss;
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < 64; ++j) Y[((int64_t)64 * b + j) * mp + i] = y[j];
+        dg[i] = dn;
+    }
+    __shared__ double sv[PC_T / 64];
+    __shared__ int si[PC_T / 64];
+    double wv = live ? dn : -INFINITY;
+    int wi = live ? (int)i : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double v = __shfl_xor(wv, o, 64);
+        const int ix = __shfl_xor(wi, o, 64);
+        if (v > wv || (v == wv && ix < wi)) {
+            wv = v;
+            wi = ix;
+        }
+    }
+    if (lane == 0) {
+        sv[tid >> 6] = wv;
+        si[tid >> 6] = wi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double v = sv[0];
+        int ix = si[0];
+#pragma unroll
+        for (int w = 1; w < PC_T / 64; ++w)
+            if (sv[w] > v || (sv[w] == v && si[w] < ix)) {
+                v = sv[w];
+                ix = si[w];
+            }
+        pm[2 * blockIdx.x] = v;
+        pm[2 * blockIdx.x + 1] = (double)ix;
+        if (blockIdx.x == 0) stt->r = 64 * b + nvalid;  // only the last accepted panel can be partial
+    }
+}
+
 struct LrPlan {
     int64_t mp;
     int nbmax, npmax, nwg, spart_tiles;
     size_t off_s, off_y, off_dg, off_pm, off_x, off_state, off_order, off_piv, off_spart, off_j, off_flags, off_stamps,
-        off_sig2, off_t, off_part, off_rot, off_scal, total;
+        off_sig2, off_t, off_part, off_rot, off_scal, off_hint, off_lcc, off_cand, total;
 };
 
 constexpr int LR_GRAM_WGS = 512;  // upper bound of the workgroups per Jacobi Gram launch (pairs x K splits)
@@ -913,6 +1101,9 @@ static LrPlan lr_plan(int64_t m) {
     p.off_part = take((size_t)16 * m * 8 * sizeof(double));
     p.off_rot = take(256);
     p.off_scal = take(256);
+    p.off_hint = take((size_t)p.mp * sizeof(int));
+    p.off_lcc = take((size_t)64 * 64 * sizeof(double));
+    p.off_cand = take(256);
     p.total = o;
     return p;
 }
@@ -1187,26 +1378,56 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
         hipLaunchKernelGGL(lr_symv_kernel, dim3((unsigned)cdiv(mp, 4)), dim3(256), 0, st, S, mp, xv, xv + mp);
         hipLaunchKernelGGL(lr_power_kernel, dim3(1), dim3(256), 0, st, xv, xv + mp, m, mp, 0, stt);
     }
-    hipLaunchKernelGGL(pchol_init_kernel, dim3(1), dim3(256), 0, st, S, m, mp, tolf, dg, pm, p.nwg, stt, info);
-    MVF_LAUNCH_CHECK();
-    int j = 0, cur = 0;
-    const int msteps = (int)m;
+    int* hint = (int*)(ws + p.off_hint);
+    double* Lcc = (double*)(ws + p.off_lcc);
+    int* candb = (int*)(ws + p.off_cand);
+    const int msteps = (int)m;  // every row of Y retires one column
     const dim3 ugrid((unsigned)(mp / 64), (unsigned)(mp / 64));
+    int j = 0, cur = 0, hinfo = 0;
+    const int use_hint = rank_hint > 0 && rank_hint <= m;
+    // with rank_hint > 0 the factorisation first follows the pivot order the previous call left in this workspace
+    if (use_hint) MVF_CHECK_HIP(hipMemcpyAsync(hint, order, (size_t)mp * sizeof(int), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(pchol_init_kernel, dim3(1), dim3(256), 0, st, S, m, mp, tolf, dg, pm, p.nwg, stt, info, use_hint,
+                       rank_hint);
+    MVF_LAUNCH_CHECK();
+    bool finished = false;
+    if (use_hint) {
+        const int npan = (int)cdiv(rank_hint, 64);
+        for (int b = 0; b < npan; ++b) {
+            hipLaunchKernelGGL(pchol_panel_factor_kernel, dim3(1), dim3(256), 0, st, S, m, mp, hint, rank_hint, b, dg, stt,
+                               order, piv, Lcc, candb);
+            hipLaunchKernelGGL(pchol_panel_rows_kernel, dim3((unsigned)p.nwg), dim3(PC_T), 0, st, S, Y, mp, b, dg, pm, stt,
+                               Lcc, candb);
+            hipLaunchKernelGGL(pchol_update_kernel, ugrid, dim3(256), 0, st, S, Y, mp, 64 * b, stt, b + 1);
+        }
+        MVF_LAUNCH_CHECK();
+        MVF_CHECK_HIP(hipMemcpyAsync(&hs, stt, sizeof(hs), hipMemcpyDeviceToHost, st));
+        MVF_CHECK_HIP(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, st));
+        MVF_CHECK_HIP(hipStreamSynchronize(st));
+        if (hinfo != 0) return 0;
+        j = hs.r;  // pivots taken from the hint (the last accepted panel may be partial: its rows behind are zero and
+                   // already applied to S, the greedy steps overwrite them)
+        finished = hs.done || j >= msteps;
+    }
+    int jbase = j;  // first row not yet applied to S by a trailing update
     auto enqueue = [&](int upto) {
         while (j < upto) {
-            const int jb = j & ~63;
-            hipLaunchKernelGGL(pchol_step_kernel, dim3((unsigned)p.nwg), dim3(PC_T), 0, st, S, Y, mp, jb, j,
+            hipLaunchKernelGGL(pchol_step_kernel, dim3((unsigned)p.nwg), dim3(PC_T), 0, st, S, Y, mp, jbase, j,
                                dg + (size_t)cur * mp, dg + (size_t)(cur ^ 1) * mp, pm + (size_t)cur * 2 * p.nwg,
                                pm + (size_t)(cur ^ 1) * 2 * p.nwg, p.nwg, stt, order, piv);
             cur ^= 1;
             ++j;
-            if ((j & 63) == 0 && j < msteps)
-                hipLaunchKernelGGL(pchol_update_kernel, ugrid, dim3(256), 0, st, S, Y, mp, jb, stt);
+            if (j - jbase == 64 && j < msteps) {
+                hipLaunchKernelGGL(pchol_update_kernel, ugrid, dim3(256), 0, st, S, Y, mp, jbase, stt, -1);
+                jbase = j;
+            }
         }
     };
-    int upto = rank_hint > 0 ? (int)std::min<int64_t>(msteps, cdiv(rank_hint + 8, 64) * 64) : std::min(msteps, 256);
-    int hinfo = 0;
-    while (true) {
+    // without a hint: the first 256 steps, then 128 more per status read; after hint panels only the tail is left: 32
+    // steps per status read
+    const bool tail_only = use_hint && j > 0;
+    int upto = tail_only ? std::min(msteps, j + 32) : std::min(msteps, 256);
+    while (!finished) {
         enqueue(upto);
         MVF_LAUNCH_CHECK();
         MVF_CHECK_HIP(hipMemcpyAsync(&hs, stt, sizeof(hs), hipMemcpyDeviceToHost, st));
@@ -1214,7 +1435,11 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
         MVF_CHECK_HIP(hipStreamSynchronize(st));
         if (hinfo != 0) return 0;  // non-finite input: info[0] tells the caller
         if (hs.done || j >= msteps) break;
-        upto = std::min(msteps, upto + 128);
+        upto = std::min(msteps, upto + (tail_only ? 32 : 128));
+    }
+    {
+        const int tag[2] = {PCHOL_MAGIC, (int)hs.r};  // this workspace now holds a finished order of hs.r rows
+        MVF_CHECK_HIP(hipMemcpyAsync(&stt->magic, tag, sizeof(tag), hipMemcpyHostToDevice, st));
     }
     const int64_t r = hs.r;
     if (timing) MVF_CHECK_HIP(hipEventRecord(ev[1], st));
@@ -1275,7 +1500,7 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
         (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
         (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
         (void)hipEventElapsedTime(&t23, ev[2], ev[3]);
-        fprintf(stderr, "[mvf_solve_minnorm_lr] m %lld r %lld launches %d: factor %.2f ms, jacobi %.2f ms (%d sweeps), solve %.2f ms\n",
+        fprintf(stderr, "[mvf_solve_minnorm_lr] m %lld rows %lld (last greedy row %d): factor %.2f ms, jacobi %.2f ms (%d sweeps), solve %.2f ms\n",
                 (long long)m, (long long)r, j, t01, t12, sweeps, t23);
 #ifdef MVF_EIG_CLOCKS
         unsigned int hc[8];

@@ -350,6 +350,47 @@ def test_solve_minnorm_kernel_gram_vs_scipy_lstsq(st, n, m, method):
     np.testing.assert_allclose(e[2], w.max(), rtol=1e-9)
 
 
+def test_solve_minnorm_lr_follows_the_previous_pivot_order(st):
+    """rank_hint > 0: the factorisation follows the pivot order the previous call left in the workspace, 64 columns per
+    three launches, accepting each pivot only while it is not small against the remaining diagonal.  Same matrix: same
+    solution (to the level the truncated solve is determined); a nearby matrix (other weights P): the hint still covers
+    almost every column and the result is that matrix's own solution; a hint from an unrelated matrix, or a hint for a
+    workspace that holds none, is rejected or ignored - never wrong."""
+    import scipy.linalg
+
+    k = _k("float64")
+    U, G, K, R, ls2 = _kernel_system(6000, 1000)
+    F_ref = U @ scipy.linalg.lstsq(G + ls2 * K, R)[0]
+    sc = np.abs(F_ref).max()
+    C0, info, e0 = _run_minnorm(k, G, K, ls2, R, method="lowrank")                      # greedy
+    r0 = int(e0[6])
+    C1, info1, e1 = _run_minnorm(k, G, K, ls2, R, method="lowrank", rank_hint=r0)      # same matrix, hinted
+    assert info == 0 and info1 == 0
+    d0, d1 = np.abs(U @ C0 - F_ref).max() / sc, np.abs(U @ C1 - F_ref).max() / sc
+    print(f"greedy: rows {r0} kept {int(e0[1])} vs lstsq {d0:.2e}; hinted: rows {int(e1[6])} kept {int(e1[1])} vs lstsq {d1:.2e}")
+    assert abs(int(e1[6]) - r0) <= 64 and abs(int(e1[1]) - int(e0[1])) <= 8
+    assert d1 < max(2.0 * d0, 1e-9)
+    # a nearby matrix: other weights
+    U2, G2, K2, R2, _ = _kernel_system(6000, 1000, seed=0, lambda_=0.02, s2=0.9e-3)
+    P2 = np.clip(np.random.default_rng(5).random(len(U2)) ** 2, 1e-5, 1.0)
+    G2 = (U2.T * P2[None, :]) @ U2
+    F2 = U2 @ scipy.linalg.lstsq(G2 + ls2 * K2, R2)[0]
+    C2g, _, e2g = _run_minnorm(_k("float64"), G2, K2, ls2, R2, method="lowrank")        # greedy on a fresh workspace
+    C2h, info2, e2h = _run_minnorm(k, G2, K2, ls2, R2, method="lowrank", rank_hint=int(e1[6]))
+    dg_, dh_ = (np.abs(U2 @ C - F2).max() / np.abs(F2).max() for C in (C2g, C2h))
+    print(f"nearby matrix: greedy rows {int(e2g[6])} vs lstsq {dg_:.2e}; hinted rows {int(e2h[6])} vs lstsq {dh_:.2e}")
+    assert info2 == 0 and dh_ < max(2.0 * dg_, 1e-9)
+    # an unrelated, well-conditioned matrix with a stale hint in the workspace, and a hint without any history
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((1000, 2000))
+    Gw = B @ B.T / 2000
+    Rw = rng.standard_normal((1000, 3))
+    for kk, hint in ((k, int(e2h[6])), (_k("float64"), 500)):
+        Cw, infow, ew = _run_minnorm(kk, Gw, np.zeros_like(Gw), 0.0, Rw, method="lowrank", rank_hint=hint)
+        assert infow == 0 and int(ew[1]) == 1000
+        assert _relmax(Cw, np.linalg.solve(Gw, Rw)) < 1e-9
+
+
 @pytest.mark.parametrize("method", METHODS)
 @pytest.mark.parametrize("m", [2000, 3000])
 def test_solve_large_rank_deficient_vs_scipy_lstsq(st, m, method):
