@@ -895,16 +895,57 @@ __global__ __launch_bounds__(256) void pchol_update_kernel(double* __restrict__ 
 // first rejected column ends the use of the hint; the greedy steps above finish the factorisation (and find any column
 // the hint does not know).
 
+// Right-looking Cholesky of the gathered 64 x 64 block, register tiled like potrf_diag_kernel of mvf_solve.hip (thread
+// (ty, tx) of a 16 x 16 grid keeps a[ty + 16 p][tx + 16 q]; per column: the owners publish it UNSCALED to LDS, one
+// barrier, every thread applies the rank-1 update to its registers), stopping at the first pivot that fails the threshold.
+template <int JQ>
+__device__ __forceinline__ bool panel_potrf_group(double (&r)[4][4], double (*col)[64], double* dgs, int tx, int ty,
+                                                  double thr, int n, int& nvalid) {
+#pragma unroll 1
+    for (int jx = 0; jx < 16; ++jx) {
+        const int j = 16 * JQ + jx;
+        if (j >= n) return false;
+        if (tx == jx) {
+#pragma unroll
+            for (int p = JQ; p < 4; ++p) col[j & 1][ty + 16 * p] = r[p][JQ];
+        }
+        __syncthreads();
+        const double* cb = col[j & 1];
+        const double d = cb[j];
+        if (!(d > thr && d <= 1.79e308)) {  // uniform: every thread reads the same pivot
+            nvalid = j;
+            return false;
+        }
+        if (threadIdx.x == 0) dgs[j] = d;
+        const double inv = 1.0 / d;
+        double ci[4], cc[4];
+#pragma unroll
+        for (int p = JQ; p < 4; ++p) {
+            ci[p] = cb[ty + 16 * p] * inv;
+            cc[p] = cb[tx + 16 * p];
+        }
+#pragma unroll
+        for (int p = JQ; p < 4; ++p)
+#pragma unroll
+            for (int q = JQ; q < 4; ++q) {
+                const double u = r[p][q] - ci[p] * cc[q];
+                r[p][q] = (ty + 16 * p > j && tx + 16 * q > j) ? u : r[p][q];
+            }
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(256) void pchol_panel_factor_kernel(const double* __restrict__ S, int64_t m, int64_t mp,
                                                                  const int* __restrict__ hint, int nh, int b,
                                                                  const double* __restrict__ dg, PcholState* __restrict__ stt,
                                                                  int* __restrict__ order, double* __restrict__ piv,
                                                                  double* __restrict__ Lcc, int* __restrict__ cand_out) {
-    __shared__ double A[64][65];
+    __shared__ double col[2][64];
+    __shared__ double dgs[64];
     __shared__ int cand[64];
     __shared__ double red[4];
     __shared__ double s_dmax;
-    __shared__ int s_n, s_ok;
+    __shared__ int s_n;
     if (stt->done || stt->hint_broken || stt->panels != b) return;  // uniform
     const int tid = threadIdx.x;
     if (tid < 64) {
@@ -935,45 +976,38 @@ __global__ __launch_bounds__(256) void pchol_panel_factor_kernel(const double* _
         }
         return;
     }
-    for (int e = tid; e < 64 * 64; e += 256) {
-        const int j = e >> 6, k = e & 63;
-        A[j][k] = (j < n && k < n) ? S[(int64_t)cand[j] * mp + cand[k]] : (j == k ? 1.0 : 0.0);
-    }
-    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    double r[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = ty + 16 * p, c = tx + 16 * q;
+            r[p][q] = (i < n && c < n) ? S[(int64_t)cand[i] * mp + cand[c]] : (i == c ? 1.0 : 0.0);
+        }
     const double thr = fmax(PCHOL_THETA * dmax, tol);
     int nvalid = n;
-    for (int j = 0; j < n; ++j) {
-        if (tid == 0) {
-            const double pv = A[j][j];
-            const int ok = pv > thr && pv <= 1.79e308;
-            s_ok = ok;
-            if (ok) {
-                piv[64 * b + j] = pv;
-                A[j][j] = sqrt(pv);
+    if (panel_potrf_group<0>(r, col, dgs, tx, ty, thr, n, nvalid))
+        if (panel_potrf_group<1>(r, col, dgs, tx, ty, thr, n, nvalid))
+            if (panel_potrf_group<2>(r, col, dgs, tx, ty, thr, n, nvalid))
+                panel_potrf_group<3>(r, col, dgs, tx, ty, thr, n, nvalid);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = ty + 16 * p, c = tx + 16 * q;
+            double v = 0.0;
+            if (i < nvalid && c <= i) {
+                const double l = sqrt(dgs[c]);
+                v = c < i ? r[p][q] / l : l;
             }
+            Lcc[i * 64 + c] = v;
         }
-        __syncthreads();
-        if (!s_ok) {
-            nvalid = j;
-            break;
-        }
-        const double d = A[j][j];
-        if (tid > j && tid < n) A[tid][j] = A[tid][j] / d;
-        __syncthreads();
-        const int cnt = n - 1 - j;
-        for (int e = tid; e < cnt * cnt; e += 256) {
-            const int i = j + 1 + e / cnt, k = j + 1 + e % cnt;
-            if (k <= i) A[i][k] = fma(-A[i][j], A[k][j], A[i][k]);
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < 64 * 64; e += 256) {
-        const int j = e >> 6, k = e & 63;
-        Lcc[e] = (j < nvalid && k <= j) ? A[j][k] : 0.0;
-    }
     if (tid < 64) {
         cand_out[tid] = tid < nvalid ? cand[tid] : -1;
         order[64 * b + tid] = tid < nvalid ? cand[tid] : -1;
+        if (tid < nvalid) piv[64 * b + tid] = dgs[tid];
     }
     if (tid == 0) {
         stt->panel_nvalid = nvalid;

@@ -61,7 +61,7 @@ def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, l
     ls2 = float(sigma2) * float(lambdaVF)
     C, info, einfo = k.zeros(m, 3, dtype=f64), k.zeros(1, dtype=torch.int32), k.zeros(12, dtype=f64)
     rcond = m * float(np.finfo(np.float64).eps)
-    if m >= 1280 and hasattr(k, "solve_minnorm_lr"):
+    if m >= 1024 and hasattr(k, "solve_minnorm_lr"):
         # rank-revealing factor + Jacobi on its columns (the faster path once the factor drops most columns)
         k.solve_minnorm_lr(G, Gamma, ls2, R, C, info, einfo, rcond=rcond)
         if int(info.cpu()[0]) != 0:

@@ -299,9 +299,10 @@ class SparseVFCEngine:
         self.basis, self.basis_valid, self.warm_start = None, False, True
         # "lowrank": pivoted-Cholesky factor + Jacobi on its r columns (mvf_solve_minnorm_lr); "full": Jacobi on all M
         # columns of the shifted factor, warm-started (mvf_solve_minnorm)
-        # measured per solve in the EM's steady state (ms, lowrank / full): M = 500: 11 / 3.7, 1000: 24 / 18, 1500: 31 / 36,
-        # 2000: 30 / 62, 3000: 30 / 122 - the full-width warm start wins while the factor keeps nearly every column
-        self.mn_method = os.environ.get("MVF_MINNORM", "lowrank" if self.M >= 1280 else "full")
+        # measured per solve in the EM's steady state (ms, lowrank / full): M = 500: 8.7 / 3.6, 1000: 17.3 / 18.4,
+        # 1500: 20.9 / 33, 2000: 21.6 / 54, 3000: 23.6 / 113 - the full-width warm start wins while the factor keeps
+        # nearly every column
+        self.mn_method = os.environ.get("MVF_MINNORM", "lowrank" if self.M >= 1024 else "full")
         self.rank_hint = 0
         # lstsq_method="cholesky" (extension, not a reference mode): jitter-escalated Cholesky, the round-1 solver
         self.jitter = 0.0
