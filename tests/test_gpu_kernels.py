@@ -350,6 +350,26 @@ def test_solve_minnorm_kernel_gram_vs_scipy_lstsq(st, n, m, method):
     np.testing.assert_allclose(e[2], w.max(), rtol=1e-9)
 
 
+def test_solve_minnorm_lr_zero_matrix_and_non_finite_input(st):
+    """The zero matrix has the minimum-norm solution 0 (factor rank 0, nothing to rotate); a non-finite entry anywhere
+    is reported through info and never turned into a silent solution."""
+    k = _k("float64")
+    m = 130
+    Z = np.zeros((m, m))
+    R = np.random.default_rng(0).standard_normal((m, 3))
+    C, info, e = _run_minnorm(k, Z, Z, 0.0, R, method="lowrank")
+    assert info == 0 and int(e[6]) == 0 and np.all(C == 0.0)
+    B = np.random.default_rng(1).standard_normal((m, 2 * m))
+    G = B @ B.T
+    for bad in (np.nan, np.inf):
+        Gb = G.copy()
+        Gb[7, 90] = Gb[90, 7] = bad
+        _, info, _ = _run_minnorm(k, Gb, Z, 0.0, R, method="lowrank")
+        assert info != 0
+    C, info, e = _run_minnorm(k, G, Z, 0.0, R, method="lowrank")  # the workspace is fine afterwards
+    assert info == 0 and _relmax(C, np.linalg.solve(G, R)) < 1e-9
+
+
 def test_solve_minnorm_lr_follows_the_previous_pivot_order(st):
     """rank_hint > 0: the factorisation follows the pivot order the previous call left in the workspace, 64 columns per
     three launches, accepting each pivot only while it is not small against the remaining diagonal.  Same matrix: same
