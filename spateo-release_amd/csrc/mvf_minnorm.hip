@@ -1471,10 +1471,9 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
         if (hs.done || j >= msteps) break;
         upto = std::min(msteps, upto + (tail_only ? 32 : 128));
     }
-    {
-        const int tag[2] = {PCHOL_MAGIC, (int)hs.r};  // this workspace now holds a finished order of hs.r rows
-        MVF_CHECK_HIP(hipMemcpyAsync(&stt->magic, tag, sizeof(tag), hipMemcpyHostToDevice, st));
-    }
+    const int tag[2] = {PCHOL_MAGIC, (int)hs.r};  // this workspace now holds a finished order of hs.r rows
+    MVF_CHECK_HIP(hipMemcpyAsync(&stt->magic, tag, sizeof(tag), hipMemcpyHostToDevice, st));  // (tag lives until the
+                                                                                                // final synchronise)
     const int64_t r = hs.r;
     if (timing) MVF_CHECK_HIP(hipEventRecord(ev[1], st));
     const double hr[1] = {(double)r};
