@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/lr4; mkdir -p $OUT
+OUT=$R/gpurun_out/minnorm_lr; mkdir -p $OUT
 cd $R
 timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -s -k "minnorm or rank_deficient" > $OUT/tests.log 2>&1; echo "tests rc $?"
 grep -E "greedy|nearby|passed|failed|Error" $OUT/tests.log | tail -8
