@@ -30,6 +30,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 struct GramPlan {
     int nt = 0, npairs = 0;
     int64_t slice_len = 0, nslices = 0;    // Gram jobs
+    int64_t phase_slices = 0, nphases = 1; // slices per launch; the partial-tile buffer holds one phase
     int64_t rslice_len = 0, rslices = 0;   // rhs jobs
     int rcolblocks = 0;
     size_t gram_bytes = 0, rhs_bytes = 0;
@@ -54,19 +55,29 @@ static int gram_slots() {
     return slots;
 }
 
-static GramPlan make_plan(int64_t n, int64_t m) {
+static GramPlan make_plan(int64_t n, int64_t m, mvf_dtype dtype) {
     GramPlan p;
     p.nt = (int)cdiv(m, GT);
     p.npairs = p.nt * (p.nt + 1) / 2;
     // Jobs = tile pairs x cell slices.  All jobs cost the same, so the launch runs in ceil(jobs / slots) rounds of
     // (slice_len + OVERHEAD) cell-times, OVERHEAD = the 128 KB partial tile a job writes and the reduce kernel reads
     // back, expressed in cells of MFMA work (measured ~150: at 50 k cells x 500 control points 1024-cell slices beat
-    // 256-cell ones by 15 % although both fill the chip).  Pick the slice count (within a memory budget of ~1.5 GB of
-    // float64 partial tiles) with the smallest modelled time.  (At 1 M cells x 300 pairs the naive 4 slices = 1200
-    // jobs on 512 slots lost 22 % to the tail.)
+    // 256-cell ones by 15 % although both fill the chip).  Pick the slice count with the smallest modelled time.  (At
+    // 1 M cells x 300 pairs the naive 4 slices = 1200 jobs on 512 slots lost 22 % to the tail.)
+    // SHORT slices also keep the workgroups that stream the same panels together: the ~24 tile pairs that share a
+    // panel start a slice in step and drift apart while they run, and once they are further apart than the 256 MB MALL
+    // holds (10 - 20 k cells of all panels) every one of them fetches the panel from HBM again.  Measured at 8 M cells x
+    // 3000 (profiles/r02_gram_slice_len.md): float64 51.1 TF with 276 k-cell slices, 53.0 / 54.3 / 54.9 / 56.4 TF at
+    // 131 k / 65 k / 32 k / 16 k, 61.1 at 8 k, 60.8 at 4 k; float32 65.6 -> 66.2 / 66.7 / 67.1 / 67.5 and 67.8 at 8 k.  So slices
+    // are capped at 8 k cells; the partial-tile buffer stays within 10 % of the size of the kernel-value cache (at most
+    // 20 GB; at least 3 GB) and is reused by several launches when the capped slices need more.
     const int64_t max_chunks = cdiv(n, GCHUNK);
-    const int64_t budget_jobs = std::max<int64_t>(p.npairs, (int64_t)(1.5e9 / (GT * GT * sizeof(double))));
-    const int64_t s_max = std::max<int64_t>(1, std::min<int64_t>(max_chunks, budget_jobs / p.npairs));
+    const double cache_bytes = (double)n * (double)m * (dtype == MVF_F64 ? 8.0 : 4.0);
+    const double budget_bytes = std::min(20e9, std::max(3e9, 0.1 * cache_bytes));
+    const int64_t budget_jobs = std::max<int64_t>(p.npairs, (int64_t)(budget_bytes / (GT * GT * sizeof(double))));
+    const int64_t fit = std::max<int64_t>(1, budget_jobs / p.npairs);  // slices whose partial tiles fit the buffer
+    constexpr int64_t SL_CAP = 8192;
+    const int64_t s_cap = std::min<int64_t>(max_chunks, std::max<int64_t>(1, cdiv(n, SL_CAP)));
     const double slots = (double)gram_slots();
     constexpr double OVERHEAD = 150.0;
     auto model = [&](int64_t s, int64_t& ns) {
@@ -74,21 +85,33 @@ static GramPlan make_plan(int64_t n, int64_t m) {
         ns = cdiv(n, sl);
         return std::ceil((double)ns * p.npairs / slots) * ((double)sl + OVERHEAD);
     };
-    int64_t best_s = s_max, ns = 0;
-    double best_t = 1e300;
-    for (int64_t s = 1; s <= s_max; ++s) best_t = std::min(best_t, model(s, ns));
-    // among plans within 0.5 % of the best modelled time take the one with the most rounds (many short rounds even
-    // out per-XCD speed differences better than a few long ones)
-    for (int64_t s = s_max; s >= 1; --s)
-        if (model(s, ns) <= best_t * 1.005) {
-            best_s = ns;
-            break;
-        }
+    int64_t best_s = s_cap, ns = 0;
+    const int64_t s_fit = std::min<int64_t>(fit, max_chunks);
+    if (s_cap <= s_fit) {
+        // one launch: the slice count in [s_cap, s_fit] with the smallest modelled time; among plans within 0.5 % of it the
+        // one with the most rounds (many short rounds even out per-XCD speed differences better than a few long ones)
+        double best_t = 1e300;
+        for (int64_t s = s_cap; s <= s_fit; ++s) best_t = std::min(best_t, model(s, ns));
+        for (int64_t s = s_fit; s >= s_cap; --s)
+            if (model(s, ns) <= best_t * 1.005) {
+                best_s = ns;
+                break;
+            }
+    } else {
+        // the capped slices need more partial tiles than the buffer holds: several launches ("phases") reuse it, each
+        // folded into G before the next one starts (8 M cells x 3000: 977 slices of 8 k cells in 2 (float64) / 4 (float32)
+        // phases).  Searching shorter slices / more phases by a tail model measured WORSE (56 instead of 61 TF in float64):
+        // every phase boundary drains the chip.
+        model(s_cap, ns);
+        best_s = ns;
+    }
     int64_t sl = cdiv(cdiv(n, best_s), GCHUNK) * GCHUNK;
     if (const char* e = getenv("MVF_SLICE_LEN")) sl = std::max<int64_t>(GCHUNK, atoll(e) / GCHUNK * GCHUNK);  // probes
     p.slice_len = sl;
     p.nslices = std::max<int64_t>(1, cdiv(n, sl));
-    p.gram_bytes = (size_t)p.nslices * p.npairs * GT * GT * sizeof(double);
+    p.nphases = cdiv(p.nslices, fit);
+    p.phase_slices = cdiv(p.nslices, p.nphases);
+    p.gram_bytes = (size_t)p.phase_slices * p.npairs * GT * GT * sizeof(double);
     p.rcolblocks = (int)cdiv(m, RHS_COLS);
     int64_t want_r = std::max<int64_t>(1, cdiv(1024, std::max(1, p.rcolblocks)));
     int64_t rsl = cdiv(cdiv(n, want_r), GCHUNK) * GCHUNK;
@@ -122,16 +145,16 @@ __global__ __launch_bounds__(256, 2) void gram_f64acc_kernel(const typename Vec4
                                                              const TIn* __restrict__ P, int64_t n,
                                                              const typename Vec4<TIn>::type* __restrict__ ctrl4,
                                                              int64_t m, TIn s, int nt, int npairs, int64_t slice_len,
-                                                             double* __restrict__ partial) {
+                                                             int64_t slice0, double* __restrict__ partial) {
     using V4 = typename Vec4<TIn>::type;
     __shared__ V4 cells[2][GCHUNK];
     const TIn PAD = sizeof(TIn) == 4 ? (TIn)1.0e18f : (TIn)1.0e150;  // padded control points sit "at infinity": K == 0 exactly
 
     const int pair = blockIdx.x % npairs;
-    const int64_t slice = blockIdx.x / npairs;
+    const int64_t slice = blockIdx.x / npairs;  // within this launch's phase; slice0 + slice = the cell slice
     int ti, tj;
     decode_pair(pair, nt, ti, tj);
-    const int64_t n0 = slice * slice_len;
+    const int64_t n0 = (slice0 + slice) * slice_len;
     const int64_t n1 = min(n, n0 + slice_len);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
@@ -429,7 +452,8 @@ __device__ __forceinline__ void cached_block(const T* __restrict__ ublk, const T
 template <typename T>
 __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const T* __restrict__ ublk, const T* __restrict__ P,
                                                              int64_t n, int64_t n_pad, int64_t m, int nt, int npairs,
-                                                             int64_t slice_len, double* __restrict__ partial) {
+                                                             int64_t slice_len, int64_t slice0,
+                                                             double* __restrict__ partial) {
     // Off-diagonal tile: wave tile 32 x 128 (2 row blocks x 8 column blocks of 16) - the four waves stack in the row
     // direction and all read the same 8 column panels (L1 hits); per k-step a lane does 10 loads and only TWO
     // v_mul_f64 (P K, kept exact) for 16 MFMAs - the f64 VALU work is what steals MFMA time on gfx950.
@@ -441,7 +465,7 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
     const int64_t slice = blockIdx.x / npairs;
     int ti, tj;
     decode_pair(pair, nt, ti, tj);
-    const int64_t n0 = slice * slice_len;
+    const int64_t n0 = (slice0 + slice) * slice_len;  // `slice` indexes the partial tile inside this launch's phase
     const int64_t n1 = min(n_pad, n0 + slice_len);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* out = partial + ((size_t)slice * npairs + pair) * (size_t)(GT * GT);
@@ -537,7 +561,7 @@ __global__ __launch_bounds__(256) void rhs_kernel(const T* __restrict__ x4, cons
 // deterministic reductions of the per-slice partials
 // ----------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ partial, int64_t nslices, int nt,
-                                                          int npairs, int64_t m, double* __restrict__ G) {
+                                                          int npairs, int64_t m, double* __restrict__ G, int accumulate) {
     const int pair = blockIdx.y;
     int ti, tj;
     decode_pair(pair, nt, ti, tj);
@@ -546,7 +570,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restri
     const int64_t i = (int64_t)ti * GT + row, j = (int64_t)tj * GT + col;
     if (i >= m || j >= m) return;
     if (ti == tj && col < row) return;  // diagonal tiles: keep the upper triangle, mirror it -> G exactly symmetric
-    double acc = 0.0;
+    double acc = accumulate ? G[i * m + j] : 0.0;  // later phases continue the sum in slice order
     const double* p = partial + (size_t)pair * (GT * GT) + e;
     const size_t stride = (size_t)npairs * (GT * GT);
     for (int64_t s = 0; s < nslices; ++s) acc += p[s * stride];
@@ -585,9 +609,8 @@ __global__ __launch_bounds__(256) void rhs_reduce_kernel(const double* __restric
 using namespace mvf;
 
 extern "C" size_t mvf_gram_workspace_bytes(int64_t n, int64_t m, mvf_dtype dtype) {
-    (void)dtype;
     if (n <= 0 || m <= 0) return 0;
-    const GramPlan p = make_plan(n, m);
+    const GramPlan p = make_plan(n, m, dtype);
     return align_up(p.gram_bytes, 256) + align_up(p.rhs_bytes, 256);
 }
 
@@ -609,24 +632,32 @@ extern "C" int mvf_gram_stages(int stages, const void* x4, const void* P, const 
     }
     MVF_REQUIRE(x4 && P && ctrl4, "mvf_gram: null input");
     MVF_REQUIRE(!(stages & MVF_GRAM_STAGE_RHS) || y4, "mvf_gram: null y4");
-    const GramPlan p = make_plan(n, m);
+    const GramPlan p = make_plan(n, m, dtype);
     const size_t need = align_up(p.gram_bytes, 256) + align_up(p.rhs_bytes, 256);
     MVF_REQUIRE(workspace && workspace_bytes >= need, "mvf_gram: workspace too small (%zu < %zu)", workspace_bytes, need);
-    MVF_REQUIRE((int64_t)p.nslices * p.npairs < (1LL << 31), "mvf_gram: too many jobs");
+    MVF_REQUIRE((int64_t)p.phase_slices * p.npairs < (1LL << 31), "mvf_gram: too many jobs");
     MVF_REQUIRE(p.rslices <= 65535, "mvf_gram: rhs slice count too large");
     double* gpart = (double*)workspace;
     double* rpart = (double*)((char*)workspace + align_up(p.gram_bytes, 256));
     const double s = std::sqrt(beta * LOG2E);
-    const unsigned njobs = (unsigned)(p.nslices * p.npairs);
     dim3 rgrid((unsigned)p.rcolblocks, (unsigned)p.rslices);
     if (stages & MVF_GRAM_STAGE_TILES) {
-        if (dtype == MVF_F32)
-            hipLaunchKernelGGL(gram_f64acc_kernel<float>, dim3(njobs), dim3(256), 0, st, (const float4*)x4,
-                               (const float*)P, n, (const float4*)ctrl4, m, (float)s, p.nt, p.npairs, p.slice_len,
-                               gpart);
-        else
-            hipLaunchKernelGGL(gram_f64acc_kernel<double>, dim3(njobs), dim3(256), 0, st, (const double4*)x4,
-                               (const double*)P, n, (const double4*)ctrl4, m, s, p.nt, p.npairs, p.slice_len, gpart);
+        MVF_REQUIRE(p.nphases == 1 || G, "mvf_gram: null G (the tile stage reduces all but its last phase)");
+        for (int64_t ph = 0; ph < p.nphases; ++ph) {
+            const int64_t s0 = ph * p.phase_slices, ns = std::min(p.phase_slices, p.nslices - s0);
+            const unsigned njobs = (unsigned)(ns * p.npairs);
+            if (dtype == MVF_F32)
+                hipLaunchKernelGGL(gram_f64acc_kernel<float>, dim3(njobs), dim3(256), 0, st, (const float4*)x4,
+                                   (const float*)P, n, (const float4*)ctrl4, m, (float)s, p.nt, p.npairs, p.slice_len, s0,
+                                   gpart);
+            else
+                hipLaunchKernelGGL(gram_f64acc_kernel<double>, dim3(njobs), dim3(256), 0, st, (const double4*)x4,
+                                   (const double*)P, n, (const double4*)ctrl4, m, s, p.nt, p.npairs, p.slice_len, s0,
+                                   gpart);
+            if (ph + 1 < p.nphases)  // the buffer is reused: fold this phase into G now
+                hipLaunchKernelGGL(gram_reduce_kernel, dim3(GT * GT / 256, (unsigned)p.npairs), dim3(256), 0, st, gpart,
+                                   ns, p.nt, p.npairs, m, G, ph > 0 ? 1 : 0);
+        }
         MVF_LAUNCH_CHECK();
     }
     if (stages & MVF_GRAM_STAGE_RHS) {
@@ -639,8 +670,10 @@ extern "C" int mvf_gram_stages(int stages, const void* x4, const void* P, const 
         MVF_LAUNCH_CHECK();
     }
     if (stages & MVF_GRAM_STAGE_REDUCE) {
+        // the last phase's partial tiles (all of them when there is one phase), added to what the tile stage folded in
+        const int64_t s0 = (p.nphases - 1) * p.phase_slices;
         hipLaunchKernelGGL(gram_reduce_kernel, dim3(GT * GT / 256, (unsigned)p.npairs), dim3(256), 0, st, gpart,
-                           p.nslices, p.nt, p.npairs, m, G);
+                           p.nslices - s0, p.nt, p.npairs, m, G, p.nphases > 1 ? 1 : 0);
         MVF_LAUNCH_CHECK();
     }
     if (stages & MVF_GRAM_STAGE_REDUCE_RHS) {
@@ -693,18 +726,27 @@ extern "C" int mvf_gram_cached(int stages, const void* ublk, const void* x4, con
     MVF_REQUIRE(ublk && P, "mvf_gram_cached: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (stages & MVF_GRAM_STAGE_TILES) {
-        const GramPlan p = make_plan(n, m);
+        const GramPlan p = make_plan(n, m, dtype);
         const size_t need = align_up(p.gram_bytes, 256) + align_up(p.rhs_bytes, 256);
         MVF_REQUIRE(workspace && workspace_bytes >= need, "mvf_gram_cached: workspace too small (%zu < %zu)",
                     workspace_bytes, need);
-        MVF_REQUIRE((int64_t)p.nslices * p.npairs < (1LL << 31), "mvf_gram_cached: too many jobs");
-        const unsigned njobs = (unsigned)(p.nslices * p.npairs);
-        if (dtype == MVF_F32)
-            hipLaunchKernelGGL(gram_cached_kernel<float>, dim3(njobs), dim3(256), 0, st, (const float*)ublk,
-                               (const float*)P, n, ublk_npad(n), m, p.nt, p.npairs, p.slice_len, (double*)workspace);
-        else
-            hipLaunchKernelGGL(gram_cached_kernel<double>, dim3(njobs), dim3(256), 0, st, (const double*)ublk,
-                               (const double*)P, n, ublk_npad(n), m, p.nt, p.npairs, p.slice_len, (double*)workspace);
+        MVF_REQUIRE((int64_t)p.phase_slices * p.npairs < (1LL << 31), "mvf_gram_cached: too many jobs");
+        MVF_REQUIRE(p.nphases == 1 || G, "mvf_gram_cached: null G (the tile stage reduces all but its last phase)");
+        for (int64_t ph = 0; ph < p.nphases; ++ph) {
+            const int64_t s0 = ph * p.phase_slices, ns = std::min(p.phase_slices, p.nslices - s0);
+            const unsigned njobs = (unsigned)(ns * p.npairs);
+            if (dtype == MVF_F32)
+                hipLaunchKernelGGL(gram_cached_kernel<float>, dim3(njobs), dim3(256), 0, st, (const float*)ublk,
+                                   (const float*)P, n, ublk_npad(n), m, p.nt, p.npairs, p.slice_len, s0,
+                                   (double*)workspace);
+            else
+                hipLaunchKernelGGL(gram_cached_kernel<double>, dim3(njobs), dim3(256), 0, st, (const double*)ublk,
+                                   (const double*)P, n, ublk_npad(n), m, p.nt, p.npairs, p.slice_len, s0,
+                                   (double*)workspace);
+            if (ph + 1 < p.nphases)
+                hipLaunchKernelGGL(gram_reduce_kernel, dim3(GT * GT / 256, (unsigned)p.npairs), dim3(256), 0, st,
+                                   (const double*)workspace, ns, p.nt, p.npairs, m, G, ph > 0 ? 1 : 0);
+        }
         MVF_LAUNCH_CHECK();
     }
     const int rest = stages & (MVF_GRAM_STAGE_RHS | MVF_GRAM_STAGE_REDUCE | MVF_GRAM_STAGE_REDUCE_RHS);

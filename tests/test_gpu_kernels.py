@@ -201,6 +201,57 @@ def test_gram_cached_u_is_bit_identical_to_recompute(st, n, m, dtype):
     assert _relmax(G1.cpu().numpy(), Gr) < (3e-6 if dtype == "float32" else 1e-11)
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_gram_partial_tiles_in_phases(st, dtype, monkeypatch):
+    """When the (capped) slices need more partial tiles than the buffer holds, the tile stage runs in several launches
+    that reuse the buffer, each folded into G before the next starts (float64 mode at 8 M cells x 3000 control points:
+    977 slices in 2 phases).  Forced here with 256-cell slices at 1.2 M cells x 300 control points (4688 slices x 6 tile
+    pairs > the 22 888 tiles of the minimum buffer): G equals the single-launch result to the rounding of the changed
+    summation partition and the NumPy Gram matrix; recompute and cached kernels stay bit-identical; the split stage calls
+    (tile stage first, reductions later: what bench.py does to time the kernel) give the same bits."""
+    n, m = 1_200_000, 300
+    rng, X, ctrl = _cloud(77, n, m)
+    beta = 0.003
+    Y = rng.standard_normal((n, 3))
+    P = torch.from_numpy(rng.uniform(1e-5, 1.0, n).astype(np.float32 if dtype == "float32" else np.float64)).to("cuda:0")
+    k = _k(dtype)
+    center = ctrl.mean(0)
+    x4, c4, y4 = k.to_x4(X, center), k.to_x4(ctrl, center), k.to_x4(Y)
+    out = {}
+    for name, sl in (("one_launch", None), ("phases", "256")):
+        if sl is None:
+            monkeypatch.delenv("MVF_SLICE_LEN", raising=False)
+        else:
+            monkeypatch.setenv("MVF_SLICE_LEN", sl)
+        kk = _k(dtype)
+        G = torch.empty(m, m, dtype=torch.float64, device="cuda:0")
+        R = torch.empty(m, 3, dtype=torch.float64, device="cuda:0")
+        kk.gram(x4, P, y4, c4, beta, G, R)
+        kk.build_ublk(x4, c4, beta)
+        Gc, Rc = torch.empty_like(G), torch.empty_like(R)
+        kk.gram_events = []  # the timed path: tile stage and reductions as separate calls
+        kk.gram(x4, P, y4, c4, beta, Gc, Rc)
+        assert len(kk.gram_events) == 1
+        assert torch.equal(G, Gc) and torch.equal(R, Rc)
+        assert torch.equal(G, G.T)
+        out[name] = G.cpu().numpy()
+        if sl is not None:  # the buffer really is smaller than all partial tiles
+            need = kk.lib.mvf_gram_workspace_bytes(n, m, kk.cdtype)
+            assert need < (n // 256) * 6 * 128 * 128 * 8
+    monkeypatch.delenv("MVF_SLICE_LEN", raising=False)
+    assert _relmax(out["phases"], out["one_launch"]) < 1e-12
+    U = svo.con_K(X[:100_000], ctrl, beta)
+    # (the oracle on the first 100 k cells only bounds nothing about the rest; the full comparison is the one above)
+    Gr = (U.T * P.double().cpu().numpy()[None, :100_000]) @ U
+    kk = _k(dtype)
+    G = torch.empty(m, m, dtype=torch.float64, device="cuda:0")
+    R = torch.empty(m, 3, dtype=torch.float64, device="cuda:0")
+    monkeypatch.setenv("MVF_SLICE_LEN", "256")
+    # 100 k cells x 6 pairs at 256-cell slices = 2346 tiles: one phase; 1.2 M: two - same kernels, so a cheap oracle check
+    kk.gram(x4[:100_000].contiguous(), P[:100_000].contiguous(), y4[:100_000].contiguous(), c4, beta, G, R)
+    assert _relmax(G.cpu().numpy(), Gr) < (3e-6 if dtype == "float32" else 1e-11)
+
+
 # ------------------------------------------------------------------------------------------------- solve
 @pytest.mark.parametrize("m,nrhs", [(64, 3), (100, 3), (300, 2), (517, 1)])
 def test_solve_spd_vs_numpy(st, m, nrhs):
