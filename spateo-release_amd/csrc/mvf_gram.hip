@@ -102,7 +102,12 @@ static GramPlan make_plan(int64_t n, int64_t m, mvf_dtype dtype) {
         // folded into G before the next one starts (8 M cells x 3000: 977 slices of 8 k cells in 2 (float64) / 4 (float32)
         // phases).  Searching shorter slices / more phases by a tail model measured WORSE (56 instead of 61 TF in float64):
         // every phase boundary drains the chip.
-        model(s_cap, ns);
+        // Slices up to 10 % longer than the cap are accepted if that saves a launch (977 = 4 x 244 + 1 slices would
+        // otherwise take a fifth phase for one slice).
+        int64_t s = s_cap;
+        const int64_t nph0 = cdiv(s_cap, fit);
+        if (nph0 > 1 && (nph0 - 1) * fit * 10 >= s_cap * 9) s = (nph0 - 1) * fit;
+        model(s, ns);
         best_s = ns;
     }
     int64_t sl = cdiv(cdiv(n, best_s), GCHUNK) * GCHUNK;

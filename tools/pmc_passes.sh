@@ -10,7 +10,10 @@ OUT=$R/gpurun_out/r2pmc
 mkdir -p $OUT
 B="python $R/bench.py --no-conk --cpu-cells 0 --no-f64 --lstsq cholesky --steps 1 --warmup 1"
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
-for cfg in "8m_f32:--cells 8000000 --dtype float32" "8m_f64:--cells 8000000 --dtype float64" "1m_f32:--cells 1000000 --dtype float32" "1m_f64:--cells 1000000 --dtype float64"; do
+ALL=("8m_f32:--cells 8000000 --dtype float32" "8m_f64:--cells 8000000 --dtype float64" "1m_f32:--cells 1000000 --dtype float32" "1m_f64:--cells 1000000 --dtype float64")
+# PMC_CONFIGS="8m_f32 8m_f64" restricts the passes to some configurations
+for cfg in "${ALL[@]}"; do
+  if [ -n "${PMC_CONFIGS:-}" ] && [[ " $PMC_CONFIGS " != *" ${cfg%%:*} "* ]]; then continue; fi
   name=${cfg%%:*}; args=${cfg#*:}
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $ctr --kernel-trace -d $OUT/${name}_$ctr -o p -- $B $args > /dev/null 2>&1
