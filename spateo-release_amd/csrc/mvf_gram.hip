@@ -449,7 +449,7 @@ __device__ __forceinline__ void cached_block(const T* __restrict__ ublk, const T
                 for (int r = 0; r < 4; ++r) {
                     const int row = orow0 + a * 16 + lk + 4 * r;
                     const int col = ocol0 + b * 16 + li;
-                    out[row * GT + col] = acc[a][b][r];
+                    __builtin_nontemporal_store(acc[a][b][r], &out[row * GT + col]);  // read once, by the reduction
                 }
             }
 }
