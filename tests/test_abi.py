@@ -82,6 +82,26 @@ def test_error_channel_without_launching_anything():
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_gram_workspace_is_bounded_by_a_fraction_of_the_kernel_value_cache():
+    """The Gram tile stage runs 8 k-cell slices in phases that REUSE one partial-tile buffer: the workspace stays within
+    ~10 % of the kernel-value cache (3 GB floor, 20 GB cap) whatever the cell count, instead of one 128 KB tile per
+    (slice, tile pair) - 38 GB at 8 M cells x 3000 control points."""
+    from spateo_amd import _lib
+
+    lib = _lib.load()
+    tile = 128 * 128 * 8
+    for n, m, dt, dsize in ((8_000_000, 3000, _lib.MVF_F32, 4), (8_000_000, 3000, _lib.MVF_F64, 8), (1_000_000, 3000, _lib.MVF_F32, 4),
+                            (50_000, 500, _lib.MVF_F32, 4), (300_000_000, 3000, _lib.MVF_F32, 4), (1000, 100, _lib.MVF_F64, 8)):
+        nt = -(-m // 128)
+        npairs = nt * (nt + 1) // 2
+        ws = lib.mvf_gram_workspace_bytes(n, m, dt)
+        rhs_part = 1100 * m * 4 * 8  # ~1024 rhs slices of m x 4 float64
+        assert ws >= npairs * tile
+        assert ws <= max(3e9, min(20e9, 0.1 * n * m * dsize)) + npairs * tile + rhs_part + 4096, (n, m, ws)
+    all_tiles = (8_000_000 // 8192 + 1) * 300 * tile
+    assert lib.mvf_gram_workspace_bytes(8_000_000, 3000, _lib.MVF_F32) < all_tiles / 3
+
+
 def test_no_gpu_means_loud_failure_not_a_fallback():
     import spateo_amd as st
     from spateo_amd import _lib
