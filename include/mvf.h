@@ -195,6 +195,15 @@ int mvf_solve_minnorm_lr(const double* G, const double* K, double lambda_sigma2,
                          const double* R, int64_t m, int nrhs, double* C, int* info, double* einfo, int max_sweeps,
                          int reuse, int rank_hint, void* workspace, size_t workspace_bytes, void* stream);
 
+/* diag_out[n] = (U pinv(A) U^T)_nn, U = con_K(x, ctrl, beta), with the decomposition of A that the previous
+ * mvf_solve_minnorm_lr (lowrank != 0) / mvf_solve_minnorm (lowrank == 0) call left in `workspace` (same m, same rcond
+ * semantics: eigenvalues below rcond * max|lambda| dropped).  Replaces the last statement of
+ * `Morpho_pairwise._update_nonrigid`, spateo/alignment/methods/morpho_class.py:1295-1297:
+ * `SigmaDiag = sigma2 * einsum("ij->i", einsum("ij,ji->ij", U, dot(Sigma, U.T)))` (the caller multiplies by sigma2).
+ * x4: n x 4 (dtype), ctrl4: m x 4 (dtype), diag_out: n float64.  Synchronises `stream` once on the lowrank path. */
+int mvf_pinv_diag(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, double rcond, int lowrank,
+                  double* diag_out, void* workspace, size_t workspace_bytes, mvf_dtype dtype, void* stream);
+
 /* trace(C^T K C) -> out[0] (float64), the regulariser of the energy (App. A 5b). K: m x m, C: m x nrhs;
  * scratch >= m float64 (row partials, summed in row order). */
 int mvf_quadform(const double* K, const double* C, int64_t m, int nrhs, double* out, double* scratch, void* stream);

@@ -1142,6 +1142,79 @@ static LrPlan lr_plan(int64_t m) {
     return p;
 }
 
+
+// ---- diag(U pinv(A) U^T) from the decomposition a solve left in its workspace ------------------------------------------
+// (the alignment's variational sigma^2 needs SigmaDiag = sigma2 diag(U pinv(SigmaInv) U^T), morpho_class.py:1295-1297).
+// Rows of Y are sigma_i w_i^T, so  pinv(A) = sum_kept w_i w_i^T / lambda_i  and
+//   d_n = sum_i g_i (sum_m K(x_n, c_m) Y[i][m])^2,   g_i = [kept] / (sigma_i^2 lambda_i)   (the weights of the solve).
+__global__ __launch_bounds__(256) void pinv_weights_kernel(const double* __restrict__ sig2, int64_t nrows,
+                                                           const double* __restrict__ scal, double rcond,
+                                                           double* __restrict__ gw) {
+    __shared__ double red[4];
+    __shared__ double bc;
+    const double delta = scal[1];
+    double mx = 0.0;
+    for (int64_t i = threadIdx.x; i < nrows; i += 256)
+        if (sig2[i] > 0.0) mx = fmax(mx, fabs(sig2[i] - delta));
+    const double t = -block_min<256>(-mx, red);
+    if (threadIdx.x == 0) bc = t;
+    __syncthreads();
+    const double cut = rcond * bc;
+    for (int64_t i = threadIdx.x; i < nrows; i += 256) {
+        const double s2 = sig2[i], lam = s2 - delta;
+        gw[i] = (s2 > 0.0 && fabs(lam) > cut) ? 1.0 / (s2 * lam) : 0.0;
+    }
+}
+
+constexpr int PD_CT = 128;  // control points per LDS stage
+constexpr int PD_RB = 8;    // rows of Y per pass over the control points
+template <typename T>
+__global__ __launch_bounds__(256) void pinv_diag_kernel(const T* __restrict__ x4, int64_t n, const T* __restrict__ ctrl4,
+                                                        int64_t m, T s, const double* __restrict__ Y, int64_t nrows,
+                                                        int64_t mp, const double* __restrict__ gw,
+                                                        double* __restrict__ out) {
+    using V4T = typename Vec4<T>::type;
+    __shared__ V4T sc[PD_CT];
+    __shared__ double sy[PD_RB][PD_CT];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const V4T xv = (i < n) ? reinterpret_cast<const V4T*>(x4)[i] : V4T{0, 0, 0, 0};
+    const T px = xv.x * s, py = xv.y * s, pz = xv.z * s;
+    double d = 0.0;
+    for (int64_t rb = 0; rb < nrows; rb += PD_RB) {
+        double acc[PD_RB];
+#pragma unroll
+        for (int q = 0; q < PD_RB; ++q) acc[q] = 0.0;
+        for (int64_t m0 = 0; m0 < m; m0 += PD_CT) {
+            const int mc = (int)min((int64_t)PD_CT, m - m0);
+            __syncthreads();
+            if (threadIdx.x < PD_CT) {
+                const int j = threadIdx.x;
+                if (j < mc) {
+                    const V4T cv = reinterpret_cast<const V4T*>(ctrl4)[m0 + j];
+                    sc[j] = V4T{cv.x * s, cv.y * s, cv.z * s, 0};
+                } else {
+                    sc[j] = V4T{0, 0, 0, 0};
+                }
+            }
+            for (int e = threadIdx.x; e < PD_RB * PD_CT; e += 256) {
+                const int q = e / PD_CT, j = e % PD_CT;
+                sy[q][j] = (rb + q < nrows && j < mc) ? Y[(rb + q) * mp + m0 + j] : 0.0;  // zero rows / columns add nothing
+            }
+            __syncthreads();
+            for (int j = 0; j < mc; ++j) {
+                const V4T cv = sc[j];
+                const double k = (double)kernel_value(px, py, pz, cv.x, cv.y, cv.z);
+#pragma unroll
+                for (int q = 0; q < PD_RB; ++q) acc[q] = fma(k, sy[q][j], acc[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PD_RB; ++q)
+            if (rb + q < nrows) d = fma(gw[rb + q] * acc[q], acc[q], d);
+    }
+    if (i < n) out[i] = d;
+}
+
 struct JacPlan {
     int64_t mp;
     int nb, npairs, nsplit, kchunks, bsplit, rows_per_split;
@@ -1545,5 +1618,60 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
     const double hsw[1] = {(double)sweeps + (hrot != 0 ? 0.5 : 0.0)};  // x.5 = sweep cap hit before convergence
     MVF_CHECK_HIP(hipMemcpyAsync(einfo, hsw, sizeof(double), hipMemcpyHostToDevice, st));
     MVF_CHECK_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int mvf_pinv_diag(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, double rcond,
+                             int lowrank, double* diag_out, void* workspace, size_t workspace_bytes, mvf_dtype dtype,
+                             void* stream) {
+    MVF_REQUIRE(n >= 0 && m > 0, "mvf_pinv_diag: need n >= 0 and m > 0");
+    MVF_REQUIRE(beta >= 0.0 && std::isfinite(beta) && rcond >= 0.0, "mvf_pinv_diag: bad beta / rcond");
+    MVF_REQUIRE(dtype == MVF_F32 || dtype == MVF_F64, "mvf_pinv_diag: bad dtype %d", (int)dtype);
+    if (n == 0) return 0;
+    MVF_REQUIRE(x4 && ctrl4 && diag_out && workspace, "mvf_pinv_diag: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const double *Y, *sig2, *scal;
+    double* gw;
+    int64_t nrows, mp;
+    if (lowrank) {
+        const LrPlan p = lr_plan(m);
+        MVF_REQUIRE(workspace_bytes >= p.total, "mvf_pinv_diag: not the workspace of mvf_solve_minnorm_lr for this m");
+        PcholState hs;
+        MVF_CHECK_HIP(hipMemcpyAsync(&hs, ws + p.off_state, sizeof(hs), hipMemcpyDeviceToHost, st));
+        MVF_CHECK_HIP(hipStreamSynchronize(st));
+        MVF_REQUIRE(hs.magic == PCHOL_MAGIC && hs.r >= 0 && hs.r <= m, "mvf_pinv_diag: the workspace holds no finished decomposition");
+        mp = p.mp;
+        nrows = cdiv(hs.r, 64) * 64;
+        Y = (const double*)(ws + p.off_y);
+        sig2 = (const double*)(ws + p.off_sig2);
+        scal = (const double*)(ws + p.off_scal);  // [1] = 0: no shift on this path
+        gw = (double*)(ws + p.off_t);
+    } else {
+        const JacPlan p = jac_plan(m, 1);
+        MVF_REQUIRE(workspace_bytes >= p.total, "mvf_pinv_diag: not the workspace of mvf_solve_minnorm for this m");
+        CholPlan cq;
+        chol_layout(m, 0, workspace, &cq);
+        mp = p.mp;
+        nrows = p.mp;
+        Y = (const double*)(ws + p.off_y);
+        sig2 = (const double*)(ws + p.off_sig2);
+        scal = cq.scal;  // [1] = the shift delta that the solve subtracted from the eigenvalues
+        gw = (double*)(ws + p.off_t);
+    }
+    if (nrows == 0) {
+        MVF_CHECK_HIP(hipMemsetAsync(diag_out, 0, (size_t)n * sizeof(double), st));
+        return 0;
+    }
+    hipLaunchKernelGGL(pinv_weights_kernel, dim3(1), dim3(256), 0, st, sig2, nrows, scal, rcond, gw);
+    const double s = std::sqrt(beta * LOG2E);
+    const unsigned grid = (unsigned)cdiv(n, 256);
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(pinv_diag_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x4, n, (const float*)ctrl4, m,
+                           (float)s, Y, nrows, mp, gw, diag_out);
+    else
+        hipLaunchKernelGGL(pinv_diag_kernel<double>, dim3(grid), dim3(256), 0, st, (const double*)x4, n,
+                           (const double*)ctrl4, m, s, Y, nrows, mp, gw, diag_out);
+    MVF_LAUNCH_CHECK();
     return 0;
 }

@@ -238,6 +238,20 @@ class HipKernels:
                                               self._mn_ws.numel(), self._stream()), "mvf_solve_minnorm")
 
     @_on_device
+    def pinv_diag(self, x4, ctrl4, beta, rcond=None, lowrank=False):
+        """diag(U pinv(A) U^T) (float64, n) from the decomposition the last solve_minnorm_lr (lowrank=True) / solve_minnorm
+        call of this object left in its workspace; U = con_K(x, ctrl, beta) is regenerated, never materialised."""
+        ws = self._lr_ws if lowrank else self._mn_ws
+        if ws is None:
+            raise RuntimeError("pinv_diag without a previous decomposition")
+        n, m = x4.shape[0], ctrl4.shape[0]
+        out = torch.empty(n, dtype=torch.float64, device=self.device)
+        rc = float(np.finfo(np.float64).eps) if rcond is None else float(rcond)
+        _lib.check(self.lib.mvf_pinv_diag(_ptr(x4), n, _ptr(ctrl4), m, float(beta), rc, 1 if lowrank else 0, _ptr(out),
+                                          _ptr(ws), ws.numel(), self.cdtype, self._stream()), "mvf_pinv_diag")
+        return out
+
+    @_on_device
     def solve_minnorm_lr(self, G, K, lambda_sigma2, R, C_out, info, einfo, rcond=None, reuse=False, max_sweeps=60,
                          rank_hint=0, tolf=0.25):
         """The same truncated minimum-norm solve through the rank-revealing factor (pivoted Cholesky stopped at

@@ -34,8 +34,9 @@ def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, l
     * ``U @ Coff``                               -> ``mvf_apply``.
 
     ``PXB_term`` (n x D) is the reference's ``P @ coordsB - RnA * K_NA[:, None]`` (O(n nb) host work that belongs to the
-    assignment step, not to this one).  Returns ``{"SigmaInv", "Coff", "VnA"}`` as host float64.  ``SigmaDiag`` (the
-    n-vector ``sigma2 diag(U pinv(SigmaInv) U^T)`` feeding the alignment's variational sigma^2) is not computed."""
+    assignment step, not to this one).  Returns ``{"SigmaInv", "Coff", "VnA", "SigmaDiag"}`` as host float64;
+    ``SigmaDiag`` = ``sigma2 diag(U pinv(SigmaInv) U^T)`` (the n-vector feeding the alignment's variational sigma^2,
+    ``:1295-1297``) comes from the decomposition the solve left on the device (``mvf_pinv_diag``)."""
     if dtype not in ("float32", "float64"):
         raise ValueError("dtype must be 'float32' or 'float64'")
     X = np.asarray(coordsA, dtype=np.float64)
@@ -61,7 +62,8 @@ def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, l
     ls2 = float(sigma2) * float(lambdaVF)
     C, info, einfo = k.zeros(m, 3, dtype=f64), k.zeros(1, dtype=torch.int32), k.zeros(12, dtype=f64)
     rcond = m * float(np.finfo(np.float64).eps)
-    if m >= 1024 and hasattr(k, "solve_minnorm_lr"):
+    lowrank = m >= 1024 and hasattr(k, "solve_minnorm_lr")
+    if lowrank:
         # rank-revealing factor + Jacobi on its columns (the faster path once the factor drops most columns)
         k.solve_minnorm_lr(G, Gamma, ls2, R, C, info, einfo, rcond=rcond)
         if int(info.cpu()[0]) != 0:
@@ -77,8 +79,12 @@ def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, l
                 raise _lib.MVFError("update_nonrigid: SigmaInv is not numerically positive semi-definite")
     V4, _ = k.apply(x4, c4, float(beta), C)
     SigmaInv = G.cpu().numpy() + ls2 * Gamma.cpu().numpy()
-    return {"SigmaInv": SigmaInv, "Coff": C.cpu().numpy()[:, :D].copy(),
-            "VnA": V4[:, :D].to(f64).cpu().numpy()}
+    # SigmaDiag = sigma2 diag(U pinv(SigmaInv) U^T) (morpho_class.py:1295-1297) from the decomposition the solve left
+    diag = k.pinv_diag(x4, c4, float(beta), rcond=rcond, lowrank=lowrank) if hasattr(k, "pinv_diag") else None
+    out = {"SigmaInv": SigmaInv, "Coff": C.cpu().numpy()[:, :D].copy(), "VnA": V4[:, :D].to(f64).cpu().numpy()}
+    if diag is not None:
+        out["SigmaDiag"] = float(sigma2) * diag.cpu().numpy()
+    return out
 
 
 def BA_transform(vecfld, quary_points, deformation_scale: int = 1, dtype: str = "float64", device=None):

@@ -29,6 +29,7 @@ def check_ba(fn, g, rtol, **kw):
 def check_update_nonrigid(fn, g, dtype, device=None):
     """fn = spateo_amd.align.update_nonrigid against the goldens of the real Morpho_pairwise._update_nonrigid."""
     tol = {"float64": (1e-8, 1e-8, 5e-3), "float32": (2e-3, 1e-3, 2e-2)}[dtype]
+    dtol = {"float64": (1e-8, 1e-3), "float32": (2e-3, 5e-2)}[dtype]  # SigmaDiag: well conditioned / rank deficient case
     out = {}
     for tag in ("a", "b"):
         r = fn(g[f"{tag}_coordsA"], g[f"{tag}_inducing_variables"], float(g[f"{tag}_beta"]), g[f"{tag}_K_NA"],
@@ -37,7 +38,10 @@ def check_update_nonrigid(fn, g, dtype, device=None):
         assert r["Coff"].shape == g[f"{tag}_Coff"].shape and r["VnA"].shape == g[f"{tag}_VnA"].shape
         e_s = rel(r["SigmaInv"], g[f"{tag}_SigmaInv"])
         e_v = rel(r["VnA"], g[f"{tag}_VnA"])
-        out[tag] = (e_s, e_v)
+        e_d = rel(r["SigmaDiag"], g[f"{tag}_SigmaDiag"])
+        assert r["SigmaDiag"].shape == g[f"{tag}_SigmaDiag"].shape
+        assert e_d < dtol[0 if tag == "a" else 1], (tag, e_d)
+        out[tag] = (e_s, e_v, e_d)
         assert e_s < (1e-10 if dtype == "float64" else 1e-5), (tag, e_s)
         if tag == "a":  # well conditioned: the coefficients themselves are determined
             assert rel(r["Coff"], g["a_Coff"]) < tol[0]

@@ -169,6 +169,19 @@ class CpuKernels:
             einfo[0] = 1.0
             einfo[6] = float(r)
 
+    def pinv_diag(self, x4, ctrl4, beta, rcond=None, lowrank=False):
+        """diag(U pinv(A) U^T) from the decomposition of the last solve_minnorm_lr / solve_minnorm call."""
+        rc = np.finfo(float).eps if rcond is None else rcond
+        X, ctrl = _np(x4)[:, :3], _np(ctrl4)[:, :3]
+        U = svo.con_K(X, ctrl, beta).reshape(len(X), len(ctrl))
+        if lowrank:
+            q, w, _ = self._lr
+        else:
+            w, q = self._eig
+        keep = np.abs(w) > rc * np.abs(w).max() if len(w) else np.zeros(0, bool)
+        Z = U @ q[:, keep]
+        return torch.from_numpy((Z * Z / w[keep]).sum(1))
+
     def sym_pack(self, G, tri):
         g = _np(G)
         tri.copy_(torch.from_numpy(g[np.triu_indices(len(g))]))

@@ -421,6 +421,36 @@ def test_solve_minnorm_lr_zero_matrix_and_non_finite_input(st):
     assert info == 0 and _relmax(C, np.linalg.solve(G, R)) < 1e-9
 
 
+@pytest.mark.parametrize("m,lowrank", [(1100, True), (300, False)])
+def test_pinv_diag_is_the_leverage_of_the_kernel_matrix(st, m, lowrank):
+    """mvf_pinv_diag: diag(U pinv(A) U^T) from the decomposition the solve left in its workspace.  With A = U^T U these
+    are the leverage scores of U's rows: in [0, 1], summing to the kept rank; checked against NumPy's eigh with the same
+    cut-off (1e-10 relative: clear of the rounding level, so the truncated sum is well determined)."""
+    n = 3000
+    rng, X, ctrl = _cloud(m, n, m)
+    beta = 0.004
+    U = svo.con_K(X, ctrl, beta)
+    G = U.T @ U
+    R = rng.standard_normal((m, 3))
+    rcond = 1e-10
+    k = _k("float64")
+    C, info, e = _run_minnorm(k, G, np.zeros((m, m)), 0.0, R, method="lowrank" if lowrank else "full", rcond=rcond)
+    assert info == 0
+    center = ctrl.mean(0)
+    x4, c4 = k.to_x4(X, center), k.to_x4(ctrl, center)
+    d = k.pinv_diag(x4, c4, beta, rcond=rcond, lowrank=lowrank).cpu().numpy()
+    w, q = np.linalg.eigh(G)
+    keep = w > rcond * w.max()
+    Z = U @ q[:, keep]
+    dr = (Z * Z / w[keep]).sum(1)
+    print(f"m={m} lowrank={lowrank}: kept {int(e[1])} (numpy {keep.sum()}), leverage sum {d.sum():.3f}, max rel dev "
+          f"{np.abs(d - dr).max() / dr.max():.2e}")
+    assert abs(int(e[1]) - int(keep.sum())) <= 2
+    assert np.abs(d - dr).max() < 1e-4 * dr.max() + 2.0 * abs(int(e[1]) - int(keep.sum()))
+    assert d.min() > -1e-9 and d.max() < 1.0 + 1e-6
+    assert abs(d.sum() - int(e[1])) < 1e-3 * int(e[1])
+
+
 def test_solve_minnorm_lr_follows_the_previous_pivot_order(st):
     """rank_hint > 0: the factorisation follows the pivot order the previous call left in the workspace, 64 columns per
     three launches, accepting each pivot only while it is not small against the remaining diagonal.  Same matrix: same
