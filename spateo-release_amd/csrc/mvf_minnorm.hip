@@ -6,7 +6,15 @@
 // sparsevfc.py:110,194,250); in-tree analogue `_pinv(SigmaInv)` spateo/alignment/methods/morpho_class.py:1287.
 // lhs is symmetric, so its singular values are |eigenvalues| and the SVD-truncated solution is the formula above.
 //
-// Algorithm (hand-written for gfx950; no rocSOLVER):
+// Two hand-written solvers for gfx950 (no rocSOLVER) share the Jacobi kernels of this file:
+//
+// mvf_solve_minnorm_lr (the host uses it from m = 1024): rank-revealing.
+//   1. A = L L^T + E, L m x r: greedy diagonally pivoted Cholesky (LAPACK pstrf's lazy scheme, one launch per pivot and one
+//      MFMA trailing update per 64), stopped when every remaining diagonal entry is <= 0.25 eps lambda_max; from the second
+//      call on a workspace it follows the previous call's pivot order in 64-column panels (three launches per 64 pivots).
+//   2. one-sided block Jacobi on the r columns of L only;  3. as below with delta = 0.
+//
+// mvf_solve_minnorm (m < 1024, where the factor keeps nearly every column and a warm start pays): full width.
 //   1. A + delta I = L L^T      blocked Cholesky of mvf_solve.hip, delta = shift * mean(diag) > 0 only makes the
 //                               factorisation exist (A is numerically semi-definite); it is subtracted again below.
 //   2. one-sided block Jacobi on the COLUMNS of L (Veselic-Hari: orthogonalising L's columns diagonalises L^T L, one
@@ -20,6 +28,7 @@
 //      delta and   C = Y^T ( g .* (Y R) ),   g_i = [|lambda_i| > rcond max|lambda|] / (sigma_i^2 lambda_i).
 // Every transformation applied to Y is orthogonal to rounding, so Y^T Y == L L^T to rounding whatever the rotation
 // choices were: the result is the truncated solve of a matrix within O(eps ||A||) of A, like gelsd's.
+// mvf_pinv_diag evaluates diag(U pinv(A) U^T) from the Y either solver left behind.
 #include "mvf_common.h"
 #include "mvf_solve.h"
 
