@@ -58,6 +58,14 @@ size_t mvf_unique_rows_workspace_bytes(int64_t n, int d);
 int mvf_unique_rows(const double* X, int64_t n, int d, int64_t* uid, double* rows, int64_t* count, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* ---- preprocessing: kNN bandwidth -------------------------------------------------------------------------------------
+ * Replaces the neighbour search of dynamo `bandwidth_selector` (exact kNN with
+ * k = max(2, int(0.2 m)) neighbours incl. the point itself, `d = mean(dist[:, 1:]) / 1.5`, `h = sqrt(2) d`).
+ * X: m x d float64 row-major (device), 1 <= m <= 8192, d <= 8.  rowsum[i] (device, m float64) = sum of the distances from
+ * point i to its k - 1 nearest OTHER points; the caller takes mean = sum(rowsum) / (m (k - 1)).  One workgroup per point:
+ * all m squared distances in LDS, bitonic sort, fixed-order sum (deterministic). */
+int mvf_knn_rowsum(const double* X, int64_t m, int d, int k, double* rowsum, void* stream);
+
 /* ---- con_K ----------------------------------------------------------------------------------------------------
  * K[i, j] = exp(-beta * ||x_i - y_j||^2), materialised n x m row-major.
  * Replaces: dynamo `con_K` / in-tree twin `_con_K` spateo/tdr/morphometrics/morphofield/gaussian_process.py:16-36

@@ -85,6 +85,54 @@ static PrepPlan prep_plan(int64_t n) {
     return p;
 }
 
+
+// ---- kNN bandwidth of the control points ----------------------------------------------------------------------------
+// dynamo `bandwidth_selector`: exact kNN with k = max(2, int(0.2 m)) neighbours (self included), d = mean of the k - 1
+// non-self distances over all points, h = sqrt(2) d / 1.5.  One workgroup per point: all m
+// squared distances into LDS (float64; the squares are accumulated coordinate by coordinate, no contraction), an
+// ascending bitonic sort of the padded power-of-two array, then the sum of the square roots of ranks 1 .. k-1 (rank 0 is
+// the point itself).  rowsum[i] is deterministic (fixed-order block sum); the host takes the mean.
+__global__ __launch_bounds__(256) void knn_rowsum_kernel(const double* __restrict__ X, int m, int d, int k, int np2,
+                                                         double* __restrict__ rowsum) {
+    extern __shared__ double sd[];
+    __shared__ double red[4];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    double xi[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) xi[c] = c < d ? X[(int64_t)i * d + c] : 0.0;
+    for (int j = tid; j < np2; j += 256) {
+        double s2 = INFINITY;
+        if (j < m) {
+            s2 = 0.0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < d) {
+                    const double df = xi[c] - X[(int64_t)j * d + c];
+                    s2 = s2 + df * df;
+                }
+        }
+        sd[j] = s2;
+    }
+    for (int size = 2; size <= np2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < np2 / 2; t += 256) {
+                const int i0 = (t / stride) * 2 * stride + (t % stride), i1 = i0 + stride;
+                const bool up = (i0 & size) == 0;
+                const double a = sd[i0], b = sd[i1];
+                if ((a > b) == up) {
+                    sd[i0] = b;
+                    sd[i1] = a;
+                }
+            }
+        }
+    __syncthreads();
+    double acc = 0.0;
+    for (int j = 1 + tid; j < k; j += 256) acc += sqrt(sd[j]);
+    const double t = block_sum<256>(acc, red);
+    if (tid == 0) rowsum[i] = t;
+}
+
 }  // namespace mvf
 
 using namespace mvf;
@@ -127,6 +175,19 @@ extern "C" int mvf_unique_rows(const double* X, int64_t n, int d, int64_t* uid, 
     MVF_CHECK_HIP(rocprim::select(tmp, bytes, ia, flag, (long long*)uid, (long long*)count, (size_t)n, st));
     hipLaunchKernelGGL(prep_gather_rows_kernel, grid, dim3(256), 0, st, X, d, (const long long*)uid,
                        (const long long*)count, rows);
+    MVF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mvf_knn_rowsum(const double* X, int64_t m, int d, int k, double* rowsum, void* stream) {
+    MVF_REQUIRE(m >= 1 && m <= 8192 && d >= 1 && d <= 8, "mvf_knn_rowsum: need 1 <= m <= 8192 points of 1 <= d <= 8 (got %lld x %d)",
+                (long long)m, d);
+    MVF_REQUIRE(k >= 2 && k <= m, "mvf_knn_rowsum: need 2 <= k <= m (got k=%d, m=%lld)", k, (long long)m);
+    MVF_REQUIRE(X && rowsum, "mvf_knn_rowsum: null pointer");
+    int np2 = 2;
+    while (np2 < m) np2 <<= 1;
+    hipLaunchKernelGGL(knn_rowsum_kernel, dim3((unsigned)m), dim3(256), (size_t)np2 * sizeof(double), (hipStream_t)stream, X,
+                       (int)m, d, k, np2, rowsum);
     MVF_LAUNCH_CHECK();
     return 0;
 }

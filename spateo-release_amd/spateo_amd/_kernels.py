@@ -104,6 +104,17 @@ class HipKernels:
         return rows[:k].cpu().numpy(), uid[:k].cpu().numpy()
 
     @_on_device
+    def knn_mean_distance(self, X, k):
+        """Mean distance from each point to its k - 1 nearest other points (host float64 (m, d) in, float out): the
+        neighbour search of dynamo's bandwidth_selector on the device (m <= 8192, d <= 8)."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        m, d = X.shape
+        xd = torch.from_numpy(X).to(self.device)
+        rows = torch.empty(m, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mvf_knn_rowsum(_ptr(xd), m, d, int(k), _ptr(rows), self._stream()), "mvf_knn_rowsum")
+        return float(np.sum(rows.cpu().numpy()) / (m * (k - 1)))
+
+    @_on_device
     def con_k(self, x, y, beta, return_d=False, dtype=None):
         """x: (n, d), y: (m, d) device tensors (cell dtype, or `dtype`) -> K (n, m) [and D (n, d, m)]."""
         tdtype, cdtype = _DT[dtype] if dtype is not None else (self.tdtype, self.cdtype)

@@ -26,6 +26,7 @@ SIGNATURES = {
     "mvf_device_count": (_i, [C.POINTER(C.c_int)]),
     "mvf_unique_rows_workspace_bytes": (_sz, [_i64, _i]),
     "mvf_unique_rows": (_i, [_p, _i64, _i, _p, _p, _p, _p, _sz, _p]),
+    "mvf_knn_rowsum": (_i, [_p, _i64, _i, _i, _p, _p]),
     "mvf_con_k": (_i, [_p, _i64, _p, _i64, _i, _d, _p, _i, _p]),
     "mvf_con_k_d": (_i, [_p, _i64, _p, _i64, _i, _d, _p, _p, _i, _p]),
     "mvf_reduce_scratch_doubles": (_sz, [_i64]),

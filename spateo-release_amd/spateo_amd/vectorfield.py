@@ -79,14 +79,26 @@ def set_default_dtype(dtype: str):
 # =====================================================================================================================
 # host-side preprocessing (dynamo SparseVFC steps 1-3) - NumPy on purpose
 # =====================================================================================================================
-def bandwidth_selector(X: np.ndarray) -> float:
-    """dynamo ``bandwidth_selector``: exact kNN, k = max(2, int(0.2 n)) incl. self; h = sqrt(2) mean(d[:, 1:]) / 1.5."""
-    from scipy.spatial import cKDTree
+_DEVICE_KNN_MIN_POINTS = 1024
 
+
+def bandwidth_selector(X: np.ndarray, device=None) -> float:
+    """dynamo ``bandwidth_selector``: exact kNN, k = max(2, int(0.2 n)) incl. self; h = sqrt(2) mean(d[:, 1:]) / 1.5.
+    From 1024 points on, with a GPU: the neighbour search runs on the device (``mvf_knn_rowsum``: all squared distances of
+    a point in LDS, bitonic sort; 0.33 s of kd-tree time at 3000 control points -> about a millisecond); same distances,
+    summed in another order: h agrees with the host path to ~1e-15 relative."""
     n = X.shape[0]
     k = max(2, int(0.2 * n))
     if k > n:  # same condition and exception type as the sklearn kNN the reference goes through (a single control point)
         raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {k}, n_samples_fit = {n}")
+    X = np.asarray(X, dtype=np.float64)
+    if (_DEVICE_KNN_MIN_POINTS <= n <= 8192 and X.ndim == 2 and X.shape[1] <= 8 and np.isfinite(X).all()
+            and torch.cuda.is_available()):
+        kern = _make_kernels(device, "float64")
+        if hasattr(kern, "knn_mean_distance"):
+            return float(np.sqrt(2) * kern.knn_mean_distance(X, k) / 1.5)
+    from scipy.spatial import cKDTree
+
     distances, _ = cKDTree(X).query(X, k=k)
     d = np.mean(distances[:, 1:]) / 1.5
     return float(np.sqrt(2) * d)
@@ -166,7 +178,7 @@ def _sparsevfc_preprocess(X, Y, M, beta, velocity_based_sampling, seed, device=N
         idx = idx[range(M)]
     ctrl_pts = tmp_X[idx, :]
     if beta is None:
-        h = bandwidth_selector(ctrl_pts)
+        h = bandwidth_selector(ctrl_pts, device)
         beta = 1 / h**2
     return valid_ind, Xv, Yv, idx, ctrl_pts, float(beta)
 

@@ -653,3 +653,35 @@ def test_preprocess_uses_the_device_unique_and_matches_the_host(st):
         vfm._DEVICE_UNIQUE_MIN_ROWS = old
     for u, v in zip(a, b):
         np.testing.assert_array_equal(u, v)
+
+
+@pytest.mark.parametrize("m,d", [(1024, 3), (1500, 3), (3000, 3), (2000, 2), (8192, 3)])
+def test_knn_bandwidth_on_the_device_is_the_host_bandwidth(st, m, d):
+    """dynamo's bandwidth_selector with the neighbour search on the device (all squared distances of a point in LDS,
+    bitonic sort, sum of the k - 1 smallest non-self distances) against the kd-tree route: the same distances summed in
+    another order."""
+    from spateo_amd import vectorfield as vfm
+
+    rng = np.random.default_rng(m + d)
+    X = rng.standard_normal((m, d)) * np.array([300.0, 200.0, 150.0])[:d]
+    hd = vfm.bandwidth_selector(X, device="cuda:0")
+    old = vfm._DEVICE_KNN_MIN_POINTS
+    vfm._DEVICE_KNN_MIN_POINTS = 10**9  # force the host route
+    try:
+        hh = vfm.bandwidth_selector(X)
+    finally:
+        vfm._DEVICE_KNN_MIN_POINTS = old
+    assert abs(hd - hh) <= 1e-12 * hh, (hd, hh)
+    # and the preprocessing picks it up: beta from the device route
+    if m == 1500:
+        from spateo_amd._synthetic import make_config
+
+        Xc, Vc, _ = make_config("C3", N=20_000)
+        a = vfm.sparsevfc_preprocess(Xc, Vc, M=m, seed=0, device="cuda:0")
+        vfm._DEVICE_KNN_MIN_POINTS = 10**9
+        try:
+            b = vfm.sparsevfc_preprocess(Xc, Vc, M=m, seed=0)
+        finally:
+            vfm._DEVICE_KNN_MIN_POINTS = old
+        np.testing.assert_array_equal(a[4], b[4])
+        assert abs(a[5] - b[5]) <= 1e-12 * b[5]
