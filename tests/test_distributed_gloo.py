@@ -45,6 +45,19 @@ def _worker(rank, world, port, case, out_dir, mode="all"):
                 Recording.fills.append(zero_fill)
                 super().estep_p(r, sigma2, gamma, a, dy, minP, theta, zero_fill, P_out, stats)
 
+            hints = []
+
+            def solve(self, G, K, ls2, jitter, R, C_out, info, pivots=None):
+                super().solve(G, K, ls2, jitter, R, C_out, info, pivots)
+                if case == "minnorm_lr" and pivots is not None:
+                    pivots[0] = 1e-14 * pivots[1]  # full rank NOT certified: every rank must switch to the min-norm solve
+
+            def solve_minnorm_lr(self, *a, **kw):
+                Recording.hints.append(kw.get("rank_hint", 0))
+                super().solve_minnorm_lr(*a, **kw)
+
+        if case == "minnorm_lr":
+            os.environ["MVF_MINNORM"] = "lowrank"  # the rank-revealing solve regardless of M
         Grid = X[::30]
         kw = dict(M=25, lambda_=3.0, lstsq_method="scipy", MaxIter=6, seed=0)
         if case == "wide":
@@ -67,12 +80,13 @@ def _worker(rank, world, port, case, out_dir, mode="all"):
             got = st.SparseVFC(X, V, Grid, distributed=True, gather=mode, _kernels=Recording(), **kw)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), V=got["V"], P=got["P"], C=got["C"], grid_V=got["grid_V"],
                  sigma2=got["sigma2"], iteration=got["iteration"], E=got["E_traj"], fills=np.array(Recording.fills),
-                 unique_calls=calls["unique"], valid_ind=got["valid_ind"], vfc=got["VFCIndex"])
+                 unique_calls=calls["unique"], valid_ind=got["valid_ind"], vfc=got["VFCIndex"],
+                 hints=np.array(Recording.hints, dtype=np.int64))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["plain", "zeros"])
+@pytest.mark.parametrize("case", ["plain", "zeros", "minnorm_lr"])
 def test_two_rank_gloo_matches_single_process(tmp_path, case):
     sys.path.insert(0, HERE)
     from oracle import sparsevfc_oracle as svo
@@ -102,6 +116,11 @@ def test_two_rank_gloo_matches_single_process(tmp_path, case):
     np.testing.assert_allclose(float(r0["sigma2"]), ref["sigma2"], rtol=1e-8)
     # the O(N log N) host preprocessing ran on rank 0 only
     assert int(r0["unique_calls"]) == 1 and int(r1["unique_calls"]) == 0
+    if case == "minnorm_lr":
+        # both ranks took the rank-revealing minimum-norm path in every iteration, with identical factor-rank hints
+        # (the first call has none; afterwards the previous factor's 25 rows)
+        np.testing.assert_array_equal(r0["hints"], r1["hints"])
+        assert len(r0["hints"]) == int(r0["iteration"]) + 1 and r0["hints"][0] == 0 and (r0["hints"][1:] == 25).all()
 
 
 @pytest.mark.parametrize("mode,case", [("root", "plain"), ("sharded", "plain"), ("sharded", "wide"), ("root", "wide")])
