@@ -73,8 +73,10 @@ class HipKernels:
         buf[:, : a.shape[1]] = a
         return torch.from_numpy(buf).to(self.device)
 
-    def _red(self, n):
-        need = int(self.lib.mvf_reduce_scratch_doubles(int(n)))
+    def _red(self, n, at_least=0):
+        """Scratch of the deterministic reductions: mvf_reduce_scratch_doubles(n) float64, and never fewer than
+        `at_least` (mvf_quadform writes one partial per control point: m float64, mvf.h)."""
+        need = max(int(self.lib.mvf_reduce_scratch_doubles(int(n))), int(at_least))
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = torch.empty(need, dtype=torch.float64, device=self.device)
         return self._scratch.data_ptr()
@@ -288,8 +290,8 @@ class HipKernels:
 
     @_on_device
     def quadform(self, K, C, out):
-        _lib.check(self.lib.mvf_quadform(_ptr(K), _ptr(C), K.shape[0], C.shape[1], _ptr(out), self._red(K.shape[0]),
-                                         self._stream()), "mvf_quadform")
+        _lib.check(self.lib.mvf_quadform(_ptr(K), _ptr(C), K.shape[0], C.shape[1], _ptr(out),
+                                         self._red(K.shape[0], at_least=K.shape[0]), self._stream()), "mvf_quadform")
 
     @_on_device
     def sym_pack(self, G, tri):

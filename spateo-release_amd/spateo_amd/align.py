@@ -68,11 +68,13 @@ def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, l
         k.solve_minnorm_lr(G, Gamma, ls2, R, C, info, einfo, rcond=rcond)
         if int(info.cpu()[0]) != 0:
             raise _lib.MVFError("update_nonrigid: SigmaInv has non-finite entries")
+        _vf.SparseVFCEngine._check_converged(float(einfo.cpu()[0]))
     else:
         shift = 2.0 ** -36
         while True:
             k.solve_minnorm(G, Gamma, ls2, shift, R, C, info, einfo, rcond=rcond)
             if int(info.cpu()[0]) == 0:
+                _vf.SparseVFCEngine._check_converged(float(einfo.cpu()[0]))
                 break
             shift *= 16.0
             if shift > 2.0 ** -12:

@@ -427,6 +427,14 @@ class SparseVFCEngine:
         for j, g in enumerate(gs):
             self.C_new[g].copy_(Ccat[:, 3 * j : 3 * j + 3])
 
+    @staticmethod
+    def _check_converged(sweeps):
+        """mvf_solve_minnorm(_lr) report a sweep count of x.5 when the Jacobi iteration hit its sweep cap before a clean
+        sweep: the factor is then not orthogonal and the truncated back-solve is not an eigen-solve - fail loudly."""
+        if float(sweeps) % 1.0 != 0.0:
+            raise _lib.MVFError(f"coefficient solve failed: the Jacobi eigensolver did not converge in {int(sweeps)} "
+                                f"sweeps (non-finite or wildly scaled Gram system?)")
+
     def _host_stats(self, *extra):
         """ONE device -> host copy: [extra ... | stats (5) | quad per column group] as float64."""
         h = torch.cat([t.to(torch.float64).reshape(-1) for t in extra] + [self.st, self.quad]).cpu()
@@ -471,6 +479,7 @@ class SparseVFCEngine:
             h = self._host_stats(self.info, self.einfo)
             if int(h[0]) != 0:
                 raise _lib.MVFError("coefficient solve failed: G + lambda sigma^2 K has non-finite entries")
+            self._check_converged(h[1])
             self.rank_hint = int(h[1 + 6])
             for gs in batches[1:]:
                 self._solve_batch(gs, lambda R, C: k.solve_minnorm_lr(self.G, self.K, ls2, R, C, self.info, self.einfo,
@@ -491,6 +500,7 @@ class SparseVFCEngine:
                                                                        warm=self.basis_valid))
             h = self._host_stats(self.info, self.einfo)
             if int(h[0]) == 0:
+                self._check_converged(h[1])
                 self.basis_valid = self.basis is not None and self.warm_start
                 break
             self.basis_valid = False
@@ -658,7 +668,8 @@ def SparseVFC(
     preprocessing and broadcasts the control points), ``sharded_input`` (False: every rank passes the same full X, Y and
     takes a block of it; True: every rank passes only ITS rows - ``Grid`` is still the same everywhere) and ``gather``
     ("root": the per-cell outputs ``V``, ``P``, ``VFCIndex`` are complete on rank 0 only, other ranks keep their own rows;
-    "all": complete on every rank).
+    "all": complete on every rank).  Multi-rank results carry ``row_range`` = (lo, hi): the positions within
+    ``valid_ind`` that this rank's ``V`` / ``P`` rows correspond to (``VFCIndex`` counts from ``lo``).
     ``lstsq_method``: "scipy" (what Spateo passes) = minimum-norm solve with gelsd's eps * s_max cut-off on the
     device (Cholesky while the pivots certify full numerical rank, else the hand-written symmetric eigensolver);
     "drouin" maps to the same solve with a warning; "cholesky" is a non-reference fast mode.  The coefficients ``C`` are
@@ -738,7 +749,14 @@ def SparseVFC(
     V, P, C = eng.results(gather=gather)
     grid_V = eng.predict(Grid) if Grid is not None else None
     i = eng.iteration
+    extra = {}
+    if world > 1:
+        # which rows of the finite-row sequence (positions in `valid_ind`) the per-cell outputs V / P / VFCIndex of THIS
+        # rank cover: all of them on rank 0 and with gather="all", this rank's block otherwise (VFCIndex is relative to it)
+        first = sum(eng.shard_sizes[:rank])
+        extra["row_range"] = (0, N) if (gather == "all" or rank == 0) else (first, first + eng.shard_sizes[rank])
     return {
+        **extra,
         "X": X_ori,
         "valid_ind": valid_ind,
         "X_ctrl": ctrl_pts,
@@ -1059,7 +1077,10 @@ def integrate_field(vf_dict, init_states, t_end=None, interpolation_num=250, dir
         ts, xs = [], []
         for lo in range(0, len(start), max_cells_per_launch):
             x4 = k.to_x4(start[lo : lo + max_cells_per_launch], center)
-            tr = k.integrate(x4, c4, beta, Cd, sign * dt, 2 if arc else substeps, n_fine, affine=affine)
+            # arc-length mode samples 4x finer than the output, so `substeps` RK4 steps per OUTPUT interval become
+            # max(2, substeps // 2) per fine interval (the default 4 -> 2, i.e. 8 per output interval; more on request)
+            tr = k.integrate(x4, c4, beta, Cd, sign * dt, max(2, int(substeps) // 2) if arc else substeps, n_fine,
+                             affine=affine)
             if not arc:
                 xs.append(tr.cpu().numpy()[:, :, :d] + center[None, None, :d])
                 continue
