@@ -10,9 +10,12 @@ inputs resident in HBM.  Workload: BASELINE config 4 = 8 M cells, M = 3000 contr
 MI355X, so the same total problem is run at every N (cells block-sharded across ranks: strong scaling).
 Rank 0 prints ONE JSON line.  Extra objects: ``roofline`` (dominant kernel = the MFMA Gram kernel, timed with HIP
 events on its launch stream; ``traffic`` = the PMC figure parsed from the committed ``profiles/r02_pmc_traffic.json``),
-``solve`` (the coefficient solve: path, Jacobi sweeps, ms), ``f64`` (the SAME workload in float64 mode - the mode the
-1e-5 parity clause is about - with its own roofline; N = 1 only), ``con_k`` (the materialised-kernel HBM-write
-bandwidth) and ``cpu_baseline`` (the float64 NumPy oracle on the host cores at two sample sizes; N = 1 only).
+``solve`` (the coefficient solve: path, Jacobi sweeps, ms, MFMA-tile TFLOP/s), ``f64`` (the SAME workload in float64
+mode - the mode the 1e-5 parity clause is about - with its own roofline; N = 1 only), ``con_k`` (the materialised-kernel
+HBM-write bandwidth), ``cpu_baseline`` (the float64 NumPy oracle on the host cores at N_cpu = 200 k and 100 k cells; its
+``value`` is the rate its fitted t(N) = a N + b gives at the bench's own cell count; N = 1 only) and ``parity`` (the GPU
+engine, float64 and float32, on exactly the 100 k-cell arrays of that CPU sample against the oracle's field after the
+same EM iterations, with the oracle's own lstsq-vs-eigh noise floor beside it; N = 1 only).
 """
 from __future__ import annotations
 
@@ -54,7 +57,18 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def _cpu_steps(M, lambda_, n_cpu, steps):
+def _eigh_solver(lhs, rhs, method=None):
+    """The reference's solve with its LAPACK driver swapped for a mathematically identical one (truncated symmetric
+    eigendecomposition, same eps * max|lambda| cut-off as gelsd): oracle-vs-oracle deviation = the reference noise floor."""
+    w, q = np.linalg.eigh((lhs + lhs.T) / 2)
+    keep = np.abs(w) > np.finfo(float).eps * np.abs(w).max()
+    return (q[:, keep] / w[keep]) @ (q[:, keep].T @ rhs)
+
+
+def _cpu_steps(M, lambda_, n_cpu, steps, keep=False):
+    """`steps` EM iterations of the float64 oracle on the C4 generator at n_cpu cells.  keep=True also returns the
+    arrays and the oracle's state after the last step (the parity leg runs the GPU engine on exactly these arrays) and
+    the same trajectory with the LAPACK driver swapped (the reference noise floor of this sample)."""
     from oracle import sparsevfc_oracle as svo
     from spateo_amd._synthetic import make_config
 
@@ -65,41 +79,66 @@ def _cpu_steps(M, lambda_, n_cpu, steps):
     U = svo.con_K(Xv, ctrl, beta)
     t_conk = time.perf_counter() - t1
     N, D = Yv.shape
-    Vc, C = np.zeros((N, D)), np.zeros((len(ctrl), D))
-    s2, gamma, E = np.sum(Yv**2) / (N * D), 0.9, 1
-    ts = []
-    for _ in range(steps):
-        t2 = time.perf_counter()
-        P, E, tecr, C, Vc, s2, gamma = svo.em_step(U, K, Yv, Vc, C, s2, gamma, E, a=5, lambda_=lambda_, minP=1e-5,
-                                                   theta=0.75, lstsq_method="scipy")
-        ts.append(time.perf_counter() - t2)
-    return N, len(ctrl), float(np.median(ts)), t_conk, U.nbytes
+    kw = dict(a=5, lambda_=lambda_, minP=1e-5, theta=0.75, lstsq_method="scipy")
+
+    def trajectory(timed):
+        Vc, C = np.zeros((N, D)), np.zeros((len(ctrl), D))
+        s2, gamma, E, P = np.sum(Yv**2) / (N * D), 0.9, 1, None
+        ts = []
+        for _ in range(steps):
+            t2 = time.perf_counter()
+            P, E, tecr, C, Vc, s2, gamma = svo.em_step(U, K, Yv, Vc, C, s2, gamma, E, **kw)
+            ts.append(time.perf_counter() - t2)
+        return (ts if timed else None), dict(V=Vc, sigma2=s2, P=P, E=E)
+
+    ts, state = trajectory(True)
+    rec = (N, len(ctrl), float(np.median(ts)), t_conk, U.nbytes)
+    if not keep:
+        return rec, None
+    orig = svo.lstsq_solver
+    svo.lstsq_solver = _eigh_solver
+    try:
+        _, alt = trajectory(False)
+    finally:
+        svo.lstsq_solver = orig
+    vmax = np.abs(state["V"]).max()
+    floor = {"V": float(np.abs(alt["V"] - state["V"]).max() / vmax),
+             "sigma2": float(abs(alt["sigma2"] - state["sigma2"]) / state["sigma2"])}
+    return rec, dict(Xv=Xv, Yv=Yv, ctrl=ctrl, beta=float(beta), steps=steps, state=state, floor=floor)
 
 
-def cpu_baseline(M, lambda_, n_cpu, steps=3):
+def cpu_baseline(M, lambda_, n_cpu, n_target, steps=3):
     """The float64 NumPy/SciPy oracle (kind "port": dynamo is not installable) on a bounded sample of the SAME
     workload: the C4 generator at n_cpu cells and at n_cpu / 2 with the same M, median of `steps` EM steps each
-    (BASELINE.md section 3).  cells/s per EM iteration is size independent at fixed M up to the O(M^3) solve, which the
-    two sizes separate: t(N) = a N + b."""
+    (N_cpu = 200 k at M = 3000).  The step time is t(N) = a N + b (b = the O(M^3) lstsq, which
+    does not grow with N), fitted through the two sizes; `value` is the rate that fit gives at the bench's own cell count
+    n_target - the honest denominator for a speed-up - and the raw sample rates are kept beside it.
+    Returns (record, parity sample = the half-size arrays with the oracle's state after `steps` iterations)."""
     try:
         from threadpoolctl import threadpool_info
 
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         threads = os.cpu_count() or 1
-    N, Mc, t_step, t_conk, ubytes = _cpu_steps(M, lambda_, n_cpu, steps)
-    Nh, _, t_half, _, _ = _cpu_steps(M, lambda_, n_cpu // 2, steps)
+    (N, Mc, t_step, t_conk, ubytes), _ = _cpu_steps(M, lambda_, n_cpu, steps)
+    (Nh, _, t_half, _, _), sample = _cpu_steps(M, lambda_, n_cpu // 2, steps, keep=True)
     a = (t_step - t_half) / (N - Nh)  # seconds per cell (the part that scales with N)
     b = t_step - a * N                # the N-independent part (lstsq of the M x M system)
-    return {
-        "value": N / t_step,
+    t_target = a * n_target + b if a > 0 else None
+    rec = {
+        "value": (n_target / t_target) if t_target else N / t_step,
         "unit": "cells/s",
         "cores": int(threads),
         "host_cpus": os.cpu_count(),
         "kind": "port",
         "sample": f"float64 NumPy oracle (cdist+exp con_K, U.T*repmat(P) temporary, scipy.linalg.lstsq), C4 generator at "
                   f"N_cpu={N} and {Nh} cells, M={Mc}, median of {steps} EM steps each ({t_step:.2f} / {t_half:.2f} s/step); "
-                  f"con_K {t_conk:.2f} s = {ubytes / t_conk / 1e9:.2f} GB/s of output",
+                  f"value = {n_target} cells / t({n_target}) of the fit t(N) = a N + b through the two sizes (the lstsq "
+                  f"constant b amortised as it would be at the bench's size); con_K {t_conk:.2f} s = "
+                  f"{ubytes / t_conk / 1e9:.2f} GB/s of output",
+        "extrapolated_to_cells": int(n_target),
+        "extrapolated_s_per_step": t_target,
+        "sample_value": N / t_step,
         "ms_per_step": 1e3 * t_step,
         "half_sample": {"cells": Nh, "ms_per_step": 1e3 * t_half, "value": Nh / t_half},
         "linearity_ratio": (Nh / t_half) / (N / t_step),
@@ -107,6 +146,40 @@ def cpu_baseline(M, lambda_, n_cpu, steps=3):
         "fit_constant_seconds": b,
         "asymptotic_cells_per_s": (1.0 / a) if a > 0 else None,
     }
+    return rec, sample
+
+
+def parity_on_sample(sample, lambda_, device):
+    """The GPU engine (float64 and float32 cells) on EXACTLY the arrays of the CPU baseline's half-size sample - same
+    control points, same beta, same number of EM iterations from the same initial state - against the oracle's field:
+    a driver-run parity figure for the bench's own workload generator at M = 3000, lambda_ as benchmarked.
+    floor = the oracle against itself with the LAPACK driver swapped (lstsq -> truncated eigh)."""
+    import torch
+    from spateo_amd.vectorfield import SparseVFCEngine
+
+    st = sample["state"]
+    vmax = float(np.abs(st["V"]).max())
+    out = {"cells": int(len(sample["Xv"])), "ctrl": int(len(sample["ctrl"])), "em_steps": int(sample["steps"]),
+           "lambda_": lambda_, "reference": "float64 NumPy oracle (scipy.linalg.lstsq), same arrays",
+           "floor": sample["floor"]}
+    for dtype in ("float64", "float32"):
+        eng = SparseVFCEngine(sample["Xv"], sample["Yv"], sample["ctrl"], sample["beta"], dtype=dtype, device=device)
+        eng.lstsq_method = "scipy"
+        eng.init_state(gamma=0.9)
+        for _ in range(sample["steps"]):
+            E, _ = eng.em_step(a=5.0, lambda_=lambda_, minP=1e-5, theta=0.75)
+        V, P, _ = eng.results()
+        out["f64" if dtype == "float64" else "f32"] = {
+            "V_rel_err": float(np.abs(V - st["V"]).max() / vmax),
+            "sigma2_rel_err": float(abs(eng.sigma2 - st["sigma2"]) / st["sigma2"]),
+            "P_max_abs_err": float(np.abs(P - st["P"]).max()),
+            "E_rel_err": float(abs(E - st["E"]) / abs(st["E"])),
+            "V_err_over_floor": float(np.abs(V - st["V"]).max() / vmax / max(sample["floor"]["V"], 1e-300)),
+        }
+        eng.k.drop_ublk()
+        del eng
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -118,8 +191,9 @@ def main():
     ap.add_argument("--ctrl", type=int, default=3000, help="control points M")
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
     ap.add_argument("--lambda_", type=float, default=0.02, help="Spateo's default regularisation")
-    ap.add_argument("--cpu-cells", type=int, default=100_000,
-                    help="sample size of the CPU baseline, also run at half of it (0 = skip)")
+    ap.add_argument("--cpu-cells", type=int, default=200_000,
+                    help="sample size of the CPU baseline (BASELINE.md section 3: 200 k at M = 3000), also run at half of "
+                         "it - the half-size arrays are also what the parity leg runs the GPU on (0 = skip both)")
     ap.add_argument("--no-f64", action="store_true", help="skip the float64-mode run of the same workload")
     ap.add_argument("--lstsq", default="scipy", choices=["scipy", "cholesky"],
                     help="coefficient solve: scipy = the reference's minimum-norm gelsd semantics (default); cholesky = "
@@ -260,6 +334,7 @@ def main():
                 # committed profiles/r02_pmc_traffic.json for exactly this (dtype, cells per rank, M); null otherwise
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "traffic_from_committed_profile": traffic is not None,  # a PMC pass of this build, not of this run
                 "avg_kernel_ms": gram_avg_ms,
                 "launches": len(gram_ms),
                 "algorithmic_flops_per_launch": alg_flops,
@@ -283,8 +358,26 @@ def main():
             "sigma2_after": eng.sigma2,
             # whole-step rates over all ranks, U counted as materialised (2 s N M bytes, 2 N M^2 flop)
             "step_effective_GBps": 2.0 * (4 if dtype == "float32" else 8) * N * Mc / (ms_per_step * 1e-3) / 1e9,
-            "step_TFLOPs_2NM2": 2.0 * N * Mc * Mc / (ms_per_step * 1e-3) / 1e12,
+            # flops the symmetric Gram kernel executes algorithmically, N M (M + 1), over the whole step's time
+            "step_TFLOPs_NM_Mplus1": float(N) * Mc * (Mc + 1) / (ms_per_step * 1e-3) / 1e12,
         }
+        # "MFMA utilisation on the solve" (north_star): MFMA-tile flops of the solve over its wall time.  Rank-revealing
+        # path: 2 r M^2 in the trailing updates of the pivoted factor + 8 r^2 M per Jacobi sweep (Gram + update tiles);
+        # full width: M^3 / 3 (Cholesky) + 8 M^3 per sweep; Cholesky only: M^3 / 3.
+        sv = rec["solve"]
+        if eng.rank_deficient and sv["jacobi_sweeps"]:
+            sw = float(np.mean([int(x) for x in sv["jacobi_sweeps"]]))
+            if eng.mn_method == "lowrank" and sv["factor_rank"]:
+                rr = float(sv["factor_rank"])
+                fl = 2.0 * rr * Mc * Mc + sw * 8.0 * rr * rr * Mc
+            else:
+                fl = Mc**3 / 3.0 + sw * 8.0 * float(Mc) ** 3
+        else:
+            fl = Mc**3 / 3.0
+        sv["mfma_flops_per_solve"] = fl
+        sv["TFLOPs"] = fl / (sv["avg_ms"] * 1e-3) / 1e12
+        sv["frac_of_f64_mfma_peak"] = sv["TFLOPs"] / PEAK_F64_MFMA_TFLOPS
+        sv["bound"] = "latency (dependent launches / rotation chains), not MFMA"
         if distributed:
             # what the first multi-GPU run needs to explain itself: per-rank Gram time and the collectives
             big = [(e0.elapsed_time(e1), nb) for e0, e1, nb in eng.comm_events if nb > 1024]
@@ -332,7 +425,7 @@ def main():
             "gram_mode": "f64acc",
             "cached_u": main_rec["cached_u"],
             "step_effective_GBps": main_rec["step_effective_GBps"],
-            "step_TFLOPs_2NM2": main_rec["step_TFLOPs_2NM2"],
+            "step_TFLOPs_NM_Mplus1": main_rec["step_TFLOPs_NM_Mplus1"],
         },
         "roofline": main_rec["roofline"],
         "solve": main_rec["solve"],
@@ -387,9 +480,14 @@ def main():
 
     # ---------------------------------------------------------------- CPU baseline (N = 1, rank 0, bounded sample)
     if rank == 0 and world == 1 and args.cpu_cells > 0:
-        cb = cpu_baseline(Mc, args.lambda_, args.cpu_cells)
+        cb, sample = cpu_baseline(Mc, args.lambda_, args.cpu_cells, N)
         out["cpu_baseline"] = cb
+        # against the fitted t(N) at the bench's own cell count (the lstsq constant amortised), not the small sample
         out["speedup_vs_cpu_baseline"] = value / cb["value"]
+        out["speedup_vs_cpu_sample_rate"] = value / cb["sample_value"]
+        # ------------------------------------------------------------ parity on the CPU sample's arrays (driver-run)
+        out["parity"] = parity_on_sample(sample, args.lambda_, device)
+        del sample
 
     if rank == 0:
         print(json.dumps(out), flush=True)
