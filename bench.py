@@ -386,8 +386,15 @@ def main():
                     "allreduce_ms": float(np.mean([t for t, _ in big])) if big else None,
                     "allreduce_bytes": big[0][1] if big else 0,
                     "scalar_allreduce_ms": float(np.mean(small)) if small else None}
+            # every rank also prints its own record on stderr BEFORE the gather: a run that dies in a collective still
+            # leaves the per-rank figures in the log
+            log(f"[bench rank {rank}] " + json.dumps(mine))
             allr = [None] * world
-            dist.all_gather_object(allr, mine)
+            try:
+                dist.all_gather_object(allr, mine)
+            except Exception as exc:  # noqa: BLE001
+                log(f"[bench rank {rank}] gathering the per-rank records failed: {exc!r}")
+                allr = [mine]
             rec["per_rank"] = allr
             rec["comm"] = {"collectives_per_step": len(eng.comm_events) / steps, "allreduce_bytes": mine["allreduce_bytes"],
                            "allreduce_ms_max": max((r_["allreduce_ms"] or 0.0) for r_ in allr),
@@ -399,7 +406,15 @@ def main():
         return rec
 
     del X, V
-    main_rec = run_mode(args.dtype, args.steps, args.warmup)
+    try:
+        main_rec = run_mode(args.dtype, args.steps, args.warmup)
+    except Exception as exc:
+        # one JSON line per failing rank on stderr (which rank, what, where), then the error itself
+        import traceback
+
+        log(f"[bench rank {rank}] " + json.dumps({"rank": rank, "failed": True, "error": repr(exc), "cells": n_loc,
+                                                  "traceback": traceback.format_exc().splitlines()[-6:]}))
+        raise
     value, ms_per_step = main_rec["value"], main_rec["ms_per_step"]
 
     out = {

@@ -159,6 +159,13 @@ def sparsevfc_setup(X, Y, M=100, beta=None, velocity_based_sampling=True, seed=0
     return valid_ind, Xv, Yv, idx, ctrl_pts, beta
 
 
+def gram_dot(a, b):
+    """``a.dot(b)`` of the M-step (``UP.dot(U)``, ``UP.dot(Y)``).  A module-level name so that the tests can measure the
+    reference's own sensitivity to the summation order over cells (what a different BLAS thread count does to it) by
+    swapping in a chunked sum - see ``tests/_floors.py``."""
+    return a.dot(b)
+
+
 def em_step(U, K, Y, V, C, sigma2, gamma, E, *, a, lambda_, minP, theta, lstsq_method):
     """One EM iteration exactly as the body of dynamo's ``while`` loop (Appendix A step 5 a-e).
 
@@ -172,8 +179,8 @@ def em_step(U, K, Y, V, C, sigma2, gamma, E, *, a, lambda_, minP, theta, lstsq_m
 
     P = np.maximum(P, minP)
     UP = U.T * np.tile(P.T, (M, 1))  # numpy.matlib.repmat(P.T, M, 1): the M x N temporary
-    lhs = UP.dot(U) + lambda_ * sigma2 * K
-    rhs = UP.dot(Y)
+    lhs = gram_dot(UP, U) + lambda_ * sigma2 * K
+    rhs = gram_dot(UP, Y)
     C = lstsq_solver(lhs, rhs, method=lstsq_method)
 
     V = U.dot(C)

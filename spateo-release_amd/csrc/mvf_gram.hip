@@ -39,20 +39,26 @@ struct GramPlan {
 constexpr int RHS_CPT = 2;                  // control points per lane in the rhs kernel
 constexpr int RHS_COLS = 256 * RHS_CPT;     // control points per rhs workgroup
 
-// Resident workgroup slots of the Gram kernels: 2 workgroups (8 waves) per CU (register-limited), 256 CUs.
+// Resident workgroup slots of the Gram kernels: 2 workgroups (8 waves) per CU (register-limited), 256 CUs on MI355X.
+// Looked up per CURRENT device (the host binding makes the launch stream's device current) and remembered per device
+// index; the idempotent lazy write needs no lock.
 static int gram_slots() {
-    static int slots = 0;
-    if (slots == 0) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                cus = prop.multiProcessorCount;
-        }
+    constexpr int MAXDEV = 64;
+    static int slots[MAXDEV] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) {
         (void)hipGetLastError();
-        slots = 2 * cus;
+        return 2 * 256;
     }
-    return slots;
+    if (slots[dev] == 0) {
+        int cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        (void)hipGetLastError();
+        slots[dev] = 2 * cus;
+    }
+    return slots[dev];
 }
 
 static GramPlan make_plan(int64_t n, int64_t m, mvf_dtype dtype) {

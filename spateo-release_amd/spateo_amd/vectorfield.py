@@ -203,6 +203,47 @@ def shard_bounds(n: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _current_device(device):
+    """Context that makes `device` the thread's current GPU: torch's OBJECT collectives move their pickles through the
+    current device under the RCCL backend, whatever device the caller's tensors live on."""
+    import contextlib
+
+    if device is None or not torch.cuda.is_available():
+        return contextlib.nullcontext()
+    dev = torch.device(device)
+    return torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()
+
+
+def _collective_device(group, device):
+    """Where a tensor must live for a collective on `group`: the GPU under RCCL ("nccl"), the host under gloo."""
+    import torch.distributed as dist
+
+    if "nccl" in str(dist.get_backend(group)) and torch.cuda.is_available():
+        return torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    return torch.device("cpu")
+
+
+def _gather_rows_np(arr, sizes, rank, world, group, device, to_all):
+    """Concatenate the ranks' row blocks of a host (n_r, c) array (sizes[r] rows on rank r) with ONE padded tensor
+    collective (all_gather if to_all, else gather to rank 0; other ranks get None)."""
+    import torch.distributed as dist
+
+    dev = _collective_device(group, device)
+    mx = max(max(sizes), 1)
+    pad = torch.zeros((mx, arr.shape[1]), dtype=torch.from_numpy(arr[:0]).dtype, device=dev)
+    pad[: len(arr)] = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+    if to_all:
+        outs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(outs, pad, group=group)
+    else:
+        outs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+        dst = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.gather(pad, outs, dst=dst, group=group)
+        if rank != 0:
+            return None
+    return torch.cat([o[:sz] for o, sz in zip(outs, sizes)], dim=0).cpu().numpy()
+
+
 def _consistent_K(k, ctrl, center, beta):
     """con_K(ctrl, ctrl) as float64, its values generated by the kernels' own kernel_value<cell dtype>."""
     cc = np.zeros((len(ctrl), 3), dtype=np.float32 if k.tdtype == torch.float32 else np.float64)
@@ -442,8 +483,47 @@ class SparseVFCEngine:
 
     def _solve_all(self, ls2):
         """C_new = lstsq(G + ls2 K, R) for every column group, with the semantics `self.lstsq_method` names.
-        Returns the host copy of [stats (5) | quad per group] (read in the same round trip as the solve's status)."""
+        Returns the host copy of [stats (5) | quad per group] (read in the same round trip as the solve's status).
+
+        Multi-rank: every rank solves the same all-reduced system redundantly and must take the same branch (Cholesky /
+        rank-revealing / full-width, retries, sweeps) - the kernels are deterministic, so they do.  That is VERIFIED every
+        step: one tiny MAX all-reduce of (+signature, -signature) of this rank's solver decisions, a failure on any
+        rank included; a disagreement (or a rank that failed) raises on EVERY rank instead of leaving the others hanging
+        in the next collective."""
+        if self.world == 1:
+            return self._solve_all_local(ls2)
+        err, h = None, None
+        try:
+            h = self._solve_all_local(ls2)
+            sig = list(self._solver_signature)
+        except (_lib.MVFError, RuntimeError) as exc:
+            err, sig = exc, [-1.0] * 6
+        self._agree(sig, err)
+        return h
+
+    def _agree(self, sig, err=None):
+        """Raise on every rank unless all ranks hold the same signature (and none of them failed)."""
+        import torch.distributed as dist
+
+        v = [float(x) for x in sig] + [1.0 if err is not None else 0.0]
+        t = torch.tensor(v + [-x for x in v], dtype=torch.float64, device=self.k.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        t = t.cpu().numpy()
+        n = len(v)
+        hi, lo = t[:n], -t[n:]
+        if err is not None:
+            raise err
+        if hi[-1] != 0.0:
+            raise _lib.MVFError(f"SparseVFC (rank {self.rank}): the coefficient solve failed on another rank")
+        if not np.array_equal(hi, lo):
+            raise _lib.MVFError(
+                f"SparseVFC (rank {self.rank}): ranks disagree on the coefficient solve's decisions "
+                f"[branch, status, sweeps, kept rank, factor rank, retries]: mine {v[:-1]}, min over ranks "
+                f"{lo[:-1].tolist()}, max {hi[:-1].tolist()} - the all-reduced Gram systems are not identical")
+
+    def _solve_all_local(self, ls2):
         k = self.k
+        self._solver_signature = (0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
         batches = self._rhs_batches()
         if self.lstsq_method == "cholesky":
             while True:
@@ -453,6 +533,7 @@ class SparseVFCEngine:
                 fail = int(h[0])
                 if fail == 0:
                     self.solver_stats["cholesky"] += 1
+                    self._solver_signature = (1.0, 0.0, 0.0, float(self.M), 0.0, float(self.solve_retries))
                     return h[1:]
                 self.solve_retries += 1
                 self.jitter = max(self.jitter * 10.0, self.jitter_first)
@@ -468,6 +549,7 @@ class SparseVFCEngine:
             h = self._host_stats(self.info, self.pivots)
             if int(h[0]) == 0 and float(h[1]) > self.pivot_ratio * float(h[2]):
                 self.solver_stats["cholesky"] += 1
+                self._solver_signature = (2.0, 0.0, 0.0, float(self.M), 0.0, 0.0)
                 return h[3:]
             self.rank_deficient = True
         # truncated minimum-norm solve (gelsd cut-off eps * max|lambda|)
@@ -488,6 +570,7 @@ class SparseVFCEngine:
             self.solver_stats["sweeps"].append(float(h[1]))
             self.solver_stats["rank"].append(int(h[2]))
             self.solver_stats.setdefault("factor_rank", []).append(self.rank_hint)
+            self._solver_signature = (3.0, 0.0, float(h[1]), float(h[2]), float(self.rank_hint), 0.0)
             return h[1 + 12:]
         # mn_method = "full": Jacobi on all M columns of the shifted Cholesky factor; the shift only has to make the
         # factorisation inside the eigensolver exist, it is subtracted from the eigenvalues again.
@@ -514,6 +597,7 @@ class SparseVFCEngine:
         self.solver_stats["minnorm"] += 1
         self.solver_stats["sweeps"].append(float(h[1]))
         self.solver_stats["rank"].append(int(h[2]))
+        self._solver_signature = (4.0, 0.0, float(h[1]), float(h[2]), 0.0, float(np.log2(self.mn_shift)))
         return h[1 + 12:]
 
     def fit(self, *, a=5, gamma=0.9, lambda_=3, minP=1e-5, MaxIter=500, theta=0.75, ecr=1e-5, lstsq_method="scipy"):
@@ -704,17 +788,20 @@ def SparseVFC(
         valid_loc = np.where(np.isfinite(Y.sum(1)))[0]
         if sharded_input:
             lens = [None] * world
-            dist.all_gather_object(lens, (len(X), len(valid_loc)), group=group)
+            with _current_device(device):
+                dist.all_gather_object(lens, (len(X), len(valid_loc)), group=group)  # two integers per rank
             offset = sum(n_in for n_in, _ in lens[:rank])
             shard_sizes = [n_v for _, n_v in lens]
-            vparts = [None] * world
-            dist.all_gather_object(vparts, valid_loc + offset, group=group)  # global row numbers of the finite rows
-            valid_ind = np.concatenate(vparts)
+            # global row numbers of the finite rows (every rank) and the finite rows themselves (rank 0 only, for the
+            # control-point selection): padded TENSOR collectives, not pickles of whole arrays
+            valid_ind = _gather_rows_np((valid_loc + offset)[:, None].astype(np.int64), shard_sizes, rank, world, group,
+                                        device, to_all=True)[:, 0]
             Xloc, Yloc = X[valid_loc], Y[valid_loc]
-            parts = [None] * world if rank == 0 else None
-            dist.gather_object((Xloc, Yloc), parts, dst=root, group=group)
+            XY = _gather_rows_np(np.concatenate([Xloc, Yloc], axis=1), shard_sizes, rank, world, group, device,
+                                 to_all=False)
             if rank == 0:
-                Xall, Yall = np.concatenate([p_[0] for p_ in parts]), np.concatenate([p_[1] for p_ in parts])
+                Xall, Yall = np.ascontiguousarray(XY[:, : X.shape[1]]), np.ascontiguousarray(XY[:, X.shape[1]:])
+            del XY
             N = sum(shard_sizes)
         else:
             valid_ind = valid_loc
@@ -733,7 +820,8 @@ def SparseVFC(
                 box = [(idx0, ctrl0, beta0)]
             except Exception as exc:  # every rank must leave the collective: ship the error
                 box = [exc]
-        dist.broadcast_object_list(box, src=root, group=group)
+        with _current_device(device):
+            dist.broadcast_object_list(box, src=root, group=group)  # (ctrl_idx, M control points, beta): small
         if isinstance(box[0], Exception):
             raise box[0]
         idx, ctrl_pts, beta = box[0]

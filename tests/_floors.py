@@ -1,0 +1,127 @@
+"""Reference noise floors: how far the float64 oracle moves under changes that leave the mathematics untouched.
+
+Where the M-step system ``(U^T P U + lambda sigma^2 K) C = U^T P Y`` is numerically rank deficient (every case with M in
+the thousands, and M = 500 from the second or third EM iteration on at Spateo's default lambda_ = 0.02) the reference's
+own result is only determined up to a noise level far above the 1e-5 / 1e-3 of ``north_star``.  Two ways to measure
+that level on the oracle itself, both deterministic:
+
+* ``eigh``      - the LAPACK driver of the solve swapped for a mathematically identical one: ``scipy.linalg.lstsq``
+                  (gelsd) -> truncated symmetric eigendecomposition with the same ``eps * max|lambda|`` cut-off;
+* ``sumorder``  - the Gram / rhs products ``UP.dot(U)``, ``UP.dot(Y)`` summed over the cells in 7 sequential chunks
+                  instead of one BLAS call: what a different BLAS thread count does to the reference (and what any
+                  GPU reduction order necessarily does);
+* ``f32kernel`` - (float32 mode only) the oracle fed with kernel values computed in float32 arithmetic from float32
+                  coordinates, exactly as the float32 mode generates U and K: the effect of the data type itself.
+
+A floor is reported per quantity (field on the cells, grid field inside / outside the data hull, sigma^2, P, energy).
+"""
+import numpy as np
+
+from oracle import sparsevfc_oracle as svo
+
+ALLOW = 1.25  # a GPU result may sit at most this factor above the reference's own floor (or inside the mode's tolerance)
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max())
+
+
+def eigh_solver(lhs, rhs, method=None):
+    w, q = np.linalg.eigh((lhs + lhs.T) / 2)
+    keep = np.abs(w) > np.finfo(float).eps * np.abs(w).max()
+    return (q[:, keep] / w[keep]) @ (q[:, keep].T @ rhs)
+
+
+def chunked_dot(a, b, chunks=7):
+    """a (M x N) . b (N x k) summed over N in `chunks` sequential pieces."""
+    n = a.shape[1]
+    edges = np.linspace(0, n, chunks + 1).astype(int)
+    out = a[:, edges[0] : edges[1]].dot(b[edges[0] : edges[1]])
+    for lo, hi in zip(edges[1:-1], edges[2:]):
+        out = out + a[:, lo:hi].dot(b[lo:hi])
+    return out
+
+
+def con_K_float32_arithmetic(x, y, beta, *a, **k):
+    """con_K as the float32 mode computes it: coordinates centred on the control points and cast to float32, scaled by
+    sqrt(beta log2 e) in float32, squared distance accumulated in float32, exp2 in float32 (the arithmetic of
+    csrc/mvf_common.h::kernel_value<float>); returned as float64."""
+    f32 = np.float32
+    x, y = np.atleast_2d(np.asarray(x, dtype=np.float64)), np.asarray(y, dtype=np.float64)
+    c = y.mean(0)
+    s = f32(np.sqrt(beta * 1.4426950408889634))
+    cy = (y - c).astype(f32) * s
+    out = np.empty((len(x), len(y)))
+    for lo in range(0, len(x), 16384):
+        px = (x[lo : lo + 16384] - c).astype(f32) * s
+        e = np.zeros((len(px), len(y)), dtype=f32)
+        for j in range(x.shape[1]):
+            d = px[:, j : j + 1] - cy[None, :, j]
+            e += d * d
+        out[lo : lo + 16384] = np.exp2(-e).astype(f32)
+    return out
+
+
+def oracle_fit(X, V, Grid, variant=None, **kw):
+    """svo.SparseVFC, optionally as one of the variants above."""
+    saved = svo.lstsq_solver, svo.con_K, svo.gram_dot
+    if variant == "eigh":
+        svo.lstsq_solver = eigh_solver
+    elif variant == "sumorder":
+        svo.gram_dot = chunked_dot
+    elif variant == "f32kernel":
+        svo.con_K = con_K_float32_arithmetic
+    elif variant is not None:
+        raise ValueError(variant)
+    try:
+        return svo.SparseVFC(X, V, Grid, **kw)
+    finally:
+        svo.lstsq_solver, svo.con_K, svo.gram_dot = saved
+
+
+def deviations(got, ref, in_hull=None):
+    """Per-quantity deviation of one result dict from the reference dict (inf if the iteration counts differ: the
+    trajectories are then not comparable step by step)."""
+    if got["iteration"] != ref["iteration"]:
+        return None
+    vmax = np.abs(ref["V"]).max()
+    d = {"V": rel(got["V"], ref["V"]),
+         "sigma2": abs(got["sigma2"] - ref["sigma2"]) / ref["sigma2"],
+         "P": float(np.abs(got["P"] - ref["P"]).max()),
+         "E": float(np.abs((got["E_traj"] - ref["E_traj"]) / ref["E_traj"]).max())}
+    if ref.get("grid_V") is not None:
+        gd = np.abs(got["grid_V"] - ref["grid_V"])
+        d["grid"] = float(gd.max() / vmax)
+        if in_hull is not None:
+            d["hull"] = float(gd[in_hull].max() / vmax)
+    return d
+
+
+def floor_table(X, V, Grid, ref, kw, in_hull=None, variants=("eigh", "sumorder"), f32=True):
+    """{quantity: (float64-mode floor, float32-mode floor)}; the per-variant numbers under "_variants"."""
+    per = {}
+    for v in tuple(variants) + (("f32kernel",) if f32 else ()):
+        per[v] = deviations(oracle_fit(X, V, Grid, variant=v, **kw), ref, in_hull)
+    keys = [k for k in ("V", "grid", "hull", "sigma2", "P", "E") if any(p and k in p for p in per.values())]
+    table = {}
+    for k in keys:
+        f64 = max((per[v][k] if per[v] else np.inf) for v in variants)
+        f32v = max(f64, (per["f32kernel"][k] if per.get("f32kernel") else np.inf)) if f32 else f64
+        table[k] = (float(f64), float(f32v))
+    table["_variants"] = per
+    return table
+
+
+def tol(dtype, table, key, base):
+    """max(ALLOW x the reference's own floor for this quantity, the mode's base tolerance)."""
+    return max(ALLOW * table[key][0 if dtype == "float64" else 1], base)
+
+
+def fmt(table):
+    per = table["_variants"]
+    cols = [k for k in table if k != "_variants"]
+    lines = []
+    for v, d in per.items():
+        lines.append(f"    floor[{v}]: " + ("iterations differ" if d is None else
+                                             ", ".join(f"{k} {d[k]:.2e}" for k in cols if k in d)))
+    return "\n".join(lines)

@@ -1,10 +1,12 @@
 #!/usr/bin/env python
 """Writes tests/golden/scale_oracle.npz: the float64 ORACLE's outputs (this repo's restatement, not the reference - the
-reference cannot run: dynamo is absent) for the seeded M = 2000 / 3000 cases of tests/test_gpu_scale.py, so that the GPU
-suite does not spend minutes of host time in 3000 x 3000 lstsq calls.  It calls the very compute functions of the tests
-(single EM step and 10-step fits, lambda_ = 3 and 0.02, plus the lstsq-vs-eigh and float32-kernel floors).
+reference cannot run: dynamo is absent) for the seeded cases of tests/test_gpu_scale.py that need minutes of host time:
+M = 2000 / 3000 at 20 k cells (single EM step and 10-step fits, lambda_ = 3 and 0.02) and the bench's own generator at
+BASELINE.md section 3's N_cpu (C4, 200 k cells x 3000, lambda_ = 0.02, 10 steps; every 8th cell of V / P stored).  Each
+case carries the reference noise floors of tests/_floors.py (LAPACK driver swapped, Gram summation order changed,
+float32 kernel values), computed on all cells.  It calls the very compute functions of the tests.
 
-    python tests/golden/make_scale_oracle.py        (about 10 minutes on 8 cores)
+    python tests/golden/make_scale_oracle.py        (about 50 minutes on 8 cores, 12 GB of RAM)
 """
 import os
 import sys
@@ -20,19 +22,26 @@ os.environ["MVF_SCALE_ORACLE_LIVE"] = "1"
 import test_gpu_scale as T  # noqa: E402
 
 
+def save():
+    out = {f"{k}|{f}": v for k, d in T._ORACLE_STORE.items() for f, v in d.items()}
+    path = os.path.join(HERE, "scale_oracle.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, len(out), "arrays", os.path.getsize(path) / 1e6, "MB", flush=True)
+
+
 def main():
-    for M in (2000, 3000):
-        for lam in (3.0, 0.02):
-            T._large_m_case(M, lam)
-            print("fit", M, lam, "done", flush=True)
     for M in (2000, 3000):
         for lam in (3.0, 0.02):
             T._single_step_case(M, lam)
             print("step", M, lam, "done", flush=True)
-    out = {f"{k}|{f}": v for k, d in T._ORACLE_STORE.items() for f, v in d.items()}
-    path = os.path.join(HERE, "scale_oracle.npz")
-    np.savez_compressed(path, **out)
-    print("wrote", path, len(out), "arrays", os.path.getsize(path) / 1e6, "MB")
+    for M in (2000, 3000):
+        for lam in (3.0, 0.02):
+            T._large_m_case(M, lam)
+            print("fit", M, lam, "done", flush=True)
+        save()
+    T._c4_sample_case()
+    print("C4 sample done", flush=True)
+    save()
 
 
 if __name__ == "__main__":

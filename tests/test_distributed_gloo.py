@@ -51,6 +51,8 @@ def _worker(rank, world, port, case, out_dir, mode="all"):
                 super().solve(G, K, ls2, jitter, R, C_out, info, pivots)
                 if case == "minnorm_lr" and pivots is not None:
                     pivots[0] = 1e-14 * pivots[1]  # full rank NOT certified: every rank must switch to the min-norm solve
+                if case == "disagree" and rank == 1 and pivots is not None:
+                    pivots[0] = 1e-14 * pivots[1]  # ONLY rank 1 sees an uncertified rank: the ranks would part ways
 
             def solve_minnorm_lr(self, *a, **kw):
                 Recording.hints.append(kw.get("rank_hint", 0))
@@ -76,6 +78,17 @@ def _worker(rank, world, port, case, out_dir, mode="all"):
             lo, hi = (0, 401) if rank == 0 else (401, 601)
             got = st.SparseVFC(X[lo:hi], V[lo:hi], Grid, distributed=True, sharded_input=True, gather="root",
                                _kernels=Recording(), **kw)
+        elif case == "disagree":
+            from spateo_amd._lib import MVFError
+
+            try:
+                st.SparseVFC(X, V, Grid, distributed=True, gather=mode, _kernels=Recording(), **kw)
+                msg = "no error"
+            except MVFError as exc:
+                msg = str(exc)
+            with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+                f.write(msg)
+            return
         else:
             got = st.SparseVFC(X, V, Grid, distributed=True, gather=mode, _kernels=Recording(), **kw)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), V=got["V"], P=got["P"], C=got["C"], grid_V=got["grid_V"],
@@ -150,6 +163,17 @@ def test_two_rank_gloo_root_gather_and_own_shards(tmp_path, mode, case):
     np.testing.assert_array_equal(r0["valid_ind"], ref["valid_ind"])
     np.testing.assert_array_equal(r0["vfc"], ref["VFCIndex"])
     assert int(r0["unique_calls"]) == 1 and int(r1["unique_calls"]) == 0
+
+
+def test_two_rank_gloo_divergent_solver_branches_raise_instead_of_hanging(tmp_path):
+    """Rank 1 alone is made to distrust the Cholesky certificate: the per-step agreement check (MAX all-reduce of
+    +/- the solver-decision signature) must raise MVFError on BOTH ranks in that very step."""
+    sys.path.insert(0, HERE)
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, "disagree", str(tmp_path)), nprocs=2, join=True)
+    for r in (0, 1):
+        msg = (tmp_path / f"rank{r}.txt").read_text()
+        assert "ranks disagree on the coefficient solve" in msg, msg
 
 
 def test_distributed_flag_requires_process_group():
