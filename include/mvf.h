@@ -53,7 +53,7 @@ int mvf_device_count(int* count);      /* number of visible HIP devices (0 witho
  * call in-tree: spateo/alignment/methods/morpho_class.py:845).  X: n x d float64 row-major (finite).  Outputs (device,
  * caller-allocated for n rows): uid[0..count) = index of the FIRST occurrence of each distinct row, in lexicographic row
  * order; rows[0..count) = those rows; count[0] = number of distinct rows.  Stable LSD radix sort over the columns
- * (rocPRIM device primitives) + run flags + compaction; bit-identical to NumPy for finite input. */
+ * (rocPRIM's device radix sort and select - library primitives, not hand-written kernels) + run flags + compaction; bit-identical to NumPy for finite input. */
 size_t mvf_unique_rows_workspace_bytes(int64_t n, int d);
 int mvf_unique_rows(const double* X, int64_t n, int d, int64_t* uid, double* rows, int64_t* count, void* workspace,
                     size_t workspace_bytes, void* stream);
@@ -65,6 +65,16 @@ int mvf_unique_rows(const double* X, int64_t n, int d, int64_t* uid, double* row
  * point i to its k - 1 nearest OTHER points; the caller takes mean = sum(rowsum) / (m (k - 1)).  One workgroup per point:
  * all m squared distances in LDS, bitonic sort, fixed-order sum (deterministic). */
 int mvf_knn_rowsum(const double* X, int64_t m, int d, int k, double* rowsum, void* stream);
+
+/* ---- grid preparation: convex-hull mask --------------------------------------------------------------------------------
+ * Replaces: `grid_in_hull = in_hull(Grid, hull.points[hull.vertices, :])` of `get_X_Y_grid`
+ * (spateo/tdr/interpolations/utils.py:48-53; `in_hull` = Delaunay(...).find_simplex(p) >= 0, spateo/tools/utils.py:205-221).
+ * A point lies in a convex hull iff it is on the inner side of every facet: inside[i] = (max_f n_f . p_i + d_f <= tol).
+ * points: n x 3 float64 row-major; equations: nfacets x 4 float64 = SciPy `ConvexHull(X).equations` (built on the host
+ * with Qhull, as the reference does); inside: n bytes (0 / 1).  tol: the caller passes 100 eps x the hull's extent,
+ * the scale of find_simplex's own barycentric tolerance. */
+int mvf_hull_mask(const double* points, int64_t n, const double* equations, int64_t nfacets, double tol,
+                  unsigned char* inside, void* stream);
 
 /* ---- con_K ----------------------------------------------------------------------------------------------------
  * K[i, j] = exp(-beta * ||x_i - y_j||^2), materialised n x m row-major.
@@ -211,6 +221,12 @@ int mvf_solve_minnorm_lr(const double* G, const double* K, double lambda_sigma2,
  * x4: n x 4 (dtype), ctrl4: m x 4 (dtype), diag_out: n float64.  Synchronises `stream` once on the lowrank path. */
 int mvf_pinv_diag(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, double rcond, int lowrank,
                   double* diag_out, void* workspace, size_t workspace_bytes, mvf_dtype dtype, void* stream);
+
+/* out[i] = a A[i] + b B[i] + c C[i], n float64 (B, C may be NULL; out may alias an input).  The compositions of
+ * `Morpho_pairwise._update_nonrigid`'s SVI and guidance branches (spateo/alignment/methods/morpho_class.py:1269-1288):
+ * `SigmaInv = step SigmaInv_new + (1 - step) SigmaInv_prev`, `SigmaInv += w U_I^T U_I`, `UPXB_term += w U_I^T (X_BI - R_AI)`. */
+int mvf_lincomb3(double* out, double a, const double* A, double b, const double* B, double c, const double* C,
+                 int64_t n, void* stream);
 
 /* trace(C^T K C) -> out[0] (float64), the regulariser of the energy (App. A 5b). K: m x m, C: m x nrhs;
  * scratch >= m float64 (row partials, summed in row order). */

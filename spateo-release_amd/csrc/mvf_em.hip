@@ -343,3 +343,28 @@ extern "C" int mvf_quadform(const double* K, const double* C, int64_t m, int nrh
     MVF_LAUNCH_CHECK();
     return 0;
 }
+
+
+// out[i] = a A[i] + b B[i] + c C[i]   (B, C may be NULL = 0; float64, elementwise, in-place allowed)
+namespace {
+__global__ __launch_bounds__(256) void lincomb3_kernel(double* __restrict__ out, double a, const double* A, double b,
+                                                       const double* B, double c, const double* C, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double v = a * A[i];
+    if (B) v = fma(b, B[i], v);
+    if (C) v = fma(c, C[i], v);
+    out[i] = v;
+}
+}  // namespace
+
+extern "C" int mvf_lincomb3(double* out, double a, const double* A, double b, const double* B, double c, const double* C,
+                            int64_t n, void* stream) {
+    MVF_REQUIRE(n >= 0, "mvf_lincomb3: negative length");
+    if (n == 0) return 0;
+    MVF_REQUIRE(out && A, "mvf_lincomb3: null out / A");
+    hipLaunchKernelGGL(lincomb3_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out, a, A, b, B,
+                       c, C, n);
+    MVF_LAUNCH_CHECK();
+    return 0;
+}

@@ -191,3 +191,45 @@ extern "C" int mvf_knn_rowsum(const double* X, int64_t m, int d, int k, double* 
     MVF_LAUNCH_CHECK();
     return 0;
 }
+
+
+// ---- convex-hull mask -------------------------------------------------------------------------------------------------
+// inside[i] = 1 iff  max over facets f of (n_f . p_i + d_f) <= tol :  a point is in a convex polytope iff it is on the inner
+// side of every facet half-space (SciPy ConvexHull.equations rows are (n_f, d_f) with n_f . x + d_f <= 0 inside).
+// One lane per point, the facets staged through LDS in chunks of 256; float64 throughout.
+namespace {
+constexpr int HULL_CHUNK = 256;
+__global__ __launch_bounds__(256) void hull_mask_kernel(const double* __restrict__ pts, int64_t n,
+                                                        const double* __restrict__ eq, int64_t nf, double tol,
+                                                        unsigned char* __restrict__ inside) {
+    __shared__ double se[HULL_CHUNK][4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n;
+    const double px = live ? pts[3 * i] : 0.0, py = live ? pts[3 * i + 1] : 0.0, pz = live ? pts[3 * i + 2] : 0.0;
+    double worst = -INFINITY;
+    for (int64_t f0 = 0; f0 < nf; f0 += HULL_CHUNK) {
+        const int fc = (int)min((int64_t)HULL_CHUNK, nf - f0);
+        __syncthreads();
+        if ((int)threadIdx.x < fc) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) se[threadIdx.x][q] = eq[(f0 + threadIdx.x) * 4 + q];
+        }
+        __syncthreads();
+        for (int f = 0; f < fc; ++f)
+            worst = fmax(worst, fma(se[f][0], px, fma(se[f][1], py, fma(se[f][2], pz, se[f][3]))));
+    }
+    if (live) inside[i] = (worst <= tol) ? 1 : 0;
+}
+}  // namespace
+
+extern "C" int mvf_hull_mask(const double* points, int64_t n, const double* equations, int64_t nfacets, double tol,
+                             unsigned char* inside, void* stream) {
+    MVF_REQUIRE(n >= 0 && nfacets >= 1, "mvf_hull_mask: need n >= 0 and at least one facet");
+    MVF_REQUIRE(std::isfinite(tol), "mvf_hull_mask: bad tolerance");
+    if (n == 0) return 0;
+    MVF_REQUIRE(points && equations && inside, "mvf_hull_mask: null pointer");
+    hipLaunchKernelGGL(hull_mask_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, points, n,
+                       equations, nfacets, tol, inside);
+    MVF_LAUNCH_CHECK();
+    return 0;
+}

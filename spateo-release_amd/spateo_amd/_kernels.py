@@ -289,6 +289,23 @@ class HipKernels:
         return torch.empty(int(self.lib.mvf_solve_minnorm_basis_bytes(m)) // 8, dtype=torch.float64, device=self.device)
 
     @_on_device
+    def lincomb3(self, out, a, A, b=0.0, B=None, c=0.0, C=None):
+        """out = a A + b B + c C (float64 device tensors of one shape; B, C optional; out may alias an input)."""
+        _lib.check(self.lib.mvf_lincomb3(_ptr(out), float(a), _ptr(A), float(b), _ptr(B), float(c), _ptr(C),
+                                         out.numel(), self._stream()), "mvf_lincomb3")
+        return out
+
+    @_on_device
+    def hull_mask(self, points, equations, tol):
+        """Host (n, 3) points and SciPy ConvexHull.equations (nf, 4) -> host bool (n,): inside the hull."""
+        P = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float64)).to(self.device)
+        E = torch.from_numpy(np.ascontiguousarray(equations, dtype=np.float64)).to(self.device)
+        out = torch.empty(P.shape[0], dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.mvf_hull_mask(_ptr(P), P.shape[0], _ptr(E), E.shape[0], float(tol), _ptr(out),
+                                          self._stream()), "mvf_hull_mask")
+        return out.cpu().numpy().astype(bool)
+
+    @_on_device
     def quadform(self, K, C, out):
         _lib.check(self.lib.mvf_quadform(_ptr(K), _ptr(C), K.shape[0], C.shape[1], _ptr(out),
                                          self._red(K.shape[0], at_least=K.shape[0]), self._stream()), "mvf_quadform")

@@ -27,6 +27,7 @@ SIGNATURES = {
     "mvf_unique_rows_workspace_bytes": (_sz, [_i64, _i]),
     "mvf_unique_rows": (_i, [_p, _i64, _i, _p, _p, _p, _p, _sz, _p]),
     "mvf_knn_rowsum": (_i, [_p, _i64, _i, _i, _p, _p]),
+    "mvf_hull_mask": (_i, [_p, _i64, _p, _i64, _d, _p, _p]),
     "mvf_con_k": (_i, [_p, _i64, _p, _i64, _i, _d, _p, _i, _p]),
     "mvf_con_k_d": (_i, [_p, _i64, _p, _i64, _i, _d, _p, _p, _i, _p]),
     "mvf_reduce_scratch_doubles": (_sz, [_i64]),
@@ -47,6 +48,7 @@ SIGNATURES = {
     "mvf_solve_minnorm_lr_workspace_bytes": (_sz, [_i64, _i]),
     "mvf_solve_minnorm_lr": (_i, [_p, _p, _d, _d, _d, _p, _i64, _i, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "mvf_pinv_diag": (_i, [_p, _i64, _p, _i64, _d, _d, _i, _p, _p, _sz, _i, _p]),
+    "mvf_lincomb3": (_i, [_p, _d, _p, _d, _p, _d, _p, _i64, _p]),
     "mvf_quadform": (_i, [_p, _p, _i64, _i, _p, _p, _p]),
     "mvf_sym_pack": (_i, [_p, _i64, _p, _p]),
     "mvf_sym_unpack": (_i, [_p, _i64, _p, _p]),

@@ -21,10 +21,10 @@ __all__ = ["BA_transform", "update_nonrigid"]
 
 
 def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, lambdaVF, dtype: str = "float64",
-                    device=None):
+                    device=None, *, guidance=None, svi=None):
     """The non-rigid update of Spateo's alignment, ``Morpho_pairwise._update_nonrigid``
-    (``spateo/alignment/methods/morpho_class.py:1254-1298``, no guidance, no SVI), on the MI355X with the kernels of the
-    SparseVFC M-step - it is the same computation (``SigmaInv = sigma2 lambdaVF Gamma + U^T diag(K_NA) U``,
+    (``spateo/alignment/methods/morpho_class.py:1254-1298``), on the MI355X with the kernels of the SparseVFC M-step - it
+    is the same computation (``SigmaInv = sigma2 lambdaVF Gamma + U^T diag(K_NA) U``,
     ``Coff = pinv(SigmaInv) U^T PXB_term``, ``VnA = U Coff``; Gamma = con_K(ctrl, ctrl), U = con_K(coordsA, ctrl) as
     ``_construct_kernel`` builds them, ``:825-875``):
 
@@ -33,10 +33,20 @@ def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, l
       ``max(M, M) * eps * s_max`` (what ``_pinv`` resolves to on the NumPy backend, ``methods/utils.py:11,1435``),
     * ``U @ Coff``                               -> ``mvf_apply``.
 
-    ``PXB_term`` (n x D) is the reference's ``P @ coordsB - RnA * K_NA[:, None]`` (O(n nb) host work that belongs to the
-    assignment step, not to this one).  Returns ``{"SigmaInv", "Coff", "VnA", "SigmaDiag"}`` as host float64;
-    ``SigmaDiag`` = ``sigma2 diag(U pinv(SigmaInv) U^T)`` (the n-vector feeding the alignment's variational sigma^2,
-    ``:1295-1297``) comes from the decomposition the solve left on the device (``mvf_pinv_diag``)."""
+    ``PXB_term`` (n x D) is the reference's ``P @ coordsB - RnA * K_NA[:, None]`` of THIS batch (O(n nb) host work that
+    belongs to the assignment step, not to this one).
+
+    ``svi`` (the ``SVI_mode`` branch, ``:1269-1275``): ``dict(step_size=, SigmaInv_prev=, PXB_prev=)`` - the running
+    averages of the previous batches; ``SigmaInv`` and ``PXB_term`` are blended ``step new + (1 - step) prev`` before the
+    solve (``mvf_lincomb3``) and returned for the next call.
+    ``guidance`` (the ``guidance_effect in ("nonrigid", "both")`` branch, ``:1282-1288,1293-1294``):
+    ``dict(X_AI=, X_BI=, R_AI=, weight=, Sp=)`` - ``U_I = con_K(X_AI, ctrl)``; ``SigmaInv += w U_I^T U_I``,
+    ``rhs += w U_I^T (X_BI - R_AI)`` with ``w = sigma2 weight Sp / n_I`` (a second ``mvf_gram`` with unit weights) and
+    ``V_AI = U_I Coff`` (``mvf_apply``) is returned too.
+
+    Returns ``{"SigmaInv", "PXB_term", "Coff", "VnA", "SigmaDiag"[, "V_AI"]}`` as host float64; ``SigmaDiag`` =
+    ``sigma2 diag(U pinv(SigmaInv) U^T)`` (the n-vector feeding the alignment's variational sigma^2, ``:1295-1297``) comes
+    from the decomposition the solve left on the device (``mvf_pinv_diag``)."""
     if dtype not in ("float32", "float64"):
         raise ValueError("dtype must be 'float32' or 'float64'")
     X = np.asarray(coordsA, dtype=np.float64)
@@ -49,30 +59,58 @@ def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, l
         raise ValueError("K_NA must be (n,) and PXB_term (n, D) with D <= 3")
     n, m, D = len(X), len(ctrl), B.shape[1]
     k = _vf._make_kernels(device, dtype)
+    npdt = np.float32 if dtype == "float32" else np.float64
     center = ctrl.mean(0)
     x4, c4 = k.to_x4(X, center), k.to_x4(ctrl, center)
     Gamma = _vf._consistent_K(k, ctrl, center, float(beta))  # generated like U (see SparseVFCEngine)
-    # rhs = U^T PXB = U^T diag(K_NA) Y with Y = PXB / K_NA (rows with K_NA == 0 have PXB == 0: cells without a partner)
-    Y = np.divide(B, w[:, None], out=np.zeros_like(B), where=w[:, None] != 0)
-    y4 = k.to_x4(Y)
-    Pw = torch.from_numpy(w.astype(np.float32 if dtype == "float32" else np.float64)).to(k.device)
     f64 = torch.float64
     G, R = k.zeros(m, m, dtype=f64), k.zeros(m, 3, dtype=f64)
-    k.gram(x4, Pw, y4, c4, float(beta), G, R)
+    Pw = torch.from_numpy(w.astype(npdt)).to(k.device)
     ls2 = float(sigma2) * float(lambdaVF)
+    step = 1.0
+    if svi is None:
+        # rhs = U^T PXB = U^T diag(K_NA) Y with Y = PXB / K_NA (rows with K_NA == 0 have PXB == 0: cells without a partner)
+        Y = np.divide(B, w[:, None], out=np.zeros_like(B), where=w[:, None] != 0)
+        k.gram(x4, Pw, k.to_x4(Y), c4, float(beta), G, R)
+    else:
+        step = float(svi["step_size"])
+        S_prev = np.ascontiguousarray(svi["SigmaInv_prev"], dtype=np.float64)
+        B_prev = np.asarray(svi["PXB_prev"], dtype=np.float64)
+        if S_prev.shape != (m, m) or B_prev.shape != B.shape or not (0.0 < step <= 1.0):
+            raise ValueError("svi needs 0 < step_size <= 1, SigmaInv_prev (M, M) and PXB_prev shaped like PXB_term")
+        B = step * B + (1.0 - step) * B_prev  # the blended n x D term (host, O(n)): rows without a partner NOW may carry
+        # the previous batches' share, so its rhs is taken with unit weights
+        k.gram(x4, Pw, k.to_x4(np.zeros_like(B)), c4, float(beta), G, R)
+        ones = torch.ones(n, dtype=Pw.dtype, device=k.device)
+        k.gram(x4, ones, k.to_x4(B), c4, float(beta), G, R, rhs_only=True)
+        # G <- step G + (1 - step) (SigmaInv_prev);  the regulariser enters the solve as (step ls2) Gamma
+        k.lincomb3(G, step, G, 1.0 - step, torch.from_numpy(S_prev).to(k.device))
+    x4_I = None
+    if guidance is not None:
+        X_AI = np.asarray(guidance["X_AI"], dtype=np.float64)
+        dXI = np.asarray(guidance["X_BI"], dtype=np.float64) - np.asarray(guidance["R_AI"], dtype=np.float64)
+        if X_AI.ndim != 2 or X_AI.shape[1] != X.shape[1] or dXI.shape != X_AI.shape:
+            raise ValueError("guidance needs X_AI, X_BI, R_AI of one (n_I, D) shape")
+        n_i = len(X_AI)
+        wg = float(sigma2) * float(guidance["weight"]) * float(guidance["Sp"]) / n_i
+        x4_I = k.to_x4(X_AI, center)
+        G_I, R_I = k.zeros(m, m, dtype=f64), k.zeros(m, 3, dtype=f64)
+        k.gram(x4_I, torch.ones(n_i, dtype=Pw.dtype, device=k.device), k.to_x4(dXI), c4, float(beta), G_I, R_I)
+        k.lincomb3(G, 1.0, G, wg, G_I)
+        k.lincomb3(R, 1.0, R, wg, R_I)
     C, info, einfo = k.zeros(m, 3, dtype=f64), k.zeros(1, dtype=torch.int32), k.zeros(12, dtype=f64)
     rcond = m * float(np.finfo(np.float64).eps)
     lowrank = m >= 1024 and hasattr(k, "solve_minnorm_lr")
     if lowrank:
         # rank-revealing factor + Jacobi on its columns (the faster path once the factor drops most columns)
-        k.solve_minnorm_lr(G, Gamma, ls2, R, C, info, einfo, rcond=rcond)
+        k.solve_minnorm_lr(G, Gamma, step * ls2, R, C, info, einfo, rcond=rcond)
         if int(info.cpu()[0]) != 0:
             raise _lib.MVFError("update_nonrigid: SigmaInv has non-finite entries")
         _vf.SparseVFCEngine._check_converged(float(einfo.cpu()[0]))
     else:
         shift = 2.0 ** -36
         while True:
-            k.solve_minnorm(G, Gamma, ls2, shift, R, C, info, einfo, rcond=rcond)
+            k.solve_minnorm(G, Gamma, step * ls2, shift, R, C, info, einfo, rcond=rcond)
             if int(info.cpu()[0]) == 0:
                 _vf.SparseVFCEngine._check_converged(float(einfo.cpu()[0]))
                 break
@@ -80,12 +118,15 @@ def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, l
             if shift > 2.0 ** -12:
                 raise _lib.MVFError("update_nonrigid: SigmaInv is not numerically positive semi-definite")
     V4, _ = k.apply(x4, c4, float(beta), C)
-    SigmaInv = G.cpu().numpy() + ls2 * Gamma.cpu().numpy()
+    SigmaInv = G.cpu().numpy() + step * ls2 * Gamma.cpu().numpy()
     # SigmaDiag = sigma2 diag(U pinv(SigmaInv) U^T) (morpho_class.py:1295-1297) from the decomposition the solve left
     diag = k.pinv_diag(x4, c4, float(beta), rcond=rcond, lowrank=lowrank) if hasattr(k, "pinv_diag") else None
-    out = {"SigmaInv": SigmaInv, "Coff": C.cpu().numpy()[:, :D].copy(), "VnA": V4[:, :D].to(f64).cpu().numpy()}
+    out = {"SigmaInv": SigmaInv, "PXB_term": B, "Coff": C.cpu().numpy()[:, :D].copy(),
+           "VnA": V4[:, :D].to(f64).cpu().numpy()}
     if diag is not None:
         out["SigmaDiag"] = float(sigma2) * diag.cpu().numpy()
+    if x4_I is not None:
+        out["V_AI"] = k.apply(x4_I, c4, float(beta), C)[0][:, :D].to(f64).cpu().numpy()
     return out
 
 

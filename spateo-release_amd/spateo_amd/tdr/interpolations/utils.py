@@ -8,11 +8,25 @@ import numpy as np
 from ...logging import logger_manager as lm
 
 
-def _in_hull(p: np.ndarray, hull_points: np.ndarray) -> np.ndarray:
-    """Points of `p` inside the convex hull of `hull_points` (reference: ``spateo/tools/utils.py:205-221``)."""
+def _in_hull(p: np.ndarray, hull) -> np.ndarray:
+    """Points of `p` inside the convex hull (reference: ``in_hull(Grid, hull.points[hull.vertices, :])`` =
+    ``Delaunay(vertices).find_simplex(p) >= 0``, ``spateo/tools/utils.py:205-221``).  `hull` is the SciPy ``ConvexHull`` of the
+    data.  With a GPU the test runs on the device from the hull's facet equations (``mvf_hull_mask``: a point is inside a
+    convex polytope iff it is on the inner side of every facet; tolerance 100 eps x the hull's extent, the scale of
+    find_simplex's own barycentric tolerance) - 262 144 grid points x ~2 k facets in well under a millisecond instead of
+    a Delaunay triangulation + point location on the host.  Without a GPU: the reference's own host formulation."""
+    import torch
+
+    if torch.cuda.is_available():
+        from ... import vectorfield as _vf
+
+        k = _vf._make_kernels(None, "float64")
+        if hasattr(k, "hull_mask"):
+            extent = float(np.max(hull.max_bound - hull.min_bound))
+            return k.hull_mask(p, hull.equations, 100.0 * np.finfo(np.float64).eps * extent)
     from scipy.spatial import Delaunay
 
-    return Delaunay(hull_points).find_simplex(p) >= 0
+    return Delaunay(hull.points[hull.vertices, :]).find_simplex(p) >= 0
 
 
 def get_X_Y_grid(
@@ -37,5 +51,5 @@ def get_X_Y_grid(
     from scipy.spatial import ConvexHull
 
     hull = ConvexHull(np.column_stack((X[:, 0], X[:, 1], X[:, 2])))
-    grid_in_hull = _in_hull(Grid, hull.points[hull.vertices, :])
+    grid_in_hull = _in_hull(Grid, hull)
     return X, Y, Grid, grid_in_hull

@@ -49,3 +49,30 @@ def check_update_nonrigid(fn, g, dtype, device=None):
         else:  # rank deficient (99 of 120 directions kept): the field, to the noise level of that system (6e-4)
             assert e_v < tol[2], e_v
     return out
+
+
+def check_update_nonrigid_branches(fn, g, dtype, device=None):
+    """The guidance ("nonrigid") and SVI branches (goldens c / d / e from the real method, morpho_class.py:1269-1294)."""
+    tol = {"float64": 1e-8, "float32": 2e-3}[dtype]
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())  # noqa: E731
+    out = {}
+    for tag in ("c", "d", "e"):
+        kw = {}
+        if f"{tag}_X_AI" in g:
+            kw["guidance"] = dict(X_AI=g[f"{tag}_X_AI"], X_BI=g[f"{tag}_X_BI"], R_AI=g[f"{tag}_R_AI"],
+                                  weight=float(g[f"{tag}_guidance_weight"]), Sp=float(g[f"{tag}_Sp"]))
+        if f"{tag}_SigmaInv_prev" in g:
+            kw["svi"] = dict(step_size=float(g[f"{tag}_step_size"]), SigmaInv_prev=g[f"{tag}_SigmaInv_prev"],
+                             PXB_prev=g[f"{tag}_PXB_prev"])
+        r = fn(g[f"{tag}_coordsA"], g[f"{tag}_inducing_variables"], float(g[f"{tag}_beta"]), g[f"{tag}_K_NA"],
+               g[f"{tag}_PXB_new"], float(g[f"{tag}_sigma2"]), float(g[f"{tag}_lambdaVF"]), dtype=dtype, device=device, **kw)
+        errs = {q: rel(r[q], g[f"{tag}_{q}"]) for q in ("SigmaInv", "PXB_term", "Coff", "VnA", "SigmaDiag")}
+        if "guidance" in kw:
+            errs["V_AI"] = rel(r["V_AI"], g[f"{tag}_V_AI"])
+        out[tag] = errs
+        assert errs["SigmaInv"] < (1e-10 if dtype == "float64" else 1e-5), (tag, errs)
+        assert errs["PXB_term"] < 1e-14, (tag, errs)
+        for q in ("Coff", "VnA", "SigmaDiag", "V_AI"):
+            if q in errs:
+                assert errs[q] < tol, (tag, q, errs)
+    return out

@@ -44,6 +44,15 @@ class CpuKernels:
         return torch.zeros(*shape, dtype=dtype or self.tdtype)
 
     # ---- kernels
+    def lincomb3(self, out, a, A, b=0.0, B=None, c=0.0, C=None):
+        v = a * A
+        if B is not None:
+            v = v + b * B
+        if C is not None:
+            v = v + c * C
+        out.copy_(v)
+        return out
+
     def con_k(self, x, y, beta, return_d=False, dtype=None):
         xn, yn = _np(x).astype(np.float64), _np(y).astype(np.float64)
         if return_d:

@@ -64,6 +64,45 @@ def one_case(mc, backend, rng, n, nb, m, beta, sigma2, lambdaVF, seed, spread):
                 PXB_term=s.PXB_term, Coff=s.Coff, VnA=s.VnA, SigmaDiag=s.SigmaDiag)
 
 
+def guided_svi_case(mc, backend, rng, n, nb, m, n_i, beta, sigma2, lambdaVF, seed, guidance, svi, step_size=0.6,
+                    guidance_weight=2.0):
+    """The guidance ("nonrigid") and SVI branches of the real _update_nonrigid (morpho_class.py:1269-1284,1293-1294):
+    U_I = con_K(X_AI, inducing variables), SigmaInv += w U_I^T U_I, rhs += w U_I^T (X_BI - R_AI), V_AI = U_I Coff with
+    w = sigma2 guidance_weight Sp / n_I; SVI: SigmaInv / PXB_term blended with the previous batch's by step_size."""
+    coordsA = rng.standard_normal((n, 3))
+    coordsB = coordsA[rng.choice(n, nb)] + 0.05 * rng.standard_normal((nb, 3))
+    d2 = ((coordsA[:, None, :] - coordsB[None, :, :]) ** 2).sum(-1)
+    P = np.exp(-d2 / (2 * 0.3**2)) * (rng.random((n, nb)) < 0.5)
+    P[rng.choice(n, n // 15, replace=False)] = 0.0
+    K_NA = P.sum(1)
+    RnA = coordsA + 0.02 * rng.standard_normal((n, 3))
+    X_AI = coordsA[rng.choice(n, n_i, replace=False)] + 0.01 * rng.standard_normal((n_i, 3))
+    X_BI = X_AI + 0.1 * rng.standard_normal((n_i, 3))
+    R_AI = X_AI + 0.02 * rng.standard_normal((n_i, 3))
+    s = types.SimpleNamespace(
+        nx=backend.NumpyBackend(), coordsA=coordsA, coordsB=coordsB, kernel_type="euc", kernel_bandwidth=beta,
+        guidance_effect="nonrigid" if guidance else False, guidance=bool(guidance), X_AI=X_AI, X_BI=X_BI, R_AI=R_AI,
+        guidance_weight=guidance_weight, Sp=float(P.sum()), SVI_mode=bool(svi), step_size=step_size, sigma2=sigma2,
+        lambdaVF=lambdaVF, P=P, K_NA=K_NA, RnA=RnA, graph=None, batch_idx=np.arange(nb),
+    )
+    np.random.seed(seed)
+    mc.Morpho_pairwise._construct_kernel(s, m, None)
+    prev = {}
+    if svi:  # the previous batch's running averages (any symmetric PSD matrix of the right shape / any n x 3 term)
+        Z = rng.standard_normal((2 * m, len(s.inducing_variables)))
+        prev["SigmaInv_prev"] = Z.T @ Z / (2 * m) * float(K_NA.sum()) / m
+        prev["PXB_prev"] = (P @ coordsB - RnA * K_NA[:, None]) * rng.uniform(0.5, 1.5, (n, 1))
+        s.SigmaInv, s.PXB_term = prev["SigmaInv_prev"].copy(), prev["PXB_prev"].copy()
+    mc.Morpho_pairwise._update_nonrigid(s)
+    out = dict(coordsA=coordsA, K_NA=K_NA, beta=beta, sigma2=sigma2, lambdaVF=lambdaVF, Sp=s.Sp,
+               inducing_variables=s.inducing_variables, SigmaInv=s.SigmaInv, PXB_term=s.PXB_term, Coff=s.Coff, VnA=s.VnA,
+               SigmaDiag=s.SigmaDiag, PXB_new=P @ coordsB - RnA * K_NA[:, None], step_size=step_size,
+               guidance_weight=guidance_weight, **prev)
+    if guidance:
+        out.update(X_AI=X_AI, X_BI=X_BI, R_AI=R_AI, V_AI=s.V_AI)
+    return out
+
+
 def main():
     mc, backend, utils = load_morpho_class()
     rng = np.random.default_rng(20260927)
@@ -82,6 +121,14 @@ def main():
         w = np.linalg.eigvalsh((res["SigmaInv"] + res["SigmaInv"].T) / 2)
         print(f"case {tag}: M = {len(res['inducing_variables'])}, cond(SigmaInv) = {w.max() / max(w.min(), 1e-300):.2e}, "
               f"|Coff|max = {np.abs(res['Coff']).max():.3g}, |VnA|max = {np.abs(res['VnA']).max():.3g}")
+    # cases c / d / e: the guidance ("nonrigid") branch, the SVI branch, and both together (well conditioned, like a)
+    for tag, kw in (("c", dict(guidance=True, svi=False)), ("d", dict(guidance=False, svi=True)),
+                    ("e", dict(guidance=True, svi=True))):
+        res = guided_svi_case(mc, backend, rng, n=600, nb=250, m=40, n_i=30, beta=0.5, sigma2=0.5, lambdaVF=100.0,
+                              seed=13, **kw)
+        for k, v in res.items():
+            out[f"{tag}_{k}"] = np.asarray(v)
+        print(f"case {tag}: M = {len(res['inducing_variables'])}, |Coff|max = {np.abs(res['Coff']).max():.3g}")
     path = os.path.join(HERE, "ref_em.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, f"({os.path.getsize(path) / 1e6:.2f} MB, {len(out)} arrays)")

@@ -34,11 +34,12 @@ def main():
         for lam in (3.0, 0.02):
             T._single_step_case(M, lam)
             print("step", M, lam, "done", flush=True)
+    save()
     for M in (2000, 3000):
         for lam in (3.0, 0.02):
             T._large_m_case(M, lam)
             print("fit", M, lam, "done", flush=True)
-        save()
+            save()
     T._c4_sample_case()
     print("C4 sample done", flush=True)
     save()

@@ -597,6 +597,10 @@ def test_update_nonrigid_against_reference_goldens(st, golden_em, dtype):
 
     errs = check_update_nonrigid(st.align.update_nonrigid, golden_em, dtype, device="cuda:0")
     print(f"update_nonrigid {dtype}: (SigmaInv, VnA) errors vs reference: {errs}")
+    from _align_case import check_update_nonrigid_branches
+
+    errs = check_update_nonrigid_branches(st.align.update_nonrigid, golden_em, dtype, device="cuda:0")
+    print(f"update_nonrigid {dtype}, guidance / SVI / both branches vs reference: {errs}")
 
 
 # ------------------------------------------------------------------------------------------- morphopath: fate semantics

@@ -685,3 +685,33 @@ def test_knn_bandwidth_on_the_device_is_the_host_bandwidth(st, m, d):
             vfm._DEVICE_KNN_MIN_POINTS = old
         np.testing.assert_array_equal(a[4], b[4])
         assert abs(a[5] - b[5]) <= 1e-12 * b[5]
+
+
+# ------------------------------------------------------------------------------------------- convex-hull mask (f4)
+def test_hull_mask_matches_delaunay_find_simplex():
+    """mvf_hull_mask (max over facet half-spaces) against the reference's own formulation, Delaunay(hull vertices)
+    .find_simplex(p) >= 0 (spateo/tools/utils.py:205-221), on the 64^3 grid of BASELINE config 2 and on random points
+    hugging the hull; the two may differ only for points within 1e-9 x extent of a facet."""
+    from scipy.spatial import ConvexHull, Delaunay
+    from spateo_amd._kernels import HipKernels
+    from spateo_amd._synthetic import make_config
+    from spateo_amd.tdr.interpolations.utils import get_X_Y_grid
+
+    X, V, _ = make_config("C2")
+    _, _, Grid, mask = get_X_Y_grid(X=X, Y=V, grid_num=[64, 64, 64])  # device path (a GPU is present)
+    hull = ConvexHull(X)
+    rng = np.random.default_rng(0)
+    near = hull.points[hull.vertices][rng.integers(0, len(hull.vertices), 20000)] * rng.uniform(0.97, 1.03, (20000, 1))
+    k = HipKernels("cuda:0", "float64")
+    extent = float(np.max(hull.max_bound - hull.min_bound))
+    tol = 100.0 * np.finfo(np.float64).eps * extent
+    tri = Delaunay(hull.points[hull.vertices, :])
+    for pts, got in ((Grid, mask), (near, k.hull_mask(near, hull.equations, tol))):
+        want = tri.find_simplex(pts) >= 0
+        diff = np.flatnonzero(got != want)
+        margin = (pts[diff] @ hull.equations[:, :3].T + hull.equations[:, 3]).max(1) if len(diff) else np.zeros(0)
+        print(f"hull mask: {len(pts)} points, {int(want.sum())} inside, {len(diff)} differ (max |margin| "
+              f"{np.abs(margin).max() if len(diff) else 0:.2e})")
+        assert got.dtype == bool and got.shape == want.shape
+        assert 0.2 < want.mean() < 0.8
+        assert (np.abs(margin) < 1e-9 * extent).all()

@@ -165,9 +165,9 @@ def _fixture_fit(key, X, V, kw, stride=1):
         table = F.floor_table(X, V, None, ref, kw)
         out = dict(V=ref["V"][::stride], P=ref["P"][::stride], sigma2=ref["sigma2"], E_traj=ref["E_traj"],
                    iteration=ref["iteration"], vmax=np.abs(ref["V"]).max())
-        for q, (f64, f32) in table.items():
+        for q, val in table.items():
             if q != "_variants":
-                out[f"floor_{q}"] = np.array([f64, f32])
+                out[f"floor_{q}"] = np.array(val)
         for v, d in table["_variants"].items():
             for q, val in (d or {}).items():
                 out[f"var_{v}_{q}"] = val

@@ -607,6 +607,9 @@ def test_update_nonrigid_host_composition_matches_reference(cpu_kernels, golden_
     from _align_case import check_update_nonrigid
 
     check_update_nonrigid(st.align.update_nonrigid, golden_em, "float64")
+    from _align_case import check_update_nonrigid_branches
+
+    check_update_nonrigid_branches(st.align.update_nonrigid, golden_em, "float64")  # guidance / SVI / both
     with pytest.raises(AssertionError):
         st.align.update_nonrigid(golden_em["a_coordsA"][:, :2], golden_em["a_inducing_variables"], 0.5,
                                  golden_em["a_K_NA"], golden_em["a_PXB_term"], 0.5, 100.0)

@@ -49,8 +49,30 @@ def engine_steps(X, V, M, dtype, steps, lambda_=0.02):
         eng.em_step(**kw)
     sync()
     ms = 1e3 * (time.perf_counter() - t0) / steps
+    import torch
+
+    # the coefficient solve alone (events on the stream), a few more steps
+    ev = []
+    inner = eng._solve_all
+
+    def timed(ls2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        h = inner(ls2)
+        e1.record()
+        ev.append((e0, e1))
+        return h
+
+    eng._solve_all = timed
+    for _ in range(min(steps, 10)):
+        eng.em_step(**kw)
+    sync()
+    solve_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    st = eng.solver_stats
     out = dict(cells=len(Xv), ctrl=len(ctrl), dtype=dtype, preprocess_s=t_pre, upload_and_cache_s=t_up, ms_per_em_step=ms,
-               cells_per_s=len(Xv) / (ms * 1e-3), cached_u=bool(eng.cached_u))
+               cells_per_s=len(Xv) / (ms * 1e-3), cached_u=bool(eng.cached_u), solve_ms=solve_ms,
+               solver=dict(cholesky=st["cholesky"], minnorm=st["minnorm"], last_sweeps=st["sweeps"][-3:],
+                           last_rank=st["rank"][-3:], method=getattr(eng, "mn_method", None)))
     eng.k.drop_ublk()
     return out
 
@@ -92,6 +114,14 @@ def main():
         assert np.isfinite(J).all() and np.isfinite(curl).all()
         res[f"C2_{dtype}"] = r
         print(f"C2_{dtype}", json.dumps(r), flush=True)
+
+    # ------------------------------------------------------------------ Spateo's stock call: M = 100 control points
+    # (the default of morphofield_sparsevfc, reference sparsevfc.py:248), on the C2 cloud and on a 250 k-cell organ
+    for name, (Xd, Vd) in (("default_M100_50k", (X, V)), ("default_M100_250k", make_config("C2", N=250_000, seed=100)[:2])):
+        for dtype in ("float32", "float64"):
+            r = engine_steps(Xd, Vd, 100, dtype, steps=50)
+            res[f"{name}_{dtype}"] = r
+            print(f"{name}_{dtype}", json.dumps(r), flush=True)
 
     # ------------------------------------------------------------------ C3: 2M cells, M = 2000
     if not args.skip_c3:
