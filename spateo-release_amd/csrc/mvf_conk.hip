@@ -9,6 +9,8 @@
 // loads.  Output is streamed with non-temporal stores (never re-read by this kernel).
 #include "mvf_common.h"
 
+#include <string>
+
 namespace mvf {
 
 template <typename T, int D, int VEC>
@@ -66,6 +68,66 @@ __global__ __launch_bounds__(256) void conk_kernel(const T* __restrict__ x, int6
     }
 }
 
+// Flat streaming form (the default for d = 3, m % VEC == 0, control points that fit LDS).  K is one contiguous array of
+// n m elements: a workgroup owns contiguous, aligned CHUNKS of it (256 lanes x VEC elements x U passes = 16 KB) and walks
+// them with a grid stride, so at any moment the resident workgroups write ONE contiguous window of memory that moves
+// linearly through the buffer - the access pattern of a device memset (6.2 - 6.3 TB/s on this part), where the 2-D form
+// above writes 4 KB pieces strided by the row length (5.2 - 5.6 TB/s; rows of 8000 B also leave every other row's wave
+// segments straddling 128-byte lines).  Price: a lane's vector no longer has a wave-uniform row, so (row, column) come
+// from one division per chunk (wave-uniform) plus a small per-lane quotient, the row's coordinates are a per-lane cached
+// load and the control points are read from an LDS copy (structure of arrays, pre-scaled; one 16-byte LDS read per
+// coordinate and vector).  Same arithmetic per element as the 2-D form (and as kernel_value): bit-identical output.
+template <typename T, int VEC, int U>
+__global__ __launch_bounds__(256) void conk_flat_kernel(const T* __restrict__ x, int64_t n, const T* __restrict__ y,
+                                                        int m, int mp /* m rounded up to VEC */, T s,
+                                                        T* __restrict__ K, int64_t nchunks, float rcp_m) {
+    extern __shared__ __align__(16) unsigned char conk_smem[];
+    T* cx = reinterpret_cast<T*>(conk_smem);
+    T* cy = cx + mp;
+    T* cz = cy + mp;
+    for (int j = threadIdx.x; j < m; j += 256) {
+        cx[j] = y[3 * j] * s;
+        cy[j] = y[3 * j + 1] * s;
+        cz[j] = y[3 * j + 2] * s;
+    }
+    __syncthreads();
+    constexpr int CH = 256 * VEC * U;  // elements per chunk
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int64_t e0 = c * CH;           // wave-uniform
+        const int64_t i0 = e0 / m;
+        const unsigned j0 = (unsigned)(e0 - i0 * m);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned off = (unsigned)(u * 256 + threadIdx.x) * VEC;
+            const unsigned jj = j0 + off;    // < m + CH < 2^24: exact in float
+            unsigned q = (unsigned)((float)jj * rcp_m);
+            int r = (int)(jj - q * (unsigned)m);
+            if (r < 0) {
+                r += m;
+                --q;
+            } else if (r >= m) {
+                r -= m;
+                ++q;
+            }
+            const int64_t i = i0 + q;
+            if (i >= n) continue;
+            const T px = x[3 * i] * s, py = x[3 * i + 1] * s, pz = x[3 * i + 2] * s;
+            const vec_t vx = *reinterpret_cast<const vec_t*>(cx + r);
+            const vec_t vy = *reinterpret_cast<const vec_t*>(cy + r);
+            const vec_t vz = *reinterpret_cast<const vec_t*>(cz + r);
+            vec_t o;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const T t0 = px - vx[v], t1 = py - vy[v], t2 = pz - vz[v];
+                const T e = fma(t2, t2, fma(t1, t1, fma(t0, t0, T(0))));
+                o[v] = exp2_neg(-e);
+            }
+            __builtin_nontemporal_store(o, reinterpret_cast<vec_t*>(K + e0 + off));
+        }
+    }
+}
+
 // D[n, :, m] = x_n - y_m  (n x d x m), the return_d=True companion (gaussian_process.py:25-29).
 template <typename T>
 __global__ __launch_bounds__(256) void conk_diff_kernel(const T* __restrict__ x, int64_t n, const T* __restrict__ y,
@@ -76,9 +138,36 @@ __global__ __launch_bounds__(256) void conk_diff_kernel(const T* __restrict__ x,
     for (int k = 0; k < d; ++k) Dout[(i * d + k) * m + j] = x[i * d + k] - y[j * d + k];
 }
 
+// LDS the flat form may use per workgroup (two workgroups per CU stay resident at the limit)
+constexpr size_t CONK_FLAT_LDS_MAX = 80 * 1024;
+
 template <typename T, int VEC>
 static int launch_conk(const T* x, int64_t n, const T* y, int64_t m, int d, double beta, T* K, hipStream_t st) {
     const T s = (T)std::sqrt(beta * LOG2E);
+    const char* knob = std::getenv("MVF_CONK");  // developer knob: "2d" = the row-block form for every shape
+    const bool legacy = knob && std::string(knob) == "2d";
+    constexpr int U = 4;
+    const size_t lds = (size_t)3 * m * sizeof(T);
+    if (!legacy && d == 3 && m % VEC == 0 && lds <= CONK_FLAT_LDS_MAX && m >= 64) {
+        constexpr int CH = 256 * VEC * U;
+        const int64_t nchunks = cdiv(n * m, CH);
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        (void)hipGetLastError();
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
+        const int64_t grid = std::min<int64_t>(nchunks, (int64_t)cus * per_cu);
+        auto kern = conk_flat_kernel<T, VEC, U>;
+        if (lds > 64 * 1024)
+            MVF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONK_FLAT_LDS_MAX));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, x, n, y, (int)m, (int)m, s, K, nchunks,
+                           1.0f / (float)m);
+        MVF_LAUNCH_CHECK();
+        return 0;
+    }
     const int rows = 32;
     dim3 grid((unsigned)cdiv(m, 256 * VEC), (unsigned)cdiv(n, rows));
     if (d == 3)

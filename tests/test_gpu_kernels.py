@@ -715,3 +715,28 @@ def test_hull_mask_matches_delaunay_find_simplex():
         assert got.dtype == bool and got.shape == want.shape
         assert 0.2 < want.mean() < 0.8
         assert (np.abs(margin) < 1e-9 * extent).all()
+
+
+@pytest.mark.parametrize("dtype,n,m", [("float32", 5003, 2000), ("float64", 3001, 1000), ("float32", 700, 3000)])
+def test_con_k_flat_streaming_form_is_bit_identical_to_the_row_block_form(dtype, n, m):
+    """The default materialised con_K kernel (flat 16 KB chunks, grid stride, control points in LDS) against the 2-D
+    row-block kernel (MVF_CONK=2d) - bit for bit, ragged last chunk included - and against the oracle."""
+    import os
+
+    from spateo_amd._kernels import HipKernels
+
+    rng = np.random.default_rng(5)
+    npdt = np.float32 if dtype == "float32" else np.float64
+    x = (rng.standard_normal((n, 3)) * 2).astype(npdt)
+    y = (rng.standard_normal((m, 3)) * 2).astype(npdt)
+    k = HipKernels("cuda:0", dtype)
+    xd, yd = torch.from_numpy(x).to("cuda:0"), torch.from_numpy(y).to("cuda:0")
+    flat = k.con_k(xd, yd, 0.37).cpu().numpy()
+    os.environ["MVF_CONK"] = "2d"
+    try:
+        rows = k.con_k(xd, yd, 0.37).cpu().numpy()
+    finally:
+        del os.environ["MVF_CONK"]
+    np.testing.assert_array_equal(flat, rows)
+    ref = svo.con_K(x.astype(np.float64), y.astype(np.float64), 0.37)
+    assert np.abs(flat - ref).max() < (2e-6 if dtype == "float32" else 1e-14)
