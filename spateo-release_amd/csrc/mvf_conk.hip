@@ -128,6 +128,46 @@ __global__ __launch_bounds__(256) void conk_flat_kernel(const T* __restrict__ x,
     }
 }
 
+// Row-contiguous form: a workgroup owns ROWS consecutive FULL rows of K - one contiguous piece of memory of ROWS m
+// elements, written front to back - and covers a row in NP passes of 256 lanes x VEC columns, so that a lane keeps the NP
+// x VEC control points of its column slots in registers (no LDS, no per-lane index arithmetic) and the row coordinates
+// stay wave-uniform scalar loads as in the 2-D form.  Same arithmetic per element: bit-identical output.
+template <typename T, int VEC, int NP>
+__global__ __launch_bounds__(256) void conk_rows_kernel(const T* __restrict__ x, int64_t n, const T* __restrict__ y,
+                                                        int m, T s, T* __restrict__ K, int rows_per_block) {
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    T cx[NP][VEC], cy[NP][VEC], cz[NP][VEC];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int j = (p * 256 + (int)threadIdx.x) * VEC + v;
+            const bool ok = j < m;
+            cx[p][v] = ok ? y[3 * j] * s : T(0);
+            cy[p][v] = ok ? y[3 * j + 1] * s : T(0);
+            cz[p][v] = ok ? y[3 * j + 2] * s : T(0);
+        }
+    const int64_t i0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t i1 = min(i0 + rows_per_block, n);
+    for (int64_t i = i0; i < i1; ++i) {
+        const T px = x[3 * i] * s, py = x[3 * i + 1] * s, pz = x[3 * i + 2] * s;  // wave-uniform
+        T* row = K + i * (int64_t)m;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int j = (p * 256 + (int)threadIdx.x) * VEC;
+            if (j >= m) continue;  // m % VEC == 0: a vector is either inside the row or outside
+            vec_t o;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const T t0 = px - cx[p][v], t1 = py - cy[p][v], t2 = pz - cz[p][v];
+                const T e = fma(t2, t2, fma(t1, t1, fma(t0, t0, T(0))));
+                o[v] = exp2_neg(-e);
+            }
+            __builtin_nontemporal_store(o, reinterpret_cast<vec_t*>(row + j));
+        }
+    }
+}
+
 // D[n, :, m] = x_n - y_m  (n x d x m), the return_d=True companion (gaussian_process.py:25-29).
 template <typename T>
 __global__ __launch_bounds__(256) void conk_diff_kernel(const T* __restrict__ x, int64_t n, const T* __restrict__ y,
@@ -144,8 +184,23 @@ constexpr size_t CONK_FLAT_LDS_MAX = 80 * 1024;
 template <typename T, int VEC>
 static int launch_conk(const T* x, int64_t n, const T* y, int64_t m, int d, double beta, T* K, hipStream_t st) {
     const T s = (T)std::sqrt(beta * LOG2E);
-    const char* knob = std::getenv("MVF_CONK");  // developer knob: "2d" = the row-block form for every shape
-    const bool legacy = knob && std::string(knob) == "2d";
+    // developer knob: "2d" = the row-block form, "flat" = the flat-chunk form, "rows" = the row-contiguous form
+    const char* knob = std::getenv("MVF_CONK");
+    const std::string form = knob ? std::string(knob) : std::string(sizeof(T) == 4 ? "rows" : "2d");
+    const bool legacy = form != "flat";
+    if (form == "rows" && d == 3 && m % VEC == 0 && m >= 64 && m <= 256 * VEC * 4 && (n * m) % VEC == 0) {
+        const int np = (int)cdiv(m, 256 * VEC);
+        const int rows_pb = 16;
+        const dim3 grid((unsigned)cdiv(n, rows_pb));
+        switch (np) {
+            case 1: hipLaunchKernelGGL((conk_rows_kernel<T, VEC, 1>), grid, dim3(256), 0, st, x, n, y, (int)m, s, K, rows_pb); break;
+            case 2: hipLaunchKernelGGL((conk_rows_kernel<T, VEC, 2>), grid, dim3(256), 0, st, x, n, y, (int)m, s, K, rows_pb); break;
+            case 3: hipLaunchKernelGGL((conk_rows_kernel<T, VEC, 3>), grid, dim3(256), 0, st, x, n, y, (int)m, s, K, rows_pb); break;
+            default: hipLaunchKernelGGL((conk_rows_kernel<T, VEC, 4>), grid, dim3(256), 0, st, x, n, y, (int)m, s, K, rows_pb); break;
+        }
+        MVF_LAUNCH_CHECK();
+        return 0;
+    }
     constexpr int U = 4;
     const size_t lds = (size_t)3 * m * sizeof(T);
     if (!legacy && d == 3 && m % VEC == 0 && lds <= CONK_FLAT_LDS_MAX && m >= 64) {

