@@ -1,5 +1,6 @@
 from .morphofield import (
     _morphofield_sparsevfc,
+    cell_directions,
     construct_genesis_states,
     morphofield_gp,
     morphofield_sparsevfc,

@@ -1,3 +1,3 @@
 from .gaussian_process import morphofield_gp
-from .sparsevfc import _morphofield_sparsevfc, morphofield_sparsevfc
+from .sparsevfc import _morphofield_sparsevfc, cell_directions, morphofield_sparsevfc
 from .trajectory import construct_genesis_states, morphopath

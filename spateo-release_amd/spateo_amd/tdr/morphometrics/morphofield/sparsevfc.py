@@ -2,7 +2,8 @@
 (``spateo/tdr/morphometrics/morphofield/sparsevfc.py:103-115,241-256``); the fit itself runs on the MI355X through
 :func:`spateo_amd.vectorfield.SparseVFC` instead of ``dynamo.vectorfield.scVectorField.SparseVFC`` (``:167``).
 
-``cell_directions`` (``:18-100``, PASTE optimal-transport mapping) is upstream of the hot path and out of tier.
+``cell_directions`` (``:18-100``) produces the ``V_mapping`` this path consumes: its mapping logic is here; the PASTE
+optimal-transport solve it starts with (POT's FGW solver) is outside this package - the coupling ``pi`` is an argument.
 """
 from __future__ import annotations
 
@@ -13,6 +14,63 @@ import numpy as np
 from ....logging import logger_manager as lm
 from ....vectorfield import SparseVFC
 from ...interpolations import get_X_Y_grid
+
+
+def _optimal_partners(X: np.ndarray, Y: np.ndarray, pi: np.ndarray, keep_all: bool) -> np.ndarray:
+    """For every row i of the coupling ``pi`` the column j it maps to: a maximum of the row; among several equal
+    maxima the one whose coordinate ``Y[j]`` is nearest to ``X[i]`` (``keep_all=False``), else the first
+    (``get_optimal_mapping_relationship``, ``spateo/alignment/utils.py:157-193``, followed by the sort / drop-duplicates
+    of ``sparsevfc.py:82-95``, which keeps one partner per cell)."""
+    cand = pi == pi.max(axis=1, keepdims=True)
+    partner = cand.argmax(axis=1)
+    if not keep_all:
+        for i in np.flatnonzero(cand.sum(axis=1) > 1):
+            js = np.flatnonzero(cand[i])
+            partner[i] = js[np.argmin(((Y[js] - X[i]) ** 2).sum(axis=1))]
+    return partner
+
+
+def cell_directions(
+    adataA,
+    adataB,
+    layer: str = "X",
+    genes: Optional[Union[list, np.ndarray]] = None,
+    spatial_key: str = "align_spatial",
+    key_added: str = "mapping",
+    alpha: float = 0.001,
+    numItermax: int = 200,
+    numItermaxEmd: int = 100000,
+    dtype: str = "float32",
+    device: str = "cpu",
+    keep_all: bool = False,
+    inplace: bool = True,
+    pi: Optional[np.ndarray] = None,
+    **kwargs,
+):
+    """Developmental direction of every cell of sample A towards its optimally mapped cell of sample B
+    (``sparsevfc.py:18-100``): ``obsm["X_<key_added>"]`` = the coordinates of the partner, ``obsm["V_<key_added>"]`` =
+    partner minus own coordinates - the ``V_mapping`` that ``morphofield_sparsevfc`` fits.  Returns
+    ``(None if inplace else adataA, pi)`` like the reference.
+
+    ``pi`` (n_A x n_B) is the coupling of the two samples.  The reference computes it first with
+    ``paste_pairwise_align`` (PASTE's fused Gromov-Wasserstein optimal transport, POT's solvers): that solve is
+    outside this package ("the rest of the alignment module") - pass the coupling obtained from
+    ``st.align.paste_pairwise_align`` (or any other aligner) as ``pi=``; the OT arguments are accepted for signature
+    compatibility and ignored."""
+    if pi is None:
+        raise NotImplementedError(
+            "cell_directions: the PASTE optimal-transport solve (paste_pairwise_align) is outside spateo_amd - compute "
+            "the coupling with Spateo / POT and pass it as pi=; everything after it runs here.")
+    pi = np.asarray(pi)
+    XA = np.asarray(adataA.obsm[spatial_key])
+    XB = np.asarray(adataB.obsm[spatial_key])
+    if pi.shape != (len(XA), len(XB)):
+        raise ValueError(f"pi must be (n_A, n_B) = {(len(XA), len(XB))}, got {pi.shape}")
+    partner = _optimal_partners(XA.copy(), XB.copy(), pi, keep_all)
+    out = adataA if inplace else adataA.copy()
+    out.obsm[f"X_{key_added}"] = XB[partner]
+    out.obsm[f"V_{key_added}"] = out.obsm[f"X_{key_added}"] - XA
+    return None if inplace else out, pi
 
 
 def _cosine_score(vf_dict: dict) -> float:

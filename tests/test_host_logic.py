@@ -641,3 +641,28 @@ def test_construct_genesis_states_like_the_reference_loop(cpu_kernels, golden):
     np.testing.assert_allclose(tv2, np.logspace(0, np.log10(max(flats[flats <= 25]) + 1), 4) - 1)
     with pytest.raises(Exception, match="develop_trajectory"):
         st.tdr.construct_genesis_states(ad, fate_key="nope")
+
+
+def test_cell_directions_mapping_logic_matches_the_real_function():
+    """st.tdr.cell_directions (coupling -> one partner per cell -> X_mapping, V_mapping) against goldens produced by the
+    REAL cell_directions + get_optimal_mapping_relationship (tests/golden/make_golden_celldir.py; only the PASTE solve
+    in front of them was replaced by a prepared coupling with exact ties)."""
+    import os
+
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_celldir.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    for keep_all, tag in ((False, "nearest"), (True, "all")):
+        A = st.AnnDataLite(obsm={"align_spatial": g["XA"].copy()})
+        B = st.AnnDataLite(obsm={"align_spatial": g["XB"].copy()})
+        ret, pi = st.tdr.cell_directions(A, B, pi=g["pi"], keep_all=keep_all)
+        assert ret is None and pi.shape == g["pi"].shape
+        np.testing.assert_array_equal(A.obsm["X_mapping"], g[f"{tag}_X_mapping"])
+        np.testing.assert_array_equal(A.obsm["V_mapping"], g[f"{tag}_V_mapping"])
+    assert not np.array_equal(g["nearest_X_mapping"], g["all_X_mapping"])  # the ties do matter in this fixture
+    A = st.AnnDataLite(obsm={"align_spatial": g["XA"].copy()})
+    A2, _ = st.tdr.cell_directions(A, B, pi=g["pi"], inplace=False, key_added="m2")
+    assert "X_m2" in A2.obsm and "X_m2" not in A.obsm
+    with pytest.raises(NotImplementedError, match="optimal-transport"):
+        st.tdr.cell_directions(A, B)
+    with pytest.raises(ValueError):
+        st.tdr.cell_directions(A, B, pi=g["pi"][:5])
