@@ -186,11 +186,18 @@ static int launch_conk(const T* x, int64_t n, const T* y, int64_t m, int d, doub
     const T s = (T)std::sqrt(beta * LOG2E);
     // developer knob: "2d" = the row-block form, "flat" = the flat-chunk form, "rows" = the row-contiguous form
     const char* knob = std::getenv("MVF_CONK");
-    const std::string form = knob ? std::string(knob) : std::string(sizeof(T) == 4 ? "rows" : "2d");
+    // Default by shape (measured, profiles/r03_conk_ab.json): rows that are a multiple of 64 bytes long (the HBM burst)
+    // keep every wave's 1 KB segment burst-aligned in the row forms -> "rows" (5.65 - 5.69 TB/s at 2 M x 2000, either
+    // dtype); otherwise (3000 float32 columns: 12 000-byte rows, segments straddle bursts, 4.5 TB/s) the flat form,
+    // whose segments are aligned whatever m is (5.4 TB/s); float64 outside the row form's register budget: "2d".
+    const bool burst_rows = (m * (int64_t)sizeof(T)) % 64 == 0;
+    const std::string form = knob ? std::string(knob)
+                                  : std::string(burst_rows ? "rows" : (sizeof(T) == 4 ? "flat" : "2d"));
     const bool legacy = form != "flat";
     if (form == "rows" && d == 3 && m % VEC == 0 && m >= 64 && m <= 256 * VEC * 4 && (n * m) % VEC == 0) {
         const int np = (int)cdiv(m, 256 * VEC);
-        const int rows_pb = 16;
+        const char* rk = std::getenv("MVF_CONK_ROWS");  // developer knob: rows per workgroup
+        const int rows_pb = rk ? std::max(1, atoi(rk)) : 16;
         const dim3 grid((unsigned)cdiv(n, rows_pb));
         switch (np) {
             case 1: hipLaunchKernelGGL((conk_rows_kernel<T, VEC, 1>), grid, dim3(256), 0, st, x, n, y, (int)m, s, K, rows_pb); break;
