@@ -128,42 +128,67 @@ __global__ __launch_bounds__(256) void conk_flat_kernel(const T* __restrict__ x,
     }
 }
 
-// Row-contiguous form: a workgroup owns ROWS consecutive FULL rows of K - one contiguous piece of memory of ROWS m
-// elements, written front to back - and covers a row in NP passes of 256 lanes x VEC columns, so that a lane keeps the NP
-// x VEC control points of its column slots in registers (no LDS, no per-lane index arithmetic) and the row coordinates
-// stay wave-uniform scalar loads as in the 2-D form.  Same arithmetic per element: bit-identical output.
-template <typename T, int VEC, int NP>
+// Row-contiguous form: a workgroup owns ROWS consecutive FULL rows of K - one contiguous piece of memory, written front
+// to back - and covers a SPAN of RS consecutive rows (RS m elements) in NP passes of 256 lanes x VEC elements, so that a
+// lane keeps the control points of its NP x VEC span slots in registers (no LDS, no per-lane index arithmetic in the
+// loop) and the row coordinates stay wave-uniform scalar loads as in the 2-D form.  RS is chosen by the host so that a
+// span is a multiple of 64 bytes (the HBM burst): every wave's 1 KB segment then stays burst-aligned although a single
+// row (3000 float32 = 12 000 bytes) is not - measured 4.5 TB/s with RS = 1 on such rows against 5.65 on aligned ones.
+// Same arithmetic per element: bit-identical output.
+template <typename T, int VEC, int NP, int RS>
 __global__ __launch_bounds__(256) void conk_rows_kernel(const T* __restrict__ x, int64_t n, const T* __restrict__ y,
-                                                        int m, T s, T* __restrict__ K, int rows_per_block) {
+                                                        int m, T s, T* __restrict__ K, int spans_per_block) {
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    const int span = RS * m;
     T cx[NP][VEC], cy[NP][VEC], cz[NP][VEC];
+    int roff[NP], col[NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
+    for (int p = 0; p < NP; ++p) {
+        const int c = (p * 256 + (int)threadIdx.x) * VEC;  // slot in the span
+        roff[p] = c < span ? c / m : RS;                  // RS = "outside the span"
+        col[p] = c - roff[p] * m;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            const int j = (p * 256 + (int)threadIdx.x) * VEC + v;
-            const bool ok = j < m;
+            const bool ok = c < span;
+            const int j = ok ? col[p] + v : 0;
             cx[p][v] = ok ? y[3 * j] * s : T(0);
             cy[p][v] = ok ? y[3 * j + 1] * s : T(0);
             cz[p][v] = ok ? y[3 * j + 2] * s : T(0);
         }
-    const int64_t i0 = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t i1 = min(i0 + rows_per_block, n);
-    for (int64_t i = i0; i < i1; ++i) {
-        const T px = x[3 * i] * s, py = x[3 * i + 1] * s, pz = x[3 * i + 2] * s;  // wave-uniform
-        T* row = K + i * (int64_t)m;
+    }
+    const int64_t nspans = (n + RS - 1) / RS;
+    const int64_t s0 = (int64_t)blockIdx.x * spans_per_block;
+    const int64_t s1 = min(s0 + spans_per_block, nspans);
+    for (int64_t sp = s0; sp < s1; ++sp) {
+        const int64_t i0 = sp * RS;
+        T px[RS], py[RS], pz[RS];  // wave-uniform
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const int64_t i = min(i0 + r, n - 1);
+            px[r] = x[3 * i] * s;
+            py[r] = x[3 * i + 1] * s;
+            pz[r] = x[3 * i + 2] * s;
+        }
+        T* base = K + i0 * (int64_t)m;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int j = (p * 256 + (int)threadIdx.x) * VEC;
-            if (j >= m) continue;  // m % VEC == 0: a vector is either inside the row or outside
+            if (roff[p] >= RS || i0 + roff[p] >= n) continue;
+            T qx = px[0], qy = py[0], qz = pz[0];
+#pragma unroll
+            for (int r = 1; r < RS; ++r) {
+                const bool hit = roff[p] == r;
+                qx = hit ? px[r] : qx;
+                qy = hit ? py[r] : qy;
+                qz = hit ? pz[r] : qz;
+            }
             vec_t o;
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                const T t0 = px - cx[p][v], t1 = py - cy[p][v], t2 = pz - cz[p][v];
+                const T t0 = qx - cx[p][v], t1 = qy - cy[p][v], t2 = qz - cz[p][v];
                 const T e = fma(t2, t2, fma(t1, t1, fma(t0, t0, T(0))));
                 o[v] = exp2_neg(-e);
             }
-            __builtin_nontemporal_store(o, reinterpret_cast<vec_t*>(row + j));
+            __builtin_nontemporal_store(o, reinterpret_cast<vec_t*>(base + (p * 256 + (int)threadIdx.x) * VEC));
         }
     }
 }
@@ -186,25 +211,42 @@ static int launch_conk(const T* x, int64_t n, const T* y, int64_t m, int d, doub
     const T s = (T)std::sqrt(beta * LOG2E);
     // developer knob: "2d" = the row-block form, "flat" = the flat-chunk form, "rows" = the row-contiguous form
     const char* knob = std::getenv("MVF_CONK");
-    // Default by shape (measured, profiles/r03_conk_ab.json): rows that are a multiple of 64 bytes long (the HBM burst)
-    // keep every wave's 1 KB segment burst-aligned in the row forms -> "rows" (5.65 - 5.69 TB/s at 2 M x 2000, either
-    // dtype); otherwise (3000 float32 columns: 12 000-byte rows, segments straddle bursts, 4.5 TB/s) the flat form,
-    // whose segments are aligned whatever m is (5.4 TB/s); float64 outside the row form's register budget: "2d".
-    const bool burst_rows = (m * (int64_t)sizeof(T)) % 64 == 0;
-    const std::string form = knob ? std::string(knob)
-                                  : std::string(burst_rows ? "rows" : (sizeof(T) == 4 ? "flat" : "2d"));
+    // Default: the row-contiguous form whenever a burst-aligned span of RS <= 4 rows fits its register budget (8 passes),
+    // else the flat form (float32) / the 2-D form (float64: its flat form is VALU-bound); profiles/r03_conk_ab*.json.
+    int rs = 1;
+    while (rs < 4 && ((int64_t)rs * m * (int64_t)sizeof(T)) % 64 != 0) rs *= 2;
+    const bool rows_fit = d == 3 && m % VEC == 0 && m >= 64 && ((int64_t)rs * m * (int64_t)sizeof(T)) % 64 == 0 &&
+                          (int64_t)rs * m <= 256 * VEC * 8;
+    const std::string form = knob ? std::string(knob) : std::string(rows_fit ? "rows" : (sizeof(T) == 4 ? "flat" : "2d"));
     const bool legacy = form != "flat";
-    if (form == "rows" && d == 3 && m % VEC == 0 && m >= 64 && m <= 256 * VEC * 4 && (n * m) % VEC == 0) {
-        const int np = (int)cdiv(m, 256 * VEC);
+    if (form == "rows" && rows_fit) {
+        const int np = (int)cdiv((int64_t)rs * m, 256 * VEC);
         const char* rk = std::getenv("MVF_CONK_ROWS");  // developer knob: rows per workgroup
         const int rows_pb = rk ? std::max(1, atoi(rk)) : 16;
-        const dim3 grid((unsigned)cdiv(n, rows_pb));
-        switch (np) {
-            case 1: hipLaunchKernelGGL((conk_rows_kernel<T, VEC, 1>), grid, dim3(256), 0, st, x, n, y, (int)m, s, K, rows_pb); break;
-            case 2: hipLaunchKernelGGL((conk_rows_kernel<T, VEC, 2>), grid, dim3(256), 0, st, x, n, y, (int)m, s, K, rows_pb); break;
-            case 3: hipLaunchKernelGGL((conk_rows_kernel<T, VEC, 3>), grid, dim3(256), 0, st, x, n, y, (int)m, s, K, rows_pb); break;
-            default: hipLaunchKernelGGL((conk_rows_kernel<T, VEC, 4>), grid, dim3(256), 0, st, x, n, y, (int)m, s, K, rows_pb); break;
+        const int spans_pb = std::max(1, rows_pb / rs);
+        const dim3 grid((unsigned)cdiv(cdiv(n, rs), spans_pb));
+#define MVF_CONK_ROWS_CASE(NPV, RSV)                                                                                       \
+    hipLaunchKernelGGL((conk_rows_kernel<T, VEC, NPV, RSV>), grid, dim3(256), 0, st, x, n, y, (int)m, s, K, spans_pb)
+#define MVF_CONK_ROWS_NP(RSV)                                  \
+    switch (np) {                                              \
+        case 1: MVF_CONK_ROWS_CASE(1, RSV); break;             \
+        case 2: MVF_CONK_ROWS_CASE(2, RSV); break;             \
+        case 3: MVF_CONK_ROWS_CASE(3, RSV); break;             \
+        case 4: MVF_CONK_ROWS_CASE(4, RSV); break;             \
+        case 5: MVF_CONK_ROWS_CASE(5, RSV); break;             \
+        case 6: MVF_CONK_ROWS_CASE(6, RSV); break;             \
+        case 7: MVF_CONK_ROWS_CASE(7, RSV); break;             \
+        default: MVF_CONK_ROWS_CASE(8, RSV); break;            \
+    }
+        if (rs == 1) {
+            MVF_CONK_ROWS_NP(1)
+        } else if (rs == 2) {
+            MVF_CONK_ROWS_NP(2)
+        } else {
+            MVF_CONK_ROWS_NP(4)
         }
+#undef MVF_CONK_ROWS_NP
+#undef MVF_CONK_ROWS_CASE
         MVF_LAUNCH_CHECK();
         return 0;
     }

@@ -717,10 +717,12 @@ def test_hull_mask_matches_delaunay_find_simplex():
         assert (np.abs(margin) < 1e-9 * extent).all()
 
 
-@pytest.mark.parametrize("dtype,n,m", [("float32", 5003, 2000), ("float64", 3001, 1000), ("float32", 700, 3000)])
+@pytest.mark.parametrize("dtype,n,m", [("float32", 5003, 2000), ("float64", 3001, 1000), ("float32", 701, 3000),
+                                       ("float32", 1003, 1004), ("float64", 333, 3000)])
 def test_con_k_store_patterns_are_bit_identical(dtype, n, m):
-    """The three materialised con_K kernels (row-contiguous, flat 16 KB chunks with the control points in LDS, 2-D
-    row blocks; MVF_CONK = rows | flat | 2d) agree bit for bit - ragged last chunk / pass included - and with the oracle."""
+    """The three materialised con_K kernels (row-contiguous spans of 1 / 2 / 4 rows, flat 16 KB chunks with the control
+    points in LDS, 2-D row blocks; MVF_CONK = rows | flat | 2d) agree bit for bit - ragged last chunk / pass / span
+    included - and with the oracle."""
     import os
 
     from spateo_amd._kernels import HipKernels
