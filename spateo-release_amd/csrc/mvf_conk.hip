@@ -222,7 +222,11 @@ static int launch_conk(const T* x, int64_t n, const T* y, int64_t m, int d, doub
     if (form == "rows" && rows_fit) {
         const int np = (int)cdiv((int64_t)rs * m, 256 * VEC);
         const char* rk = std::getenv("MVF_CONK_ROWS");  // developer knob: rows per workgroup
-        const int rows_pb = rk ? std::max(1, atoi(rk)) : 16;
+        // ~128 KB of contiguous output per workgroup, at most 16 rows (measured 8 / 16 / 32 / 64 rows per workgroup: within
+        // 3 % of each other, profiles/r03_conk_ab_rowspans.json)
+        const int64_t row_bytes = m * (int64_t)sizeof(T);
+        const int rows_auto = (int)std::min<int64_t>(16, std::max<int64_t>(rs, (131072 / row_bytes) / rs * rs));
+        const int rows_pb = rk ? std::max(1, atoi(rk)) : rows_auto;
         const int spans_pb = std::max(1, rows_pb / rs);
         const dim3 grid((unsigned)cdiv(cdiv(n, rs), spans_pb));
 #define MVF_CONK_ROWS_CASE(NPV, RSV)                                                                                       \
