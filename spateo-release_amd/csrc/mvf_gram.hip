@@ -330,18 +330,29 @@ template <> struct CachedPipe<double> { static constexpr int UGT = MVF_DBL_UG, N
 // One wave's share of a tile: NA x NB blocks of 16 x 16 (TRI: only the blocks b >= a of a square arrangement) whose
 // first row block is `rb0` and first column block `cb0` (absolute 16-wide block indices into Ublk); results go to
 // out[(orow0 + ...) * GT + ocol0 + ...] of the 128 x 128 partial tile.
-template <typename T, int NA, int NB, bool TRI>
+// DW >= 0 (diagonal tile, balanced): NA = 2, NB = 8; this wave takes row blocks DW and 7 - DW of the tile and, of each, only
+// the blocks on or above the diagonal (8 - DW and DW + 1 of them: 9 for every wave - the four waves of a diagonal tile finish
+// together and execute 36 of the 64 blocks; same registers as the full 2 x 8 shape, of which it is a sub-shape).
+template <typename T, int NA, int NB, bool TRI, int DW = -1>
 __device__ __forceinline__ void cached_block(const T* __restrict__ ublk, const T* __restrict__ P, int64_t n,
                                              int64_t n_pad, int64_t n0, int64_t n1, int64_t rb0, int64_t cb0,
                                              double* __restrict__ out, int orow0, int ocol0) {
     constexpr int UGT = CachedPipe<T>::UGT, NBUF = CachedPipe<T>::NBUF;
+    static_assert(DW < 0 || (NA == 2 && NB == 8 && !TRI && DW < 4), "balanced diagonal shape is a sub-shape of 2 x 8");
     const int lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
+    // block (a, b) is computed iff ...
+    auto blk_live = [](int a, int b) constexpr {
+        if (DW >= 0) return b >= (a == 0 ? DW : 7 - DW);
+        return !TRI || b >= a;
+    };
+    // row block of operand a relative to rb0, and its first row in the partial tile relative to orow0
+    auto rblk = [](int a) constexpr { return DW >= 0 ? (a == 0 ? DW : 7 - DW) : a; };
 
     const T* pa[NA];
     const T* pb[NB];
 #pragma unroll
-    for (int a = 0; a < NA; ++a) pa[a] = ublk + ((rb0 + a) * n_pad + n0 + lk) * UB + li;
+    for (int a = 0; a < NA; ++a) pa[a] = ublk + ((rb0 + rblk(a)) * n_pad + n0 + lk) * UB + li;
 #pragma unroll
     for (int b = 0; b < NB; ++b) pb[b] = ublk + ((cb0 + b) * n_pad + n0 + lk) * UB + li;
 
@@ -413,7 +424,7 @@ __device__ __forceinline__ void cached_block(const T* __restrict__ ublk, const T
             for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
-                    if (!TRI || b >= a)
+                    if (blk_live(a, b))
                         acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
 #ifndef MVF_PROBE_NO_SETPRIO
             __builtin_amdgcn_s_setprio(0);
@@ -450,10 +461,10 @@ __device__ __forceinline__ void cached_block(const T* __restrict__ ublk, const T
     for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-            if (!TRI || b >= a) {
+            if (blk_live(a, b)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = orow0 + a * 16 + lk + 4 * r;
+                    const int row = orow0 + rblk(a) * 16 + lk + 4 * r;
                     const int col = ocol0 + b * 16 + li;
                     __builtin_nontemporal_store(acc[a][b][r], &out[row * GT + col]);  // read once, by the reduction
                 }
@@ -482,25 +493,28 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
     double* out = partial + ((size_t)slice * npairs + pair) * (size_t)(GT * GT);
     constexpr int TB = GT / UB;  // 8 blocks per tile side
     const int64_t rb = (int64_t)ti * TB, cb = (int64_t)tj * TB;
+    // Both dtypes: the edge shape (2 x 4) and the balanced diagonal shape are SUB-shapes of the 2 x 8 wave tile - no
+    // extra registers.  (Round 1 - 2 gave the diagonal tile of the float32 kernel a 4 x 4 triangular body for waves 2, 3:
+    // 10 blocks against 8 for waves 0, 1; in float64 that body cost registers and lost 5 %, so float64 computed every
+    // tile in full: executed / algorithmic flops 1.108 at m = 3000.  The balanced shape gives every wave 9 blocks.)
 #ifdef MVF_PROBE_NO_SKIP
-    constexpr bool skip = false;
+    cached_block<T, 2, 8, false>(ublk, P, n, n_pad, n0, n1, rb + 2 * wave, cb, out, 32 * wave, 0);
 #else
-    constexpr bool skip = sizeof(T) == 4;  // measured: +1.6 ... 3.2 % for float, -5 % for double (register pressure)
-#endif
-    if constexpr (!skip) {
-        cached_block<T, 2, 8, false>(ublk, P, n, n_pad, n0, n1, rb + 2 * wave, cb, out, 32 * wave, 0);
-    } else if (ti != tj) {
+    if (ti != tj) {
         const int64_t live_cols = m - (int64_t)tj * GT;  // > 0
         if (live_cols <= 4 * UB)
             cached_block<T, 2, 4, false>(ublk, P, n, n_pad, n0, n1, rb + 2 * wave, cb, out, 32 * wave, 0);
         else
             cached_block<T, 2, 8, false>(ublk, P, n, n_pad, n0, n1, rb + 2 * wave, cb, out, 32 * wave, 0);
-    } else if (wave < 2) {
-        cached_block<T, 2, 4, false>(ublk, P, n, n_pad, n0, n1, rb + 2 * wave, cb + 4, out, 32 * wave, 64);
     } else {
-        const int q = wave - 2;
-        cached_block<T, 4, 4, true>(ublk, P, n, n_pad, n0, n1, rb + 4 * q, cb + 4 * q, out, 64 * q, 64 * q);
+        switch (wave) {
+            case 0: cached_block<T, 2, 8, false, 0>(ublk, P, n, n_pad, n0, n1, rb, cb, out, 0, 0); break;
+            case 1: cached_block<T, 2, 8, false, 1>(ublk, P, n, n_pad, n0, n1, rb, cb, out, 0, 0); break;
+            case 2: cached_block<T, 2, 8, false, 2>(ublk, P, n, n_pad, n0, n1, rb, cb, out, 0, 0); break;
+            default: cached_block<T, 2, 8, false, 3>(ublk, P, n, n_pad, n0, n1, rb, cb, out, 0, 0); break;
+        }
     }
+#endif
 }
 
 // ----------------------------------------------------------------------------------------------------------------

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmvf.so")
+# MVF_LIB_PATH: developer override for A/B runs of two builds of the library (never set in production)
+LIB_PATH = os.environ.get("MVF_LIB_PATH") or os.path.join(_HERE, "lib", "libmvf.so")
 
 MVF_F32, MVF_F64 = 0, 1
 MVF_ESTEP_MIN_DOUBLES = 4098
