@@ -493,14 +493,21 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
     double* out = partial + ((size_t)slice * npairs + pair) * (size_t)(GT * GT);
     constexpr int TB = GT / UB;  // 8 blocks per tile side
     const int64_t rb = (int64_t)ti * TB, cb = (int64_t)tj * TB;
-    // Both dtypes: the edge shape (2 x 4) and the balanced diagonal shape are SUB-shapes of the 2 x 8 wave tile - no
-    // extra registers.  (Round 1 - 2 gave the diagonal tile of the float32 kernel a 4 x 4 triangular body for waves 2, 3:
-    // 10 blocks against 8 for waves 0, 1; in float64 that body cost registers and lost 5 %, so float64 computed every
-    // tile in full: executed / algorithmic flops 1.108 at m = 3000.  The balanced shape gives every wave 9 blocks.)
+    // float32: work the reduction never reads is not computed - the edge shape (2 x 4: last tile column with <= 64 live
+    // control points) and the balanced diagonal shape (every wave 9 of the 36 blocks on or above the diagonal; rounds
+    // 1 - 2 used a 4 x 4 triangular body for waves 2, 3: 10 blocks against 8 for waves 0, 1) - both sub-shapes of the 2 x 8
+    // wave tile.  Same-box A/B (profiles/r03_gram_diag_ab.md): float32 67.13 -> 67.36 TF at 8 M cells.
+    // float64: every tile in full.  Measured twice now: round 2's triangular body cost registers (-5 %); round 3's
+    // register-neutral sub-shapes lose 4 % at 8 M cells (60.5 -> 58.2 TF) and nothing at 1 M - the float64 kernel lives
+    // on the tile pairs of a slice streaming their panels in step, and jobs of unequal length drift apart.
 #ifdef MVF_PROBE_NO_SKIP
-    cached_block<T, 2, 8, false>(ublk, P, n, n_pad, n0, n1, rb + 2 * wave, cb, out, 32 * wave, 0);
+    constexpr bool skip = false;
 #else
-    if (ti != tj) {
+    constexpr bool skip = sizeof(T) == 4;
+#endif
+    if constexpr (!skip) {
+        cached_block<T, 2, 8, false>(ublk, P, n, n_pad, n0, n1, rb + 2 * wave, cb, out, 32 * wave, 0);
+    } else if (ti != tj) {
         const int64_t live_cols = m - (int64_t)tj * GT;  // > 0
         if (live_cols <= 4 * UB)
             cached_block<T, 2, 4, false>(ublk, P, n, n_pad, n0, n1, rb + 2 * wave, cb, out, 32 * wave, 0);
@@ -514,7 +521,6 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
             default: cached_block<T, 2, 8, false, 3>(ublk, P, n, n_pad, n0, n1, rb, cb, out, 0, 0); break;
         }
     }
-#endif
 }
 
 // ----------------------------------------------------------------------------------------------------------------
