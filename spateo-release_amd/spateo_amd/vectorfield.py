@@ -413,8 +413,8 @@ class SparseVFCEngine:
         """One EM iteration (Appendix A step 5 a-e).  Returns (E, tecr).
 
         Collectives per step (multi-rank): the 8-byte MIN of the E-step's global min-non-zero rule, THE all-reduce of the
-        sufficient statistics [tri(G) | R | stats] and the 8-byte sum P r; none of them is followed by a host round
-        trip of its own.  Host round trips: one after the solve (its status / pivots, the statistics, the energy - every
+        sufficient statistics [tri(G) | R | stats], the 112-byte agreement check of the solver decisions (_agree) and the
+        8-byte sum P r; only the agreement check is followed by a host read of its own.  Host round trips: one after the solve (its status / pivots, the statistics, the energy - every
         control-flow decision is taken from all-reduced or replicated deterministic values, so all ranks decide alike)
         and one for sigma^2; the minimum-norm solve adds its own (one per Jacobi sweep)."""
         k = self.k
@@ -507,7 +507,14 @@ class SparseVFCEngine:
 
         v = [float(x) for x in sig] + [1.0 if err is not None else 0.0]
         t = torch.tensor(v + [-x for x in v], dtype=torch.float64, device=self.k.device)
+        ev = None
+        if self.comm_events is not None:  # counted with the step's other collectives (bench.py `comm`)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        if ev is not None:
+            ev[1].record()
+            self.comm_events.append(ev + (t.numel() * t.element_size(),))
         t = t.cpu().numpy()
         n = len(v)
         hi, lo = t[:n], -t[n:]
