@@ -286,6 +286,10 @@ __global__ __launch_bounds__(EIG_THREADS) void jac_eig_kernel(const double* __re
         {
             int pk, qk;
             inner_pair<FULL>(r, k, pk, qk);
+#ifdef MVF_EIG_NO_S  // measurement arm only (wrong results): the S update switched off
+            if (tol < 0.0)
+#endif
+            {
             const double m00 = S[pk][p], m01 = S[pk][q], m10 = S[qk][p], m11 = S[qk][q];
             const double r00 = fma(ck, m00, -(sk * m10)), r01 = fma(ck, m01, -(sk * m11));
             const double r10 = fma(sk, m00, ck * m10), r11 = fma(sk, m01, ck * m11);
@@ -299,9 +303,13 @@ __global__ __launch_bounds__(EIG_THREADS) void jac_eig_kernel(const double* __re
             S[pk][q] = n01;
             S[qk][p] = n10;
             S[qk][q] = n11;
+            }
         }
         __syncthreads();
         if (k == 0 && r + 1 < NR) rotation(r + 1, cs[(r + 1) & 1]);
+#ifdef MVF_EIG_NO_J  // measurement arm only (wrong results): the J accumulation switched off
+        if (tol < 0.0)
+#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int i = k + 32 * j;
