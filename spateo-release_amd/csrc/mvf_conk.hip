@@ -220,7 +220,6 @@ static int launch_conk(const T* x, int64_t n, const T* y, int64_t m, int d, doub
     const std::string form = knob ? std::string(knob) : std::string(rows_fit ? "rows" : (sizeof(T) == 4 ? "flat" : "2d"));
     const bool legacy = form != "flat";
     if (form == "rows" && rows_fit) {
-        const int np = (int)cdiv((int64_t)rs * m, 256 * VEC);
         const char* rk = std::getenv("MVF_CONK_ROWS");  // developer knob: rows per workgroup
         // ~128 KB of contiguous output per workgroup, at most 16 rows (measured 8 / 16 / 32 / 64 rows per workgroup: within
         // 3 % of each other, profiles/r03_conk_ab_rowspans.json)
@@ -229,26 +228,31 @@ static int launch_conk(const T* x, int64_t n, const T* y, int64_t m, int d, doub
         const int rows_pb = rk ? std::max(1, atoi(rk)) : rows_auto;
         const int spans_pb = std::max(1, rows_pb / rs);
         const dim3 grid((unsigned)cdiv(cdiv(n, rs), spans_pb));
-#define MVF_CONK_ROWS_CASE(NPV, RSV)                                                                                       \
-    hipLaunchKernelGGL((conk_rows_kernel<T, VEC, NPV, RSV>), grid, dim3(256), 0, st, x, n, y, (int)m, s, K, spans_pb)
-#define MVF_CONK_ROWS_NP(RSV)                                  \
-    switch (np) {                                              \
-        case 1: MVF_CONK_ROWS_CASE(1, RSV); break;             \
-        case 2: MVF_CONK_ROWS_CASE(2, RSV); break;             \
-        case 3: MVF_CONK_ROWS_CASE(3, RSV); break;             \
-        case 4: MVF_CONK_ROWS_CASE(4, RSV); break;             \
-        case 5: MVF_CONK_ROWS_CASE(5, RSV); break;             \
-        case 6: MVF_CONK_ROWS_CASE(6, RSV); break;             \
-        case 7: MVF_CONK_ROWS_CASE(7, RSV); break;             \
-        default: MVF_CONK_ROWS_CASE(8, RSV); break;            \
+        // (32 bytes per lane and pass - a 2 x VEC vector store - was measured too: 1.9 - 2.3 TB/s, the compiler does not emit
+        // two adjacent 16-byte stores for it; profiles/r03_conk_ab_wide.json)
+#define MVF_CONK_ROWS_CASE(VECV, NPV, RSV)                                                                                 \
+    hipLaunchKernelGGL((conk_rows_kernel<T, VECV, NPV, RSV>), grid, dim3(256), 0, st, x, n, y, (int)m, s, K, spans_pb)
+#define MVF_CONK_ROWS_NP(VECV, RSV)                                  \
+    switch ((int)cdiv((int64_t)rs * m, 256 * VECV)) {                \
+        case 1: MVF_CONK_ROWS_CASE(VECV, 1, RSV); break;             \
+        case 2: MVF_CONK_ROWS_CASE(VECV, 2, RSV); break;             \
+        case 3: MVF_CONK_ROWS_CASE(VECV, 3, RSV); break;             \
+        case 4: MVF_CONK_ROWS_CASE(VECV, 4, RSV); break;             \
+        case 5: MVF_CONK_ROWS_CASE(VECV, 5, RSV); break;             \
+        case 6: MVF_CONK_ROWS_CASE(VECV, 6, RSV); break;             \
+        case 7: MVF_CONK_ROWS_CASE(VECV, 7, RSV); break;             \
+        default: MVF_CONK_ROWS_CASE(VECV, 8, RSV); break;            \
     }
-        if (rs == 1) {
-            MVF_CONK_ROWS_NP(1)
-        } else if (rs == 2) {
-            MVF_CONK_ROWS_NP(2)
-        } else {
-            MVF_CONK_ROWS_NP(4)
-        }
+#define MVF_CONK_ROWS_RS(VECV)          \
+    if (rs == 1) {                      \
+        MVF_CONK_ROWS_NP(VECV, 1)       \
+    } else if (rs == 2) {               \
+        MVF_CONK_ROWS_NP(VECV, 2)       \
+    } else {                            \
+        MVF_CONK_ROWS_NP(VECV, 4)       \
+    }
+        MVF_CONK_ROWS_RS(VEC)
+#undef MVF_CONK_ROWS_RS
 #undef MVF_CONK_ROWS_NP
 #undef MVF_CONK_ROWS_CASE
         MVF_LAUNCH_CHECK();

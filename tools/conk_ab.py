@@ -16,11 +16,14 @@ for nk, mk in ((2_000_000, 2000), (1_000_000, 3000)):
         xs = torch.from_numpy((X - ctrl.mean(0)).astype(npdt)).cuda()
         cs = torch.from_numpy((ctrl - ctrl.mean(0)).astype(npdt)).cuda()
         K = torch.empty(nk, mk, dtype=tdt, device="cuda")
-        for form in ("rows", "rows8", "rows32", "rows64", "flat", "2d"):
+        for form in ("rows", "rows8", "flat", "2d"):
             os.environ["MVF_CONK"] = "rows" if form.startswith("rows") else form
             os.environ.pop("MVF_CONK_ROWS", None)
-            if form.startswith("rows") and form != "rows":
-                os.environ["MVF_CONK_ROWS"] = form[4:]
+            os.environ.pop("MVF_CONK_WIDE", None)
+            if form.startswith("rows8"):
+                os.environ["MVF_CONK_ROWS"] = "8"
+            if form.endswith("_wide"):
+                os.environ["MVF_CONK_WIDE"] = "1"
             f = lambda: L.check(lib.mvf_con_k(xs.data_ptr(), nk, cs.data_ptr(), mk, 3, 2.7e-6, K.data_ptr(), code, st))
             f(); torch.cuda.synchronize()
             ev = []
@@ -34,6 +37,7 @@ for nk, mk in ((2_000_000, 2000), (1_000_000, 3000)):
             print(f"{nk} x {mk} {dt} {form:5s}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
         os.environ.pop("MVF_CONK", None)
         os.environ.pop("MVF_CONK_ROWS", None)
+        os.environ.pop("MVF_CONK_WIDE", None)
         del K, xs, cs
         torch.cuda.empty_cache()
 if len(sys.argv) > 1:
