@@ -505,11 +505,15 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
 #else
     constexpr bool skip = sizeof(T) == 4;
 #endif
-    if constexpr (!skip) {
-        cached_block<T, 2, 8, false>(ublk, P, n, n_pad, n0, n1, rb + 2 * wave, cb, out, 32 * wave, 0);
-    } else if (ti != tj) {
+    // probe arms for the float64 instantiation (profiles/r03_gram_diag_ab.md): 1 = edge shape only, 2 = diagonal shape only
+#ifndef MVF_PROBE_F64_SHAPES
+#define MVF_PROBE_F64_SHAPES 0
+#endif
+    constexpr bool use_edge = skip || (MVF_PROBE_F64_SHAPES & 1);
+    constexpr bool use_diag = skip || (MVF_PROBE_F64_SHAPES & 2);
+    if (ti != tj || !use_diag) {
         const int64_t live_cols = m - (int64_t)tj * GT;  // > 0
-        if (live_cols <= 4 * UB)
+        if (use_edge && ti != tj && live_cols <= 4 * UB)
             cached_block<T, 2, 4, false>(ublk, P, n, n_pad, n0, n1, rb + 2 * wave, cb, out, 32 * wave, 0);
         else
             cached_block<T, 2, 8, false>(ublk, P, n, n_pad, n0, n1, rb + 2 * wave, cb, out, 32 * wave, 0);
