@@ -307,7 +307,8 @@ def test_morphopath_fused_rk4_vs_dop853(st, golden, dtype, tol):
 
 
 def test_many_independent_fits_on_streams(st):
-    """BASELINE config 5 shape (independent organs, one per HIP stream): concurrent fits == sequential fits."""
+    """BASELINE config 5 shape (independent organs, one per HIP stream): concurrent fits == sequential fits == the
+    oracle's fits."""
     from spateo_amd.vectorfield import SparseVFC_many
     from spateo_amd._synthetic import ellipsoid_cloud, displacement_field
 
@@ -326,6 +327,13 @@ def test_many_independent_fits_on_streams(st):
         np.testing.assert_array_equal(a["X_ctrl"], b["X_ctrl"])
         assert _rel(b["V"], a["V"]) < 1e-10 and _rel(b["grid_V"], a["grid_V"]) < 1e-10
         assert a["iteration"] == b["iteration"]
+    # ... and the concurrent fits are the ORACLE's fits (M = 100: the single-launch solve path), not only each other's
+    okw = dict(M=100, lambda_=3.0, MaxIter=8)
+    for (X, V, G), b in zip(data[:3], par[:3]):
+        ref = svo.SparseVFC(X, V, G, **okw)
+        assert b["iteration"] == ref["iteration"]
+        assert _rel(b["V"], ref["V"]) < 1e-5 and _rel(b["grid_V"], ref["grid_V"]) < 1e-5
+        np.testing.assert_allclose(b["sigma2"], ref["sigma2"], rtol=1e-5)
 
 
 def test_morphofield_missing_key_errors(st):
