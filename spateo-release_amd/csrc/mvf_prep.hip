@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void hull_mask_kernel(const double* __restrict
         for (int f = 0; f < fc; ++f)
             worst = fmax(worst, fma(se[f][0], px, fma(se[f][1], py, fma(se[f][2], pz, se[f][3]))));
     }
-    if (live) inside[i] = (worst <= tol) ? 1 : 0;
+    // fmax() drops a NaN operand, so a non-finite point would leave worst = -inf and count as inside; find_simplex says -1
+    if (live) inside[i] = (worst <= tol && isfinite(px) && isfinite(py) && isfinite(pz)) ? 1 : 0;
 }
 }  // namespace
 

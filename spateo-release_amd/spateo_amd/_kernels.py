@@ -69,9 +69,67 @@ class HipKernels:
             raise ValueError(f"expected an (n, d) array with d <= 3, got shape {a.shape}")
         if center is not None:
             a = a - np.asarray(center, dtype=np.float64)[None, : a.shape[1]]
-        buf = np.zeros((a.shape[0], 4), dtype=np.float32 if self.tdtype == torch.float32 else np.float64)
-        buf[:, : a.shape[1]] = a
+        return self.h2d_padded(a, 4, self.tdtype)
+
+    # pinned staging: host arrays up to this size travel through page-locked tensors of torch's caching host allocator
+    # (one DMA, no driver-side bounce copies); larger ones keep the pageable path so that a fit of 8 M cells does not
+    # leave hundreds of MB of the host page-locked for the life of the process
+    PINNED_MAX_BYTES = 128 << 20
+
+    def h2d_padded(self, a, width, tdtype):
+        """Host (n, d <= width) float64 array -> device (n, width) tensor of `tdtype`, zero padded."""
+        n, d = a.shape
+        nbytes = n * width * (4 if tdtype == torch.float32 else 8)
+        if 0 < nbytes <= self.PINNED_MAX_BYTES:
+            host = torch.empty((n, width), dtype=tdtype, pin_memory=True)
+            hv = host.numpy()
+            hv[:, :d] = a
+            hv[:, d:] = 0
+            return host.to(self.device, non_blocking=True)
+        buf = np.zeros((n, width), dtype=np.float32 if tdtype == torch.float32 else np.float64)
+        buf[:, :d] = a
         return torch.from_numpy(buf).to(self.device)
+
+    @_on_device
+    def to_host(self, tensors):
+        """Device tensors -> host NumPy arrays with ONE stream synchronisation: page-locked destinations while the total
+        stays under PINNED_MAX_BYTES (the arrays returned then own their pinned block until they are garbage collected),
+        otherwise pageable arrays filled through two page-locked 32 MB staging buffers."""
+        tensors = [t.contiguous() for t in tensors]
+        total = sum(t.numel() * t.element_size() for t in tensors)
+        stream = torch.cuda.current_stream(self.device)
+        if total <= self.PINNED_MAX_BYTES:
+            hosts = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
+            for h, t in zip(hosts, tensors):
+                h.copy_(t, non_blocking=True)
+            stream.synchronize()
+            return [h.numpy() for h in hosts]
+        outs = []
+        chunk = 32 << 20
+        stage = [torch.empty(chunk, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        events = [torch.cuda.Event(), torch.cuda.Event()]
+        for t in tensors:
+            out = np.empty(tuple(t.shape), dtype={torch.float64: np.float64, torch.float32: np.float32,
+                                                  torch.int64: np.int64, torch.uint8: np.uint8}[t.dtype])
+            flat_d = t.view(-1).view(torch.uint8)
+            flat_h = out.reshape(-1).view(np.uint8)
+            nb = flat_d.numel()
+            pending = []  # (buffer index, lo, hi) in flight
+            for i, lo in enumerate(range(0, nb, chunk)):
+                b = i & 1
+                if len(pending) == 2:
+                    pb, plo, phi = pending.pop(0)
+                    events[pb].synchronize()
+                    flat_h[plo:phi] = stage[pb][: phi - plo].numpy()
+                hi = min(lo + chunk, nb)
+                stage[b][: hi - lo].copy_(flat_d[lo:hi], non_blocking=True)
+                events[b].record(stream)
+                pending.append((b, lo, hi))
+            for pb, plo, phi in pending:
+                events[pb].synchronize()
+                flat_h[plo:phi] = stage[pb][: phi - plo].numpy()
+            outs.append(out)
+        return outs
 
     def _red(self, n, at_least=0):
         """Scratch of the deterministic reductions: mvf_reduce_scratch_doubles(n) float64, and never fewer than

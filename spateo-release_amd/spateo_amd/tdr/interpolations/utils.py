@@ -20,7 +20,7 @@ def _in_hull(p: np.ndarray, hull) -> np.ndarray:
     if torch.cuda.is_available():
         from ... import vectorfield as _vf
 
-        k = _vf._make_kernels(None, "float64")
+        k = _vf._shared_kernels(None, "float64")
         if hasattr(k, "hull_mask"):
             extent = float(np.max(hull.max_bound - hull.min_bound))
             return k.hull_mask(p, hull.equations, 100.0 * np.finfo(np.float64).eps * extent)

@@ -31,6 +31,13 @@ def _generate_vf_class(adata, vf_key: str, method: str = "gaussian_process", non
     )
 
 
+def _row_norms(a):
+    """``np.array([np.linalg.norm(i) for i in a])`` (``differential_geometry.py:199,244``: 2-norm of a scalar / vector,
+    Frobenius norm of a matrix entry) without the Python loop over the cells."""
+    a = np.asarray(a)
+    return np.abs(a) if a.ndim == 1 else np.sqrt(np.einsum("ij,ij->i", a.reshape(len(a), -1), a.reshape(len(a), -1)))
+
+
 def _vf(adata, vf_key, nonrigid_only):
     return _generate_vf_class(adata=adata, vf_key=vf_key, method=adata.uns[vf_key]["method"], nonrigid_only=nonrigid_only)
 
@@ -72,7 +79,7 @@ def morphofield_curl(adata, vf_key: str = "VecFld_morpho", key_added: str = "cur
     vf = _vf(adata, vf_key, nonrigid_only)
     X, _ = vf.get_data()
     curl = vf.compute_curl(X=X, method=method)
-    adata.obs[key_added] = np.array([np.linalg.norm(i) for i in curl])
+    adata.obs[key_added] = _row_norms(curl)
     adata.obsm[key_added] = curl
     return None if inplace else adata
 
@@ -84,7 +91,7 @@ def morphofield_torsion(adata, vf_key: str = "VecFld_morpho", key_added: str = "
     vf = _vf(adata, vf_key, nonrigid_only)
     X, _ = vf.get_data()
     torsion_mat = vf.compute_torsion(X=X, method=method)
-    adata.obs[key_added] = np.array([np.linalg.norm(i) for i in torsion_mat])
+    adata.obs[key_added] = _row_norms(torsion_mat)
     adata.uns[key_added] = torsion_mat
     return None if inplace else adata
 
@@ -107,9 +114,8 @@ def morphofield_jacobian(adata, vf_key: str = "VecFld_morpho", key_added: str = 
     adata = adata if inplace else adata.copy()
     vf = _vf(adata, vf_key, nonrigid_only)
     X, _ = vf.get_data()
-    Jac_func = vf.get_Jacobian(method=method)
     cell_idx = np.arange(adata.n_obs)
-    Js = Jac_func(x=X[cell_idx])
-    adata.obs[key_added] = np.linalg.det(np.moveaxis(Js, 2, 0))
+    Js, det = vf.jacobian_with_det(X[cell_idx], method=method)  # one device pass; no per-cell np.linalg.det
+    adata.obs[key_added] = det
     adata.uns[key_added] = Js
     return None if inplace else adata

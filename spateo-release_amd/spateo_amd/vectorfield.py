@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import math
 import os
+import threading
 
 import numpy as np
 import torch
@@ -45,6 +46,30 @@ _DEFAULT_DTYPE = "float64"
 def _make_kernels(device, dtype):
     """The one place that binds the HIP kernels (tests/ monkeypatch this seam to exercise the host logic on CPU)."""
     return HipKernels(device, dtype)
+
+
+_TLS = threading.local()
+
+
+def _shared_kernels(device, dtype):
+    """The kernels object of the STATELESS entry points (con_K, evaluators, preprocessing, hull mask): one per (thread,
+    device, dtype), built on first use.  A fit owns its own object (``SparseVFCEngine`` keeps workspaces, the kernel-value
+    cache and the solver's pivot-order hint in it); the stateless calls used to build a fresh one per call."""
+    if device is None and torch.cuda.is_available():
+        device = f"cuda:{torch.cuda.current_device()}"
+    key = (_make_kernels, str(device), dtype)
+    cache = _TLS.__dict__.setdefault("kernels", {})
+    k = cache.get(key)
+    if k is None:
+        k = cache[key] = _make_kernels(device, dtype)
+    return k
+
+
+def _to_host(k, tensors):
+    """Device tensors -> host NumPy arrays (pinned staging + one synchronisation on the GPU path)."""
+    if hasattr(k, "to_host"):
+        return k.to_host(tensors)
+    return [t.cpu().numpy().copy() for t in tensors]
 
 
 _LSTSQ_WARNED = set()
@@ -94,7 +119,7 @@ def bandwidth_selector(X: np.ndarray, device=None) -> float:
     X = np.asarray(X, dtype=np.float64)
     if (_DEVICE_KNN_MIN_POINTS <= n <= 8192 and X.ndim == 2 and X.shape[1] <= 8 and np.isfinite(X).all()
             and torch.cuda.is_available()):
-        kern = _make_kernels(device, "float64")
+        kern = _shared_kernels(device, "float64")
         if hasattr(kern, "knn_mean_distance"):
             return float(np.sqrt(2) * kern.knn_mean_distance(X, k) / 1.5)
     from scipy.spatial import cKDTree
@@ -136,7 +161,7 @@ def unique_rows(X: np.ndarray, device=None):
     if n < 2 or d < 1 or X.dtype.kind != "f" or not np.isfinite(X).all():
         return np.unique(X, axis=0, return_index=True)
     if n >= _DEVICE_UNIQUE_MIN_ROWS and X.dtype == np.float64 and d <= 16 and torch.cuda.is_available():
-        k = _make_kernels(device, "float64")
+        k = _shared_kernels(device, "float64")
         if hasattr(k, "unique_rows"):
             return k.unique_rows(X)
     order = np.argsort(X[:, 0], kind="stable")
@@ -669,7 +694,7 @@ def con_K(x, y, beta: float = 0.1, method: str = "cdist", return_d: bool = False
     y = np.asarray(y, dtype=np.float64)
     if x.ndim == 1:
         x = x[None, :]
-    k = _make_kernels(device, dtype)
+    k = _shared_kernels(device, dtype)
     npdt = np.float32 if dtype == "float32" else np.float64
     # translation invariance: centre before a possible cast to float32
     c = y.mean(0) if len(y) else np.zeros(x.shape[1])
@@ -688,6 +713,58 @@ def con_K(x, y, beta: float = 0.1, method: str = "cdist", return_d: bool = False
     return K
 
 
+_EVAL_ALL = (_lib.EVAL_V | _lib.EVAL_JAC | _lib.EVAL_DIV | _lib.EVAL_CURL | _lib.EVAL_ACC | _lib.EVAL_CURV |
+             _lib.EVAL_TORS | _lib.EVAL_JDET)
+_EVAL_BYTES_PER_POINT = 8 * (3 + 9 + 1 + 3 + 3 + 3 + 3 + 1)
+_EVAL_PREFETCH_CAP = 2 << 30   # every quantity is kept on the device for the next call while it fits in this many bytes
+
+
+class _FusedEval:
+    """ONE evaluator launch behind several API calls.  The kernel accumulates v and the 3 x 3 Jacobian of a query point
+    in registers whatever is asked for; every further quantity is a few register operations and an HBM store.  The
+    reference's call shape, however, is one call per quantity on the same points (``get_Jacobian()(X)`` then
+    ``compute_curl(X=X)``; the seven ``morphofield_*`` wrappers, each with a fresh vector-field object).  So the first
+    call on (points, field) launches once for ALL quantities and keeps them on the device (thread-local, one entry);
+    later calls on the same points and the same field - compared by value - only copy their quantity to the host."""
+
+    def __init__(self, X, sig):
+        self.X, self.sig, self.flags, self.dev, self.k = X.copy(), sig, 0, {}, None
+
+    def matches(self, X, sig):
+        if X.shape != self.X.shape or len(sig) != len(self.sig):
+            return False
+        for a, b in zip(sig, self.sig):
+            if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+                if not (isinstance(a, np.ndarray) and isinstance(b, np.ndarray) and a.shape == b.shape
+                        and np.array_equal(a, b)):
+                    return False
+            elif a != b:
+                return False
+        return np.array_equal(X, self.X)
+
+
+def clear_eval_cache():
+    """Drop the evaluator results kept on the device by the last ``SvcVectorField`` / ``GPVectorField`` call."""
+    _TLS.__dict__.pop("fused", None)
+
+
+def _fused_eval(X, sig, flags, k, launch):
+    """Host arrays {flag: ndarray} of the requested quantities; ``launch(flags) -> {flag: device tensor}``."""
+    sig = tuple(np.array(a, dtype=np.float64) if isinstance(a, (np.ndarray, list, tuple)) else a for a in sig)
+    ent = _TLS.__dict__.get("fused")
+    if ent is None or ent.k is not k or not ent.matches(X, sig):
+        ent = _TLS.fused = _FusedEval(X, sig)
+        ent.k = k
+    missing = flags & ~ent.flags
+    if missing:
+        want = _EVAL_ALL if len(X) * _EVAL_BYTES_PER_POINT <= _EVAL_PREFETCH_CAP else missing
+        want &= ~ent.flags
+        ent.dev.update(launch(want))
+        ent.flags |= want
+    fl = [f for f in ent.dev if flags & f]
+    return dict(zip(fl, _to_host(k, [ent.dev[f] for f in fl])))
+
+
 def _field_on_device(x, vf_dict, flags, dtype=None, device=None):
     """Run the fused evaluator for points x (n, d) against vf_dict's control points / coefficients."""
     dtype = dtype or _DEFAULT_DTYPE
@@ -698,15 +775,19 @@ def _field_on_device(x, vf_dict, flags, dtype=None, device=None):
         raise ValueError(f"query points have {x.shape[1]} dimensions, the vector field has {d}")
     if d > 3 or Cc.shape[1] > 3:
         raise NotImplementedError("the HIP evaluators support up to 3 dimensions")
-    k = _make_kernels(device, dtype)
-    center = Xc.mean(0)
-    x4 = k.to_x4(x, center)
-    c4 = k.to_x4(Xc, center)
-    C3 = np.zeros((len(Xc), 3))
-    C3[:, : Cc.shape[1]] = Cc
-    Cd = torch.from_numpy(C3).to(k.device)
-    out = k.eval(x4, c4, float(vf_dict["beta"]), Cd, flags)
-    return {f: t.cpu().numpy() for f, t in out.items()}
+    k = _shared_kernels(device, dtype)
+    beta = float(vf_dict["beta"])
+
+    def launch(fl):
+        center = Xc.mean(0)
+        x4 = k.to_x4(x, center)
+        c4 = k.to_x4(Xc, center)
+        C3 = np.zeros((len(Xc), 3))
+        C3[:, : Cc.shape[1]] = Cc
+        Cd = torch.from_numpy(C3).to(k.device)
+        return k.eval(x4, c4, beta, Cd, fl)
+
+    return _fused_eval(x, ("svc", Xc, Cc, beta), flags, k, launch)
 
 
 def vector_field_function(x, vf_dict, dim=None, *, dtype=None, device=None):
@@ -923,6 +1004,20 @@ class SvcVectorField:
 
         return jac
 
+    def jacobian_with_det(self, X, method="analytical"):
+        """(Js (d, d, n), det Js (n,)) from ONE evaluator pass: what ``morphofield_jacobian`` stores in ``uns`` and ``obs``
+        (``differential_geometry.py:331-337`` loops ``np.linalg.det`` over the cells on the host; here the 3 x 3
+        determinant is the kernel's MVF_EVAL_JDET output, a cofactor expansion in the registers that hold J)."""
+        self._check_method(method)
+        X = np.asarray(X, dtype=np.float64)
+        d = X.shape[1]
+        o = self._eval(X, _lib.EVAL_JAC | (_lib.EVAL_JDET if d == 3 else 0))
+        J = o[_lib.EVAL_JAC][:d, :d, :]
+        if d == 3:
+            return J, o[_lib.EVAL_JDET]
+        # the kernel works on zero-padded 3-D points: the d x d determinant of a 1-D / 2-D field is taken on the host
+        return J, (J[0, 0] * J[1, 1] - J[0, 1] * J[1, 0] if d == 2 else J[0, 0].copy())
+
     def compute_velocity(self, X):
         return self.func(X)
 
@@ -1014,11 +1109,15 @@ def _gp_eval(X, vf_dict, flags, nonrigid_only=False, dtype=None, device=None):
         A = (sf * R - stt * np.eye(3)) / 10000.0
         b = (sf * t + mean_f - mean_t) / 10000.0
     b = b + A @ center  # the kernel sees q = xn - center
-    k = _make_kernels(device, dtype)
-    x4, c4 = k.to_x4(xn, center), k.to_x4(ind, center)
-    Cd = torch.from_numpy(np.ascontiguousarray(Coff[:, :3])).to(k.device)
-    out = k.eval(x4, c4, float(vf_dict["beta"]), Cd, flags, affine=(sf / 10000.0, sf / stt, A, b))
-    return {f: tt.cpu().numpy() for f, tt in out.items()}
+    k = _shared_kernels(device, dtype)
+    beta = float(vf_dict["beta"])
+
+    def launch(fl):
+        x4, c4 = k.to_x4(xn, center), k.to_x4(ind, center)
+        Cd = torch.from_numpy(np.ascontiguousarray(Coff[:, :3])).to(k.device)
+        return k.eval(x4, c4, beta, Cd, fl, affine=(sf / 10000.0, sf / stt, A, b))
+
+    return _fused_eval(X, ("gp", ind, Coff, beta, sf, stt, A, b, mean_t), flags, k, launch)
 
 
 def gp_velocity(X, vf_dict, nonrigid_only=False, *, dtype=None, device=None):
@@ -1131,7 +1230,7 @@ def integrate_field(vf_dict, init_states, t_end=None, interpolation_num=250, dir
     if average == "origin":
         X0 = X0.mean(0, keepdims=True)
     d = X0.shape[1]
-    k = _make_kernels(device, dtype)
+    k = _shared_kernels(device, dtype)
     if method == "gaussian_process":
         sf, stt, mean_f, mean_t = _gp_scalars(vf_dict)
         ctrl = np.asarray(vf_dict["inducing_variables"], dtype=np.float64)
@@ -1226,7 +1325,7 @@ def genesis_states(vf_dict, init_states, time_vec, substeps=64, dtype=None, devi
     d = ctrl.shape[1]
     if pts.ndim != 2 or pts.shape[1] != d or d > 3 or Cc.shape[1] != d:
         raise NotImplementedError("genesis_states needs (n, d) states and a field with Dy == D <= 3")
-    k = _make_kernels(device, dtype)
+    k = _shared_kernels(device, dtype)
     center = ctrl.mean(0)
     C3 = np.zeros((len(ctrl), 3))
     C3[:, :d] = Cc

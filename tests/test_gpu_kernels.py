@@ -609,6 +609,53 @@ def test_evaluators_large_vs_oracle(st):
     assert _relmax(div, np.trace(Jr)) < 1e-10
 
 
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-10), ("float32", 2e-4)])
+def test_jacobian_determinant_on_the_device_and_one_fused_pass(st, dtype, tol):
+    """MVF_EVAL_JDET (the `obs` slot of ``morphofield_jacobian``, ``differential_geometry.py:336``) against
+    ``np.linalg.det`` of the oracle's Jacobians; Jacobian, determinant, curl and divergence of the same points come out of
+    ONE ``eval_kernel`` launch (the later calls are device -> host copies), 70 k points so that the pinned path is taken."""
+    from spateo_amd import vectorfield as vfm
+
+    rng, X, ctrl = _cloud(6, 70_000, 400)
+    vfd = {"X_ctrl": ctrl, "C": rng.standard_normal((400, 3)), "beta": 0.004}
+    vfm.clear_eval_cache()
+    vf = st.SvcVectorField(dtype=dtype, device="cuda:0")
+    vf.vf_dict = vfd
+    k = vfm._shared_kernels("cuda:0", dtype)
+    calls, real = [], k.eval
+    k.eval = lambda *a, **kw: (calls.append(a[4]), real(*a, **kw))[1]
+    try:
+        J, det = vf.jacobian_with_det(X)
+        curl = vf.compute_curl(X=X)
+        div = st.SvcVectorField(dtype=dtype, device="cuda:0")
+        div.vf_dict = dict(vfd)
+        div = div.compute_divergence(X=X.copy())
+    finally:
+        k.eval = real
+        vfm.clear_eval_cache()
+    assert len(calls) == 1
+    Jr = np.concatenate([dgo.Jacobian_rkhs_gaussian(X[lo:lo + 10_000], vfd, vectorize=True)
+                         for lo in range(0, len(X), 10_000)], axis=2)
+    jmax = np.abs(Jr).max()
+    assert np.abs(J - Jr).max() / jmax < tol
+    assert np.abs(det - np.linalg.det(np.moveaxis(Jr, 2, 0))).max() / jmax**3 < tol
+    assert np.abs(det - np.linalg.det(np.moveaxis(J, 2, 0))).max() / jmax**3 < 1e-14   # cofactors vs LU on the SAME J
+    assert np.abs(curl[:, 1, :] - np.stack([Jr[2, 1] - Jr[1, 2], Jr[0, 2] - Jr[2, 0], Jr[1, 0] - Jr[0, 1]], 1)).max() / jmax < tol
+    assert np.abs(div - np.trace(Jr)).max() / jmax < tol
+
+
+def test_host_transfers_beyond_the_pinned_limit(st):
+    """to_host's chunked path (two 32 MB page-locked staging buffers into pageable arrays) returns the same bytes."""
+    k = _k("float64")
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    a = torch.randn(9_000_001, 2, dtype=torch.float64, device="cuda:0", generator=g)   # 144 MB > PINNED_MAX_BYTES
+    b = torch.arange(1_000_003, dtype=torch.int64, device="cuda:0")
+    ha, hb = k.to_host([a, b])
+    assert ha.shape == (9_000_001, 2) and np.array_equal(ha, a.cpu().numpy()) and np.array_equal(hb, b.cpu().numpy())
+    small = k.to_host([a[:1000]])[0]
+    assert np.array_equal(small, a[:1000].cpu().numpy())
+
+
 def test_con_k_return_d_beyond_65535_rows(st):
     """return_d=True for more rows than one mvf_con_k_d launch takes (the reference signature has no such limit)."""
     rng = np.random.default_rng(9)
@@ -715,6 +762,9 @@ def test_hull_mask_matches_delaunay_find_simplex():
         assert got.dtype == bool and got.shape == want.shape
         assert 0.2 < want.mean() < 0.8
         assert (np.abs(margin) < 1e-9 * extent).all()
+    # non-finite points are outside, as find_simplex's -1 (fmax() would silently drop the NaN half-space values)
+    bad = np.array([[np.nan, 0, 0], [0, np.inf, 0], [0, 0, -np.inf], [0.0, 0.0, 0.0]])
+    np.testing.assert_array_equal(k.hull_mask(bad, hull.equations, tol), [False, False, False, True])
 
 
 @pytest.mark.parametrize("dtype,n,m", [("float32", 5003, 2000), ("float64", 3001, 1000), ("float32", 701, 3000),

@@ -666,3 +666,69 @@ def test_cell_directions_mapping_logic_matches_the_real_function():
         st.tdr.cell_directions(A, B)
     with pytest.raises(ValueError):
         st.tdr.cell_directions(A, B, pi=g["pi"][:5])
+
+
+# ------------------------------------------------------------------------------------------------ fused evaluator pass
+def test_one_evaluator_launch_serves_the_calls_on_the_same_points(monkeypatch):
+    """``get_Jacobian()(X)`` then ``compute_curl(X=X)`` (BASELINE config 2's call shape) and the seven ``morphofield_*``
+    wrappers, each with a fresh vector-field object, are ONE evaluator launch as long as points and field are the same by
+    value; another field or other points launch again; results are those of separate launches."""
+    launches = []
+
+    class Counting(CpuKernels):
+        def eval(self, x4, ctrl4, beta, C, flags, affine=None):
+            launches.append(flags)
+            return super().eval(x4, ctrl4, beta, C, flags, affine)
+
+    monkeypatch.setattr(vfm, "_make_kernels", lambda device, dtype: Counting(device, dtype))
+    vfm.clear_eval_cache()
+    rng = np.random.default_rng(5)
+    vfd = {"X_ctrl": rng.normal(size=(40, 3)), "C": rng.normal(size=(40, 3)), "beta": 0.3, "X": None, "Y": None}
+    X = rng.normal(size=(300, 3))
+    vf = st.SvcVectorField()
+    vf.vf_dict = vfd
+    J = vf.get_Jacobian()(X)
+    curl = vf.compute_curl(X=X.copy())          # equal by value, another array object
+    vf2 = st.SvcVectorField()
+    vf2.vf_dict = dict(vfd)                      # a fresh object and a copied dict: still the same field
+    div = vf2.compute_divergence(X=X)
+    _, acc = vf2.compute_acceleration(X=X)
+    Jd, det = vf2.jacobian_with_det(X)
+    assert len(launches) == 1 and launches[0] == vfm._EVAL_ALL
+    np.testing.assert_array_equal(Jd, J)
+    assert not np.shares_memory(Jd, J)
+    np.testing.assert_allclose(det, np.linalg.det(np.moveaxis(J, 2, 0)), rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(curl[:, 0, :], np.stack([J[2, 1] - J[1, 2], J[0, 2] - J[2, 0], J[1, 0] - J[0, 1]], 1))
+    np.testing.assert_allclose(div, np.trace(J))
+    # the host arrays handed out are the caller's own: writing into one does not leak into the next call
+    keep = J.copy()
+    J[:] = 0.0
+    np.testing.assert_array_equal(vf.get_Jacobian()(X), keep)
+    assert len(launches) == 1
+    # other points, or the same points on a changed field: a new launch each
+    vf.compute_divergence(X=X + 1e-9)
+    assert len(launches) == 2
+    vfd2 = dict(vfd, C=vfd["C"] * (1 + 1e-12))
+    vf3 = st.SvcVectorField()
+    vf3.vf_dict = vfd2
+    d3 = vf3.compute_divergence(X=X + 1e-9)
+    assert len(launches) == 3 and not np.array_equal(d3, div)
+    # beyond the prefetch cap only what is asked for is computed and kept; a later quantity launches for itself only
+    monkeypatch.setattr(vfm, "_EVAL_PREFETCH_CAP", 0)
+    vfm.clear_eval_cache()
+    vf3.compute_divergence(X=X)
+    vf3.compute_divergence(X=X)
+    vf3.compute_curl(X=X)
+    assert launches[3:] == [vfm._lib.EVAL_DIV, vfm._lib.EVAL_CURL]
+    vfm.clear_eval_cache()
+
+
+def test_jacobian_with_det_in_two_dimensions(cpu_kernels):
+    rng = np.random.default_rng(6)
+    vfd = {"X_ctrl": rng.normal(size=(30, 2)), "C": rng.normal(size=(30, 2)), "beta": 0.4}
+    vf = st.SvcVectorField()
+    vf.vf_dict = vfd
+    X = rng.normal(size=(50, 2))
+    J, det = vf.jacobian_with_det(X)
+    assert J.shape == (2, 2, 50)
+    np.testing.assert_allclose(det, np.linalg.det(np.moveaxis(J, 2, 0)), rtol=1e-12, atol=1e-15)

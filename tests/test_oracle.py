@@ -273,3 +273,52 @@ def test_m_step_arithmetic_pinned_by_the_reference_alignment_code(golden_em):
             C = scipy.linalg.pinv(lhs).dot(rhs)
         V = U.dot(C)
         assert _field_rel(V, g[f"{tag}_VnA"]) < vtol, (tag, _field_rel(V, g[f"{tag}_VnA"]))
+
+
+# ------------------------------------------------------------------------------------------------- streamed oracle
+def test_streamed_oracle_is_the_oracle_with_the_sums_over_cells_in_pieces():
+    """oracle/streamed_oracle.py (U generated chunk by chunk - what the 2 M / 8 M-cell fixtures are made with) against
+    sparsevfc_oracle.SparseVFC: BIT-identical to the oracle whose ``gram_dot`` sums the same pieces in the same order
+    (tests/_floors.py's `sumorder` form), equal to the one-call oracle to the rounding of a well-conditioned case, and
+    the threaded con_K equals ``con_K`` bit for bit."""
+    import _floors as F
+    from oracle import streamed_oracle as so
+    from spateo_amd._synthetic import make_config
+
+    X, V, _ = make_config("C3", N=7001)
+    rng = np.random.default_rng(0)
+    ctrl = X[rng.choice(len(X), 97, replace=False)]
+    np.testing.assert_array_equal(so.streamed_con_K(X, ctrl, 1e-6), svo.con_K(X, ctrl, 1e-6))
+    for lam, steps in ((0.02, 5), (3.0, 4)):
+        kw = dict(M=120, lambda_=lam, MaxIter=steps, ecr=0.0, seed=0)
+        a = F.oracle_fit(X, V, None, variant="sumorder", lstsq_method="scipy", **kw)       # 7 pieces
+        b = so.SparseVFC_streamed(X, V, chunks=7, **kw)
+        for q in ("V", "P", "C", "E_traj", "tecr_traj", "ctrl_idx"):
+            np.testing.assert_array_equal(a[q], b[q], err_msg=q)
+        assert a["sigma2"] == b["sigma2"] and a["iteration"] == b["iteration"] == steps - 1
+        c = svo.SparseVFC(X, V, None, lstsq_method="scipy", **kw)
+        assert _field_rel(b["V"], c["V"]) < (1e-9 if lam == 3.0 else 1e-4)
+        np.testing.assert_allclose(b["sigma2_traj"][-1], c["sigma2"], rtol=1e-9 if lam == 3.0 else 1e-5)
+    # the early-stopping rule is the oracle's too
+    kw = dict(M=60, lambda_=3.0, seed=0)
+    a, b = svo.SparseVFC(X, V, None, lstsq_method="scipy", **kw), so.SparseVFC_streamed(X, V, chunks=1, **kw)
+    assert a["iteration"] == b["iteration"] and a["iteration"] < 400
+    np.testing.assert_allclose(b["V"], a["V"], rtol=0, atol=1e-9 * np.abs(a["V"]).max())
+
+
+def test_stream_fixture_writer_plumbing():
+    """tests/golden/make_stream_oracle.py on its seconds-sized case: the stored fields and floors are self-consistent."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_stream_oracle.py")
+    spec = importlib.util.spec_from_file_location("make_stream_oracle", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.run("tiny")
+    c = mod.CASES["tiny"]
+    assert out["V"].shape == (c["n"] // c["stride"], 3) and out["P"].shape == (c["n"] // c["stride"], 1)
+    assert len(out["E_traj"]) == len(out["sigma2_traj"]) == c["steps"] and out["iteration"] == c["steps"] - 1
+    assert out["sigma2"] == out["sigma2_traj"][-1]
+    for q in ("V", "sigma2", "P", "E"):
+        assert out[f"floor_{q}"] == max(out[f"var_eigh_{q}"], out[f"var_sumorder_{q}"]) and 0 < out[f"floor_{q}"] < 1e-3
