@@ -15,7 +15,7 @@ mode - the mode the 1e-5 parity clause is about - with its own roofline; N = 1 o
 HBM-write bandwidth), ``cpu_baseline`` (the float64 NumPy oracle on the host cores at N_cpu = 200 k and 100 k cells; its
 ``value`` is the rate its fitted t(N) = a N + b gives at the bench's own cell count; N = 1 only) and ``parity`` (the GPU
 engine, float64 and float32, on exactly the 100 k-cell arrays of that CPU sample against the oracle's field after the
-same EM iterations, with the oracle's own lstsq-vs-eigh noise floor beside it; N = 1 only).
+same 10 EM iterations, with the oracle's own lstsq-vs-eigh noise floor beside it; N = 1 only).
 """
 from __future__ import annotations
 
@@ -63,6 +63,9 @@ def _eigh_solver(lhs, rhs, method=None):
     w, q = np.linalg.eigh((lhs + lhs.T) / 2)
     keep = np.abs(w) > np.finfo(float).eps * np.abs(w).max()
     return (q[:, keep] / w[keep]) @ (q[:, keep].T @ rhs)
+
+
+PARITY_STEPS = 10  # EM iterations of the parity leg (>= 10; the timing legs keep their 3)
 
 
 def _cpu_steps(M, lambda_, n_cpu, steps, keep=False):
@@ -121,7 +124,8 @@ def cpu_baseline(M, lambda_, n_cpu, n_target, steps=3):
     except Exception:
         threads = os.cpu_count() or 1
     (N, Mc, t_step, t_conk, ubytes), _ = _cpu_steps(M, lambda_, n_cpu, steps)
-    (Nh, _, t_half, _, _), sample = _cpu_steps(M, lambda_, n_cpu // 2, steps, keep=True)
+    # the half-size run doubles as the oracle side of the parity leg: PARITY_STEPS iterations (median step time of all)
+    (Nh, _, t_half, _, _), sample = _cpu_steps(M, lambda_, n_cpu // 2, max(steps, PARITY_STEPS), keep=True)
     a = (t_step - t_half) / (N - Nh)  # seconds per cell (the part that scales with N)
     b = t_step - a * N                # the N-independent part (lstsq of the M x M system)
     t_target = a * n_target + b if a > 0 else None
@@ -132,7 +136,8 @@ def cpu_baseline(M, lambda_, n_cpu, n_target, steps=3):
         "host_cpus": os.cpu_count(),
         "kind": "port",
         "sample": f"float64 NumPy oracle (cdist+exp con_K, U.T*repmat(P) temporary, scipy.linalg.lstsq), C4 generator at "
-                  f"N_cpu={N} and {Nh} cells, M={Mc}, median of {steps} EM steps each ({t_step:.2f} / {t_half:.2f} s/step); "
+                  f"N_cpu={N} and {Nh} cells, M={Mc}, median of {steps} / {max(steps, PARITY_STEPS)} EM steps "
+                  f"({t_step:.2f} / {t_half:.2f} s/step); "
                   f"value = {n_target} cells / t({n_target}) of the fit t(N) = a N + b through the two sizes (the lstsq "
                   f"constant b amortised as it would be at the bench's size); con_K {t_conk:.2f} s = "
                   f"{ubytes / t_conk / 1e9:.2f} GB/s of output",
@@ -380,11 +385,16 @@ def main():
         sv["bound"] = "latency (dependent launches / rotation chains), not MFMA"
         if distributed:
             # what the first multi-GPU run needs to explain itself: per-rank Gram time and the collectives
-            big = [(e0.elapsed_time(e1), nb) for e0, e1, nb in eng.comm_events if nb > 1024]
+            # per step: tri(G) (the big one, issued asynchronously: its interval also covers the rhs / quadform kernels and
+            # the [R | stats] all-reduce it overlaps), [R | stats], and the two scalar-sized ones (E-step MIN, step end)
+            nb_max = max(nb for _, _, nb in eng.comm_events)
+            big = [(e0.elapsed_time(e1), nb) for e0, e1, nb in eng.comm_events if nb == nb_max]
+            mid = [e0.elapsed_time(e1) for e0, e1, nb in eng.comm_events if 1024 < nb < nb_max]
             small = [e0.elapsed_time(e1) for e0, e1, nb in eng.comm_events if nb <= 1024]
             mine = {"rank": rank, "cells": n_loc, "gram_ms": gram_avg_ms, "solve_ms": float(np.mean(solve_ms)),
                     "allreduce_ms": float(np.mean([t for t, _ in big])) if big else None,
                     "allreduce_bytes": big[0][1] if big else 0,
+                    "rhs_stats_allreduce_ms": float(np.mean(mid)) if mid else None,
                     "scalar_allreduce_ms": float(np.mean(small)) if small else None}
             # every rank also prints its own record on stderr BEFORE the gather: a run that dies in a collective still
             # leaves the per-rank figures in the log
@@ -398,8 +408,9 @@ def main():
             rec["per_rank"] = allr
             rec["comm"] = {"collectives_per_step": len(eng.comm_events) / steps, "allreduce_bytes": mine["allreduce_bytes"],
                            "allreduce_ms_max": max((r_["allreduce_ms"] or 0.0) for r_ in allr),
-                           "note": "event time on the compute stream around each all_reduce: includes waiting for the "
-                                   "slowest rank to arrive"}
+                           "note": "event time on the compute stream from issuing a collective to the stream having waited "
+                                   "for it: includes waiting for the slowest rank to arrive; the big one is asynchronous, "
+                                   "its interval spans the rhs / quadform kernels and the [R | stats] all-reduce"}
         kern.drop_ublk()
         del eng, kern
         torch.cuda.empty_cache()
@@ -444,12 +455,16 @@ def main():
         },
         "roofline": main_rec["roofline"],
         "solve": main_rec["solve"],
+        # developer knobs of libmvf / the host that change which kernel variant runs: none set = defaults
+        "env": {k_: v_ for k_, v_ in sorted(os.environ.items()) if k_.startswith("MVF_")},
+        "developer_options": __import__("spateo_amd")._lib.debug_options(),   # mvf_debug_option values != default
     }
     if distributed:
         out["per_rank"], out["comm"] = main_rec["per_rank"], main_rec["comm"]
-        out["config"]["parallelism"] = (f"cells block-sharded over {world} GPUs; per EM step one all-reduce of "
-                                        f"[tri(G) | R | stats] ({main_rec['comm']['allreduce_bytes'] / 1e6:.1f} MB) + one "
-                                        f"scalar all-reduce; redundant coefficient solve on every rank")
+        out["config"]["parallelism"] = (f"cells block-sharded over {world} GPUs; per EM step the all-reduce of tri(G) "
+                                        f"({main_rec['comm']['allreduce_bytes'] / 1e6:.1f} MB, overlapped with the rhs "
+                                        f"kernels), [R | stats], and two scalar-sized ones (E-step MIN; sum P r + solver "
+                                        f"agreement); redundant coefficient solve on every rank")
 
     # ---------------------------------------------------------------- the same workload in float64 mode (N = 1)
     if world == 1 and args.dtype == "float32" and not args.no_f64:

@@ -51,7 +51,15 @@ enum {
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
 const char* mvf_last_error(void);
-int mvf_version(void);                 /* ABI version, currently 2 */
+int mvf_version(void);                 /* ABI version, currently 3 */
+/* Developer options, process-wide: which kernel variant / launch plan is taken in A/B measurements and in the tests that
+ * compare the variants bit for bit.  The library NEVER reads the environment (rounds 1 - 3 had getenv knobs in launch
+ * paths); nothing but this call changes its behaviour.  value 0 = default.  Names: "conk_form" (1 rows, 2 flat, 3 2d),
+ * "conk_rows" (rows per workgroup of the rows form), "slice_len" (cells per Gram slice), "solve_small_off" (1: the blocked
+ * multi-launch Cholesky at every m), "jac_gram_wgs" (workgroups per Jacobi Gram launch), "lr_timing" (1: phase times of
+ * mvf_solve_minnorm_lr on stderr).  Unknown name: non-zero return.  mvf_debug_option_get returns -1 for an unknown name. */
+int mvf_debug_option(const char* name, long long value);
+long long mvf_debug_option_get(const char* name);
 int mvf_device_count(int* count);      /* number of visible HIP devices (0 without a GPU) */
 
 /* ---- preprocessing: sorted unique rows -------------------------------------------------------------------------------

@@ -209,8 +209,10 @@ constexpr size_t CONK_FLAT_LDS_MAX = 80 * 1024;
 template <typename T, int VEC>
 static int launch_conk(const T* x, int64_t n, const T* y, int64_t m, int d, double beta, T* K, hipStream_t st) {
     const T s = (T)std::sqrt(beta * LOG2E);
-    // developer knob: "2d" = the row-block form, "flat" = the flat-chunk form, "rows" = the row-contiguous form
-    const char* knob = std::getenv("MVF_CONK");
+    // developer option conk_form: 1 = the row-contiguous form, 2 = the flat-chunk form, 3 = the 2-D row-block form
+    static const char* const forms[4] = {nullptr, "rows", "flat", "2d"};
+    const long long fk = debug_opt(DBG_CONK_FORM);
+    const char* knob = (fk >= 1 && fk <= 3) ? forms[fk] : nullptr;
     // Default: the row-contiguous form whenever a burst-aligned span of RS <= 4 rows fits its register budget (8 passes),
     // else the flat form (float32) / the 2-D form (float64: its flat form is VALU-bound); profiles/r03_conk_ab*.json.
     int rs = 1;
@@ -220,12 +222,12 @@ static int launch_conk(const T* x, int64_t n, const T* y, int64_t m, int d, doub
     const std::string form = knob ? std::string(knob) : std::string(rows_fit ? "rows" : (sizeof(T) == 4 ? "flat" : "2d"));
     const bool legacy = form != "flat";
     if (form == "rows" && rows_fit) {
-        const char* rk = std::getenv("MVF_CONK_ROWS");  // developer knob: rows per workgroup
+        const long long rk = debug_opt(DBG_CONK_ROWS);  // developer option: rows per workgroup
         // ~128 KB of contiguous output per workgroup, at most 16 rows (measured 8 / 16 / 32 / 64 rows per workgroup: within
         // 3 % of each other, profiles/r03_conk_ab_rowspans.json)
         const int64_t row_bytes = m * (int64_t)sizeof(T);
         const int rows_auto = (int)std::min<int64_t>(16, std::max<int64_t>(rs, (131072 / row_bytes) / rs * rs));
-        const int rows_pb = rk ? std::max(1, atoi(rk)) : rows_auto;
+        const int rows_pb = rk > 0 ? (int)rk : rows_auto;
         const int spans_pb = std::max(1, rows_pb / rs);
         const dim3 grid((unsigned)cdiv(cdiv(n, rs), spans_pb));
         // (32 bytes per lane and pass - a 2 x VEC vector store - was measured too: 1.9 - 2.3 TB/s, the compiler does not emit
@@ -263,12 +265,7 @@ static int launch_conk(const T* x, int64_t n, const T* y, int64_t m, int d, doub
     if (!legacy && d == 3 && m % VEC == 0 && lds <= CONK_FLAT_LDS_MAX && m >= 64) {
         constexpr int CH = 256 * VEC * U;
         const int64_t nchunks = cdiv(n * m, CH);
-        int dev = 0, cus = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-            prop.multiProcessorCount > 0)
-            cus = prop.multiProcessorCount;
-        (void)hipGetLastError();
+        const int cus = device_cu_count();  // cached per device: hipGetDeviceProperties is a slow host call
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
         const int64_t grid = std::min<int64_t>(nchunks, (int64_t)cus * per_cu);
         auto kern = conk_flat_kernel<T, VEC, U>;

@@ -40,26 +40,7 @@ constexpr int RHS_CPT = 2;                  // control points per lane in the rh
 constexpr int RHS_COLS = 256 * RHS_CPT;     // control points per rhs workgroup
 
 // Resident workgroup slots of the Gram kernels: 2 workgroups (8 waves) per CU (register-limited), 256 CUs on MI355X.
-// Looked up per CURRENT device (the host binding makes the launch stream's device current) and remembered per device
-// index; the idempotent lazy write needs no lock.
-static int gram_slots() {
-    constexpr int MAXDEV = 64;
-    static int slots[MAXDEV] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) {
-        (void)hipGetLastError();
-        return 2 * 256;
-    }
-    if (slots[dev] == 0) {
-        int cus = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            cus = prop.multiProcessorCount;
-        (void)hipGetLastError();
-        slots[dev] = 2 * cus;
-    }
-    return slots[dev];
-}
+static int gram_slots() { return 2 * device_cu_count(); }
 
 static GramPlan make_plan(int64_t n, int64_t m, mvf_dtype dtype) {
     GramPlan p;
@@ -117,7 +98,8 @@ static GramPlan make_plan(int64_t n, int64_t m, mvf_dtype dtype) {
         best_s = ns;
     }
     int64_t sl = cdiv(cdiv(n, best_s), GCHUNK) * GCHUNK;
-    if (const char* e = getenv("MVF_SLICE_LEN")) sl = std::max<int64_t>(GCHUNK, atoll(e) / GCHUNK * GCHUNK);  // probes
+    const int64_t slice_knob = debug_opt(DBG_SLICE_LEN);  // developer option (probes, tests of the multi-phase plan)
+    if (slice_knob > 0) sl = std::max<int64_t>(GCHUNK, slice_knob / GCHUNK * GCHUNK);
     p.slice_len = sl;
     p.nslices = std::max<int64_t>(1, cdiv(n, sl));
     p.nphases = cdiv(p.nslices, fit);

@@ -1,5 +1,7 @@
 // Library-level entry points: error channel, version, device probe.
 #include "mvf_common.h"
+#include <atomic>
+#include <cstring>
 
 namespace mvf {
 
@@ -16,11 +18,53 @@ int set_error(const char* fmt, ...) {
     return 1;
 }
 
+static std::atomic<long long> g_debug[DBG_COUNT];
+static const char* const g_debug_names[DBG_COUNT] = {"conk_form", "conk_rows", "slice_len", "solve_small_off", "jac_gram_wgs",
+                                                     "lr_timing"};
+long long debug_opt(DebugOpt which) { return g_debug[which].load(std::memory_order_relaxed); }
+
+// Looked up per CURRENT device (the host binding makes the launch stream's device current) and remembered per device
+// index; the idempotent lazy write needs no lock.
+int device_cu_count() {
+    constexpr int MAXDEV = 64;
+    static int cus[MAXDEV] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) {
+        (void)hipGetLastError();
+        return 256;
+    }
+    if (cus[dev] == 0) {
+        int c = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) c = prop.multiProcessorCount;
+        (void)hipGetLastError();
+        cus[dev] = c;
+    }
+    return cus[dev];
+}
+
 }  // namespace mvf
 
 extern "C" const char* mvf_last_error(void) { return mvf::err_buf(); }
 
-extern "C" int mvf_version(void) { return 2; }
+extern "C" int mvf_version(void) { return 3; }
+
+extern "C" int mvf_debug_option(const char* name, long long value) {
+    if (!name) return mvf::set_error("mvf_debug_option: null name");
+    for (int i = 0; i < mvf::DBG_COUNT; ++i)
+        if (std::strcmp(name, mvf::g_debug_names[i]) == 0) {
+            mvf::g_debug[i].store(value, std::memory_order_relaxed);
+            return 0;
+        }
+    return mvf::set_error("mvf_debug_option: unknown option '%s'", name);
+}
+
+extern "C" long long mvf_debug_option_get(const char* name) {
+    if (name)
+        for (int i = 0; i < mvf::DBG_COUNT; ++i)
+            if (std::strcmp(name, mvf::g_debug_names[i]) == 0) return mvf::g_debug[i].load(std::memory_order_relaxed);
+    return -1;
+}
 
 extern "C" int mvf_device_count(int* count) {
     if (!count) return mvf::set_error("mvf_device_count: null pointer");

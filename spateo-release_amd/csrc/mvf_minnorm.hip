@@ -1244,10 +1244,8 @@ static JacPlan jac_plan(int64_t m, int nrhs) {
     p.nb = (int)(p.mp / JB);
     p.npairs = p.nb / 2;
     const int nk = (int)(p.mp / 64);
-    static const int target = [] {
-        const char* e = std::getenv("MVF_JAC_GRAM_WGS");  // developer knob: workgroups per Gram launch (default 512)
-        return e ? std::max(64, atoi(e)) : 512;
-    }();
+    const long long tk = debug_opt(DBG_JAC_GRAM_WGS);  // developer option: workgroups per Gram launch (default 512)
+    const int target = tk > 0 ? (int)std::max<long long>(64, tk) : 512;
     int want = std::max(1, target / p.npairs);
     p.nsplit = std::min(nk, want);
     p.kchunks = (int)cdiv(nk, p.nsplit);
@@ -1460,7 +1458,7 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
     double* scal = (double*)(ws + p.off_scal);
     const int64_t mp = p.mp;
     PcholState hs;
-    static const bool timing = std::getenv("MVF_LR_TIMING") != nullptr;  // developer knob: phase times on stderr
+    const bool timing = debug_opt(DBG_LR_TIMING) != 0;  // developer option: phase times on stderr
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     if (timing && !reuse) {
         for (auto& e : ev) MVF_CHECK_HIP(hipEventCreate(&e));
@@ -1579,10 +1577,8 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
 
     // 2. one-sided block Jacobi on the r rows of Y
     const int nb = (int)(rp / JB), npairs = nb / 2, nk = (int)(mp / 64);
-    static const int gram_wgs = [] {
-        const char* e = std::getenv("MVF_JAC_GRAM_WGS");  // developer knob: workgroups per Gram launch
-        return e ? std::min(LR_GRAM_WGS, std::max(64, atoi(e))) : LR_GRAM_WGS_DEFAULT;
-    }();
+    const long long gk = debug_opt(DBG_JAC_GRAM_WGS);  // developer option: workgroups per Gram launch
+    const int gram_wgs = gk > 0 ? (int)std::min<long long>(LR_GRAM_WGS, std::max<long long>(64, gk)) : LR_GRAM_WGS_DEFAULT;
     int nsplit = std::min(nk, std::max(1, gram_wgs / npairs));
     const int kchunks = (int)cdiv(nk, nsplit);
     nsplit = (int)cdiv(nk, kchunks);

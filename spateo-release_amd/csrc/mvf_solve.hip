@@ -615,16 +615,20 @@ extern "C" int mvf_solve(const double* G, const double* K, double lambda_sigma2,
     MVF_REQUIRE(std::isfinite(lambda_sigma2) && lambda_sigma2 >= 0.0 && jitter >= 0.0, "mvf_solve: bad regularisation");
     const size_t need = mvf_solve_workspace_bytes(m, nrhs);
     MVF_REQUIRE(workspace && workspace_bytes >= need, "mvf_solve: workspace too small (%zu < %zu)", workspace_bytes, need);
-    const char* knob = std::getenv("MVF_SOLVE_SMALL");  // developer knob: "0" = the blocked multi-launch path at every m
-    if (m <= SM && !(knob && knob[0] == '0')) {
+    const bool small_off = debug_opt(DBG_SOLVE_SMALL_OFF) != 0;  // developer option: the blocked multi-launch path at every m
+    if (m <= SM && !small_off) {
         auto kern = solve_small_kernel;
         // (per call: the attribute belongs to the current device's copy of the kernel; the call costs ~1 us)
-        MVF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)SOLVE_SMALL_LDS));
-        hipLaunchKernelGGL(kern, dim3(1), dim3(1024), SOLVE_SMALL_LDS, st, G, K, lambda_sigma2, jitter, R, (int)m, nrhs, C,
-                           info, pivots);
-        MVF_LAUNCH_CHECK();
-        return 0;
+        // A device that refuses 135 KB of dynamic LDS (a part with 64 KB of LDS, a restricted carve-out) takes the blocked
+        // path below, which handles every m.
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)SOLVE_SMALL_LDS) == hipSuccess) {
+            hipLaunchKernelGGL(kern, dim3(1), dim3(1024), SOLVE_SMALL_LDS, st, G, K, lambda_sigma2, jitter, R, (int)m, nrhs,
+                               C, info, pivots);
+            MVF_LAUNCH_CHECK();
+            return 0;
+        }
+        (void)hipGetLastError();
     }
     CholPlan pl;
     if (int rc = chol_factor(st, G, K, lambda_sigma2, jitter, R, m, nrhs, workspace, &pl, info)) return rc;

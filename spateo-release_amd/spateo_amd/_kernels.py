@@ -245,8 +245,10 @@ class HipKernels:
         self._ublk_key = None
 
     @_on_device
-    def gram(self, x4, P, y4, ctrl4, beta, G, R, rhs_only=False):
-        """G = U^T P U (m x m), R = U^T P Y (m x 3).  rhs_only: only R for this y4 (G unchanged) - for Y wider than 3."""
+    def gram(self, x4, P, y4, ctrl4, beta, G, R, rhs_only=False, tiles_only=False):
+        """G = U^T P U (m x m), R = U^T P Y (m x 3).  rhs_only: only R for this y4 (G unchanged) - for Y wider than 3,
+        and the second half of a multi-rank step; tiles_only: only G (tile stage + its reduction) - the first half of a
+        multi-rank step, whose all-reduce of G then overlaps the rhs kernels."""
         n, m = x4.shape[0], ctrl4.shape[0]
         need = self.lib.mvf_gram_workspace_bytes(n, m, self.cdtype)
         if self._gram_ws is None or self._gram_ws.numel() < need:
@@ -265,15 +267,16 @@ class HipKernels:
         if rhs_only:
             run(_lib.GRAM_RHS | _lib.GRAM_REDUCE_RHS)
             return
+        rest = _lib.GRAM_REDUCE if tiles_only else _lib.GRAM_RHS | _lib.GRAM_REDUCE | _lib.GRAM_REDUCE_RHS
         if self.gram_events is None:
-            run(_lib.GRAM_TILES | _lib.GRAM_RHS | _lib.GRAM_REDUCE | _lib.GRAM_REDUCE_RHS)
+            run(_lib.GRAM_TILES | rest)
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         run(_lib.GRAM_TILES)
         e1.record()
         self.gram_events.append((e0, e1))
-        run(_lib.GRAM_RHS | _lib.GRAM_REDUCE | _lib.GRAM_REDUCE_RHS)
+        run(rest)
 
     @_on_device
     def solve(self, G, K, lambda_sigma2, jitter, R, C_out, info, pivots=None):

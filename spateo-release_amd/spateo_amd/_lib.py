@@ -9,8 +9,20 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MVF_LIB_PATH: developer override for A/B runs of two builds of the library (never set in production)
-LIB_PATH = os.environ.get("MVF_LIB_PATH") or os.path.join(_HERE, "lib", "libmvf.so")
+# Developer overrides are honoured ONLY under the explicit gate MVF_DEV_KNOBS=1 (and announced on stderr): MVF_LIB_PATH
+# (A/B runs of two builds of the library) and the legacy MVF_* kernel knobs, which are translated into mvf_debug_option
+# calls at load time.  Without the gate the environment changes nothing.
+DEV_KNOBS = os.environ.get("MVF_DEV_KNOBS") == "1"
+LIB_PATH = (DEV_KNOBS and os.environ.get("MVF_LIB_PATH")) or os.path.join(_HERE, "lib", "libmvf.so")
+DEBUG_OPTIONS = ("conk_form", "conk_rows", "slice_len", "solve_small_off", "jac_gram_wgs", "lr_timing")
+_LEGACY_ENV = {  # environment name -> (option, value parser)
+    "MVF_CONK": ("conk_form", lambda v: {"rows": 1, "flat": 2, "2d": 3}[v]),
+    "MVF_CONK_ROWS": ("conk_rows", int),
+    "MVF_SLICE_LEN": ("slice_len", int),
+    "MVF_SOLVE_SMALL": ("solve_small_off", lambda v: 1 if v.startswith("0") else 0),
+    "MVF_JAC_GRAM_WGS": ("jac_gram_wgs", int),
+    "MVF_LR_TIMING": ("lr_timing", lambda v: 1),
+}
 
 MVF_F32, MVF_F64 = 0, 1
 MVF_ESTEP_MIN_DOUBLES = 4098
@@ -24,6 +36,8 @@ _p, _i64, _i, _d, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_size_t
 SIGNATURES = {
     "mvf_last_error": (C.c_char_p, []),
     "mvf_version": (_i, []),
+    "mvf_debug_option": (_i, [C.c_char_p, C.c_longlong]),
+    "mvf_debug_option_get": (C.c_longlong, [C.c_char_p]),
     "mvf_device_count": (_i, [C.POINTER(C.c_int)]),
     "mvf_unique_rows_workspace_bytes": (_sz, [_i64, _i]),
     "mvf_unique_rows": (_i, [_p, _i64, _i, _p, _p, _p, _p, _sz, _p]),
@@ -82,7 +96,31 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    if DEV_KNOBS:
+        import sys
+
+        applied = {}
+        for env, (opt, parse) in _LEGACY_ENV.items():
+            if env in os.environ:
+                applied[opt] = int(parse(os.environ[env]))
+                check(lib.mvf_debug_option(opt.encode(), applied[opt]), "mvf_debug_option")
+        print(f"[spateo_amd] MVF_DEV_KNOBS=1: library {LIB_PATH}, developer options {applied}", file=sys.stderr, flush=True)
     return lib
+
+
+def debug_option(name, value):
+    """Set a developer option of the library (mvf.h: mvf_debug_option); returns the previous value."""
+    lib = load()
+    old = int(lib.mvf_debug_option_get(name.encode()))
+    check(lib.mvf_debug_option(name.encode(), int(value)), "mvf_debug_option")
+    return old
+
+
+def debug_options():
+    """{name: value} of the developer options that are not at their default (0)."""
+    lib = load()
+    vals = {n: int(lib.mvf_debug_option_get(n.encode())) for n in DEBUG_OPTIONS}
+    return {n: v for n, v in vals.items() if v != 0}
 
 
 def check(rc, what=""):

@@ -41,6 +41,9 @@ __all__ = [
 ]
 
 _DEFAULT_DTYPE = "float64"
+# developer override of the minimum-norm solver choice ("lowrank" | "full"; None = by M): set by tests and probes, never by
+# the environment
+MINNORM_METHOD = None
 
 
 def _make_kernels(device, dtype):
@@ -345,7 +348,9 @@ class SparseVFCEngine:
         self.C = [k.zeros(M, 3, dtype=f64) for _ in range(ng)]
         self.C_new = [k.zeros(M, 3, dtype=f64) for _ in range(ng)]
         self.quad = k.zeros(ng, dtype=f64)
-        self.spr = k.zeros(1, dtype=f64)
+        # the step's LAST collective: [sum P r | failed | solver signature (6) | its squares (6)], summed over the ranks
+        self.fin = k.zeros(14, dtype=f64)
+        self.spr = self.fin[:1]
         self.info = k.zeros(1, dtype=torch.int32)
         self.P = torch.ones(self.n_local, dtype=k.tdtype, device=k.device)
         self.V4 = [k.zeros(self.n_local, 4) for _ in range(ng)]
@@ -380,7 +385,7 @@ class SparseVFCEngine:
         # measured per solve in the EM's steady state (ms, lowrank / full): M = 500: 8.7 / 3.6, 1000: 17.3 / 18.4,
         # 1500: 20.9 / 33, 2000: 21.6 / 54, 3000: 23.6 / 113 - the full-width warm start wins while the factor keeps
         # nearly every column
-        self.mn_method = os.environ.get("MVF_MINNORM", "lowrank" if self.M >= 1024 else "full")
+        self.mn_method = MINNORM_METHOD or ("lowrank" if self.M >= 1024 else "full")
         self.rank_hint = 0
         # lstsq_method="cholesky" (extension, not a reference mode): jitter-escalated Cholesky, the round-1 solver
         self.jitter = 0.0
@@ -392,19 +397,34 @@ class SparseVFCEngine:
         self.iteration = 0
 
     # ------------------------------------------------------------------ collectives
-    def _all_reduce(self, t, op="sum"):
-        if self.world > 1:
-            import torch.distributed as dist
+    def _all_reduce(self, t, op="sum", wait=True):
+        """All-reduce `t` in place over the ranks.  wait=False: returns a handle for `_wait` - the collective runs on the
+        backend's own stream (RCCL) / thread (gloo) while this rank keeps enqueuing kernels that do not touch `t`."""
+        if self.world == 1:
+            return None
+        import torch.distributed as dist
 
-            ev = None
-            if self.comm_events is not None:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()
-            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MIN, group=self.group)
-            if ev is not None:
-                ev[1].record()
-                self.comm_events.append(ev + (t.numel() * t.element_size(),))
-        return t
+        ev = None
+        if self.comm_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        work = dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MIN, group=self.group,
+                               async_op=not wait)
+        handle = (work, ev, t.numel() * t.element_size())
+        if wait:
+            self._wait((None,) + handle[1:])
+            return None
+        return handle
+
+    def _wait(self, handle):
+        if handle is None:
+            return
+        work, ev, nbytes = handle
+        if work is not None:
+            work.wait()  # RCCL: the current stream waits for the collective; gloo: the host does
+        if ev is not None:
+            ev[1].record()
+            self.comm_events.append(ev + (nbytes,))
 
     # ------------------------------------------------------------------ EM
     def init_state(self, gamma=0.9):
@@ -437,11 +457,13 @@ class SparseVFCEngine:
     def em_step(self, *, a=5.0, lambda_=3.0, minP=1e-5, theta=0.75):
         """One EM iteration (Appendix A step 5 a-e).  Returns (E, tecr).
 
-        Collectives per step (multi-rank): the 8-byte MIN of the E-step's global min-non-zero rule, THE all-reduce of the
-        sufficient statistics [tri(G) | R | stats], the 112-byte agreement check of the solver decisions (_agree) and the
-        8-byte sum P r; only the agreement check is followed by a host read of its own.  Host round trips: one after the solve (its status / pivots, the statistics, the energy - every
-        control-flow decision is taken from all-reduced or replicated deterministic values, so all ranks decide alike)
-        and one for sigma^2; the minimum-norm solve adds its own (one per Jacobi sweep)."""
+        Collectives per step (multi-rank), four: the 8-byte MIN of the E-step's global min-non-zero rule; THE all-reduce of
+        the packed upper triangle of G, issued the moment this rank's G is final and overlapped with the rhs / quadform
+        kernels; the small [R | stats] all-reduce behind them; and one 14-double SUM at the end of the step that carries
+        sum P r together with every rank's failure flag and solver signature (`_finish_step`).  Host round trips: one after
+        the solve (its status / pivots, the statistics, the energy - every control-flow decision is taken from
+        all-reduced or replicated deterministic values, so all ranks decide alike) and one for sigma^2 + the agreement
+        check; the minimum-norm solve adds its own (one per Jacobi sweep)."""
         k = self.k
         # ---- E-step: dynamo's `t1[t1 == 0] = min(t1[t1 != 0])` needs the GLOBAL min-non-zero t1; phase 1 leaves it in
         # device memory, phase 2 reads it from there
@@ -450,29 +472,38 @@ class SparseVFCEngine:
         self._all_reduce(fill, "min")
         self.st.zero_()
         k.estep_p(self.r, self.sigma2, self.gamma, a, self.Dy, minP, theta, fill, self.P, self.st)
-        # ---- M-step assembly (MFMA Gram + rhs), energy regulariser with the OLD coefficients, the collective
-        k.gram(self.x4, self.P, self.y4[0], self.ctrl4, self.beta, self.G, self.R[0])
+        # ---- M-step assembly (MFMA Gram + rhs), energy regulariser with the OLD coefficients, the collectives
+        if self.world == 1:
+            k.gram(self.x4, self.P, self.y4[0], self.ctrl4, self.beta, self.G, self.R[0])
+        else:
+            # G first: THE all-reduce of the step (packed upper triangle, 36 MB at M = 3000) starts the moment this rank's
+            # G is final and runs while the rhs / quadform kernels below execute; their small results [R | stats] follow
+            k.gram(self.x4, self.P, None, self.ctrl4, self.beta, self.G, None, tiles_only=True)
+            k.sym_pack(self.G, self.tri)
+            big = self._all_reduce(self.tri, wait=False)
+            k.gram(self.x4, self.P, self.y4[0], self.ctrl4, self.beta, self.G, self.R[0], rhs_only=True)
         for g in range(1, self.ng):
             k.gram(self.x4, self.P, self.y4[g], self.ctrl4, self.beta, self.G, self.R[g], rhs_only=True)
         for g in range(self.ng):
             k.quadform(self.K, self.C[g], self.quad[g : g + 1])
         if self.world > 1:
-            k.sym_pack(self.G, self.tri)
-            self._all_reduce(self.red)
+            self._all_reduce(self.red[self.tri.numel():])
+            self._wait(big)
             k.sym_unpack(self.tri, self.G)
         host = self._solve_all(lambda_ * self.sigma2)
-        s_pr, s_p, s_pf, s_cnt = (float(host[i]) for i in range(4))
-        quad = float(sum(host[5:]))
-        E_old = self.E
-        E = s_pr / (2 * self.sigma2) + s_p * math.log(self.sigma2) * self.Dy / 2 + lambda_ / 2 * quad
-        self.tecr = abs((E - E_old) / E)
-        self.E = E
-        self.C, self.C_new = self.C_new, self.C
-        # ---- field + sigma^2 + gamma
-        self.spr.zero_()
-        self._apply_all(self.ctrl4)
-        self._all_reduce(self.spr)
-        self.sigma2 = float(self.spr.cpu()[0]) / (s_pf * self.Dy)
+        self.fin.zero_()
+        if host is not None:
+            s_pr, s_p, s_pf, s_cnt = (float(host[i]) for i in range(4))
+            quad = float(sum(host[5:]))
+            E_old = self.E
+            E = s_pr / (2 * self.sigma2) + s_p * math.log(self.sigma2) * self.Dy / 2 + lambda_ / 2 * quad
+            self.tecr = abs((E - E_old) / E)
+            self.E = E
+            self.C, self.C_new = self.C_new, self.C
+            # ---- field + sigma^2 + gamma
+            self._apply_all(self.ctrl4)
+        spr = self._finish_step()
+        self.sigma2 = spr / (s_pf * self.Dy)
         g = s_cnt / self.n_total
         self.gamma = 0.95 if g > 0.95 else (0.05 if g < 0.05 else g)
         self.iteration += 1
@@ -493,6 +524,16 @@ class SparseVFCEngine:
         for j, g in enumerate(gs):
             self.C_new[g].copy_(Ccat[:, 3 * j : 3 * j + 3])
 
+    def _probe_vectors(self):
+        """Two fixed +-1 vectors (M x 2, float64, identical on every rank): the right-hand sides of the inverse-iteration
+        witness of the full-rank certificate."""
+        if getattr(self, "_probes", None) is None:
+            j = np.arange(self.M, dtype=np.uint64)
+            bits = [((j * np.uint64(2654435761) + np.uint64(s_)) >> np.uint64(15)) & np.uint64(1) for s_ in (12345, 987654321)]
+            b = np.stack([1.0 - 2.0 * x.astype(np.float64) for x in bits], axis=1)
+            self._probes = torch.from_numpy(np.ascontiguousarray(b)).to(self.k.device)
+        return self._probes
+
     @staticmethod
     def _check_converged(sweeps):
         """mvf_solve_minnorm(_lr) report a sweep count of x.5 when the Jacobi iteration hit its sweep cap before a clean
@@ -512,46 +553,42 @@ class SparseVFCEngine:
 
         Multi-rank: every rank solves the same all-reduced system redundantly and must take the same branch (Cholesky /
         rank-revealing / full-width, retries, sweeps) - the kernels are deterministic, so they do.  That is VERIFIED every
-        step: one tiny MAX all-reduce of (+signature, -signature) of this rank's solver decisions, a failure on any
-        rank included; a disagreement (or a rank that failed) raises on EVERY rank instead of leaving the others hanging
-        in the next collective."""
+        step (`_finish_step`): the signature of this rank's solver decisions, or its failure, travels in the step's last
+        collective; here a failure is only recorded (returns None) so that this rank still takes part in it."""
+        self._step_error, self._solver_signature = None, (0.0,) * 6
         if self.world == 1:
             return self._solve_all_local(ls2)
-        err, h = None, None
         try:
-            h = self._solve_all_local(ls2)
-            sig = list(self._solver_signature)
-        except (_lib.MVFError, RuntimeError) as exc:
-            err, sig = exc, [-1.0] * 6
-        self._agree(sig, err)
-        return h
+            return self._solve_all_local(ls2)
+        except Exception as exc:  # noqa: BLE001 - ANY failure must reach the collective, or the other ranks hang in it
+            self._step_error = exc
+            return None
 
-    def _agree(self, sig, err=None):
-        """Raise on every rank unless all ranks hold the same signature (and none of them failed)."""
-        import torch.distributed as dist
-
-        v = [float(x) for x in sig] + [1.0 if err is not None else 0.0]
-        t = torch.tensor(v + [-x for x in v], dtype=torch.float64, device=self.k.device)
-        ev = None
-        if self.comm_events is not None:  # counted with the step's other collectives (bench.py `comm`)
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        if ev is not None:
-            ev[1].record()
-            self.comm_events.append(ev + (t.numel() * t.element_size(),))
-        t = t.cpu().numpy()
-        n = len(v)
-        hi, lo = t[:n], -t[n:]
+    def _finish_step(self):
+        """sum P r over all ranks (host float).  Multi-rank: ONE 14-double SUM all-reduce carries it together with every
+        rank's failure flag and solver signature `sig = [branch, status, sweeps, kept rank, factor rank, retries]` as
+        (sig, sig^2): all ranks hold the same signature iff  world * sum(sig^2) == sum(sig)^2  for every entry (the
+        entries are small integers or halves: the sums are exact).  A failure on any rank, or a disagreement, raises on
+        EVERY rank in this very step instead of leaving the others hanging in the next collective."""
+        if self.world == 1:
+            return float(self.spr.cpu()[0])
+        sig = [float(x) for x in self._solver_signature]
+        err = self._step_error
+        tail = [1.0 if err is not None else 0.0] + sig + [x * x for x in sig]
+        self.fin[1:].copy_(torch.tensor(tail, dtype=torch.float64))
+        self._all_reduce(self.fin)
+        h = self.fin.cpu().numpy()
         if err is not None:
             raise err
-        if hi[-1] != 0.0:
+        if h[1] != 0.0:
             raise _lib.MVFError(f"SparseVFC (rank {self.rank}): the coefficient solve failed on another rank")
-        if not np.array_equal(hi, lo):
+        s1, s2 = h[2:8], h[8:14]
+        if not np.array_equal(self.world * s2, s1 * s1):
             raise _lib.MVFError(
                 f"SparseVFC (rank {self.rank}): ranks disagree on the coefficient solve's decisions "
-                f"[branch, status, sweeps, kept rank, factor rank, retries]: mine {v[:-1]}, min over ranks "
-                f"{lo[:-1].tolist()}, max {hi[:-1].tolist()} - the all-reduced Gram systems are not identical")
+                f"[branch, status, sweeps, kept rank, factor rank, retries]: mine {sig}, mean over the ranks "
+                f"{(s1 / self.world).tolist()} - the all-reduced Gram systems are not identical")
+        return float(h[0])
 
     def _solve_all_local(self, ls2):
         k = self.k
@@ -574,15 +611,36 @@ class SparseVFCEngine:
                         f"coefficient solve failed: non-positive pivot at {fail - 1} even with jitter "
                         f"{self.jitter:g}; the system is not numerically PSD (NaN/Inf in the inputs?)")
         if not self.rank_deficient:
-            # un-regularised Cholesky for every column group; its pivots certify (or refute) full numerical rank
+            # Un-regularised Cholesky for every column group.  Full numerical rank (nothing for gelsd to truncate) is
+            # certified by TWO witnesses: (1) the pivot ratio min L_jj^2 > 2^-40 max L_jj^2 - but min L_jj^2 only bounds
+            # lambda_min from ABOVE, a Kahan-type matrix keeps large pivots over a tiny lambda_min; so (2) one step of inverse
+            # iteration from two fixed +-1 vectors, free of charge as two more right-hand sides of the first batch's
+            # factorisation: ||b|| / ||A^-1 b|| lies in [lambda_min, ~sqrt(M) lambda_min] and must clear
+            # 8 sqrt(M) eps x (M max L_jj^2 >= trace-scale bound of lambda_max).  Either witness failing sends this and every
+            # later step of the fit to the truncated solve (where nothing is truncated the two solves coincide).
+            probes = self._probe_vectors()
+            Z = None
             for i, gs in enumerate(batches):
-                self._solve_batch(gs, lambda R, C: k.solve(self.G, self.K, ls2, 0.0, R, C, self.info,
-                                                           self.pivots if i == 0 else None))
-            h = self._host_stats(self.info, self.pivots)
-            if int(h[0]) == 0 and float(h[1]) > self.pivot_ratio * float(h[2]):
+                if i == 0:
+                    Rcat = torch.cat([self.R[g] for g in gs] + [probes], dim=1).contiguous()
+                    Ccat = torch.empty_like(Rcat)
+                    k.solve(self.G, self.K, ls2, 0.0, Rcat, Ccat, self.info, self.pivots)
+                    for j, g in enumerate(gs):
+                        self.C_new[g].copy_(Ccat[:, 3 * j : 3 * j + 3])
+                    Z = Ccat[:, 3 * len(gs):]
+                else:
+                    self._solve_batch(gs, lambda R, C: k.solve(self.G, self.K, ls2, 0.0, R, C, self.info, None))
+            h = self._host_stats(self.info, self.pivots, Z)
+            nz = Z.numel()
+            z = h[3 : 3 + nz].numpy().reshape(self.M, -1)
+            with np.errstate(all="ignore"):
+                lam_hat = float(np.sqrt(self.M) / np.sqrt((z * z).sum(0)).max())   # min over the probes of ||b|| / ||z||
+            certified = (int(h[0]) == 0 and float(h[1]) > self.pivot_ratio * float(h[2]) and np.isfinite(lam_hat) and
+                         lam_hat > 8.0 * np.sqrt(self.M) * np.finfo(np.float64).eps * self.M * float(h[2]))
+            if certified:
                 self.solver_stats["cholesky"] += 1
                 self._solver_signature = (2.0, 0.0, 0.0, float(self.M), 0.0, 0.0)
-                return h[3:]
+                return h[3 + nz:]
             self.rank_deficient = True
         # truncated minimum-norm solve (gelsd cut-off eps * max|lambda|)
         if self.mn_method == "lowrank" and hasattr(k, "solve_minnorm_lr"):

@@ -93,13 +93,14 @@ class CpuKernels:
         P_out.copy_(torch.from_numpy(pf))
         stats += torch.tensor([p @ rr, p.sum(), pf.sum(), float((pf > theta).sum()), nzero], dtype=torch.float64)
 
-    def gram(self, x4, P, y4, ctrl4, beta, G, R, rhs_only=False):
+    def gram(self, x4, P, y4, ctrl4, beta, G, R, rhs_only=False, tiles_only=False):
         X, ctrl = _np(x4)[:, :3], _np(ctrl4)[:, :3]
         U = svo.con_K(X, ctrl, beta).reshape(len(X), len(ctrl))
         UP = U.T * _np(P)[None, :]
         if not rhs_only:
             G.copy_(torch.from_numpy(UP @ U))
-        R.copy_(torch.from_numpy(UP @ _np(y4)[:, :3]))
+        if not tiles_only:
+            R.copy_(torch.from_numpy(UP @ _np(y4)[:, :3]))
 
     def solve(self, G, K, lambda_sigma2, jitter, R, C_out, info, pivots=None):
         A = _np(G) + lambda_sigma2 * _np(K)

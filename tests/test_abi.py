@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libmvf.so does not export {name}"
     assert sorted(_lib.SIGNATURES) == declared, "ctypes table and include/mvf.h disagree"
-    assert lib.mvf_version() == 2
+    assert lib.mvf_version() == 3
 
 
 def test_constants_match_header():
@@ -123,3 +123,20 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_developer_options_are_an_explicit_call_not_the_environment(monkeypatch):
+    """Rounds 1 - 3 had getenv knobs in launch paths; the library no longer reads the environment at all, developer
+    options travel through mvf_debug_option (no GPU needed), and the legacy MVF_* names only act behind MVF_DEV_KNOBS=1."""
+    from spateo_amd import _lib
+
+    src = "".join(open(os.path.join(ROOT, "spateo-release_amd", "csrc", f)).read()
+                  for f in os.listdir(os.path.join(ROOT, "spateo-release_amd", "csrc")) if f.endswith((".hip", ".h")))
+    assert "getenv" not in src
+    lib = _lib.load()
+    assert _lib.debug_options() == {}
+    assert _lib.debug_option("slice_len", 4096) == 0 and _lib.debug_options() == {"slice_len": 4096}
+    assert _lib.debug_option("slice_len", 0) == 4096 and _lib.debug_options() == {}
+    assert lib.mvf_debug_option(b"no_such_option", 1) != 0 and b"unknown option" in lib.mvf_last_error()
+    assert lib.mvf_debug_option_get(b"no_such_option") == -1
+    assert not _lib.DEV_KNOBS and _lib.LIB_PATH.endswith(os.path.join("spateo_amd", "lib", "libmvf.so"))

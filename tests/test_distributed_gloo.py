@@ -53,13 +53,17 @@ def _worker(rank, world, port, case, out_dir, mode="all"):
                     pivots[0] = 1e-14 * pivots[1]  # full rank NOT certified: every rank must switch to the min-norm solve
                 if case == "disagree" and rank == 1 and pivots is not None:
                     pivots[0] = 1e-14 * pivots[1]  # ONLY rank 1 sees an uncertified rank: the ranks would part ways
+                if case == "crash" and rank == 1 and len(Recording.fills) >= 2:
+                    raise IndexError("not an MVFError: a plain bug on one rank in its second EM iteration")
 
             def solve_minnorm_lr(self, *a, **kw):
                 Recording.hints.append(kw.get("rank_hint", 0))
                 super().solve_minnorm_lr(*a, **kw)
 
         if case == "minnorm_lr":
-            os.environ["MVF_MINNORM"] = "lowrank"  # the rank-revealing solve regardless of M
+            import spateo_amd.vectorfield as _v
+
+            _v.MINNORM_METHOD = "lowrank"  # the rank-revealing solve regardless of M
         Grid = X[::30]
         kw = dict(M=25, lambda_=3.0, lstsq_method="scipy", MaxIter=6, seed=0)
         if case == "wide":
@@ -78,14 +82,12 @@ def _worker(rank, world, port, case, out_dir, mode="all"):
             lo, hi = (0, 401) if rank == 0 else (401, 601)
             got = st.SparseVFC(X[lo:hi], V[lo:hi], Grid, distributed=True, sharded_input=True, gather="root",
                                _kernels=Recording(), **kw)
-        elif case == "disagree":
-            from spateo_amd._lib import MVFError
-
+        elif case in ("disagree", "crash"):
             try:
                 st.SparseVFC(X, V, Grid, distributed=True, gather=mode, _kernels=Recording(), **kw)
                 msg = "no error"
-            except MVFError as exc:
-                msg = str(exc)
+            except Exception as exc:  # noqa: BLE001
+                msg = f"{type(exc).__name__}: {exc}"
             with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
                 f.write(msg)
             return
@@ -174,6 +176,17 @@ def test_two_rank_gloo_divergent_solver_branches_raise_instead_of_hanging(tmp_pa
     for r in (0, 1):
         msg = (tmp_path / f"rank{r}.txt").read_text()
         assert "ranks disagree on the coefficient solve" in msg, msg
+
+
+def test_two_rank_gloo_any_exception_on_one_rank_raises_on_all(tmp_path):
+    """an exception that is NOT an MVFError (a plain bug) in one rank's solve used to skip the agreement
+    collective and leave the other rank hanging in it.  Now it travels as the failure flag of the step's last collective:
+    the failing rank re-raises its own error, the other one raises MVFError - both in that very step."""
+    sys.path.insert(0, HERE)
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, "crash", str(tmp_path)), nprocs=2, join=True)
+    assert "failed on another rank" in (tmp_path / "rank0.txt").read_text()
+    assert (tmp_path / "rank1.txt").read_text().startswith("IndexError: not an MVFError")
 
 
 def test_distributed_flag_requires_process_group():

@@ -218,11 +218,10 @@ def test_gram_partial_tiles_in_phases(st, dtype, monkeypatch):
     center = ctrl.mean(0)
     x4, c4, y4 = k.to_x4(X, center), k.to_x4(ctrl, center), k.to_x4(Y)
     out = {}
+    from spateo_amd import _lib
+
     for name, sl in (("one_launch", None), ("phases", "256")):
-        if sl is None:
-            monkeypatch.delenv("MVF_SLICE_LEN", raising=False)
-        else:
-            monkeypatch.setenv("MVF_SLICE_LEN", sl)
+        _lib.debug_option("slice_len", int(sl or 0))   # developer option of the library (mvf.h), not an environment knob
         kk = _k(dtype)
         G = torch.empty(m, m, dtype=torch.float64, device="cuda:0")
         R = torch.empty(m, 3, dtype=torch.float64, device="cuda:0")
@@ -238,7 +237,7 @@ def test_gram_partial_tiles_in_phases(st, dtype, monkeypatch):
         if sl is not None:  # the buffer really is smaller than all partial tiles
             need = kk.lib.mvf_gram_workspace_bytes(n, m, kk.cdtype)
             assert need < (n // 256) * 6 * 128 * 128 * 8
-    monkeypatch.delenv("MVF_SLICE_LEN", raising=False)
+    _lib.debug_option("slice_len", 0)
     assert _relmax(out["phases"], out["one_launch"]) < 1e-12
     U = svo.con_K(X[:100_000], ctrl, beta)
     # (the oracle on the first 100 k cells only bounds nothing about the rest; the full comparison is the one above)
@@ -246,9 +245,12 @@ def test_gram_partial_tiles_in_phases(st, dtype, monkeypatch):
     kk = _k(dtype)
     G = torch.empty(m, m, dtype=torch.float64, device="cuda:0")
     R = torch.empty(m, 3, dtype=torch.float64, device="cuda:0")
-    monkeypatch.setenv("MVF_SLICE_LEN", "256")
+    _lib.debug_option("slice_len", 256)
     # 100 k cells x 6 pairs at 256-cell slices = 2346 tiles: one phase; 1.2 M: two - same kernels, so a cheap oracle check
-    kk.gram(x4[:100_000].contiguous(), P[:100_000].contiguous(), y4[:100_000].contiguous(), c4, beta, G, R)
+    try:
+        kk.gram(x4[:100_000].contiguous(), P[:100_000].contiguous(), y4[:100_000].contiguous(), c4, beta, G, R)
+    finally:
+        _lib.debug_option("slice_len", 0)
     assert _relmax(G.cpu().numpy(), Gr) < (3e-6 if dtype == "float32" else 1e-11)
 
 
@@ -771,7 +773,7 @@ def test_hull_mask_matches_delaunay_find_simplex():
                                        ("float32", 1003, 1004), ("float64", 333, 3000)])
 def test_con_k_store_patterns_are_bit_identical(dtype, n, m):
     """The three materialised con_K kernels (row-contiguous spans of 1 / 2 / 4 rows, flat 16 KB chunks with the control
-    points in LDS, 2-D row blocks; MVF_CONK = rows | flat | 2d) agree bit for bit - ragged last chunk / pass / span
+    points in LDS, 2-D row blocks; developer option conk_form = 1 rows | 2 flat | 3 2d) agree bit for bit - ragged last chunk / pass / span
     included - and with the oracle."""
     import os
 
@@ -784,12 +786,14 @@ def test_con_k_store_patterns_are_bit_identical(dtype, n, m):
     k = HipKernels("cuda:0", dtype)
     xd, yd = torch.from_numpy(x).to("cuda:0"), torch.from_numpy(y).to("cuda:0")
     out = {}
+    from spateo_amd import _lib
+
     try:
-        for form in ("rows", "flat", "2d"):
-            os.environ["MVF_CONK"] = form
+        for code, form in ((1, "rows"), (2, "flat"), (3, "2d")):
+            _lib.debug_option("conk_form", code)
             out[form] = k.con_k(xd, yd, 0.37).cpu().numpy()
     finally:
-        del os.environ["MVF_CONK"]
+        _lib.debug_option("conk_form", 0)
     default = k.con_k(xd, yd, 0.37).cpu().numpy()
     np.testing.assert_array_equal(out["rows"], out["2d"])
     np.testing.assert_array_equal(out["flat"], out["2d"])
@@ -802,7 +806,7 @@ def test_con_k_store_patterns_are_bit_identical(dtype, n, m):
 @pytest.mark.parametrize("m,nrhs,jitter", [(100, 3, 0.0), (128, 6, 0.0), (37, 1, 0.0), (100, 8, 1e-9), (2, 3, 0.0)])
 def test_solve_small_single_workgroup_path(st, m, nrhs, jitter):
     """m <= 128 (Spateo's stock M = 100): mvf_solve runs as ONE single-workgroup launch (Cholesky in registers, factor in
-    LDS, substitutions).  Against LAPACK, against the blocked multi-launch path (MVF_SOLVE_SMALL=0), pivots and the
+    LDS, substitutions).  Against LAPACK, against the blocked multi-launch path (developer option solve_small_off), pivots and the
     non-positive-pivot report included."""
     import os
 
@@ -825,11 +829,13 @@ def test_solve_small_single_workgroup_path(st, m, nrhs, jitter):
         return C.cpu().numpy(), int(info.cpu()[0]), piv.cpu().numpy()
 
     C1, info1, piv1 = run()
-    os.environ["MVF_SOLVE_SMALL"] = "0"
+    from spateo_amd import _lib
+
+    _lib.debug_option("solve_small_off", 1)
     try:
         C0, info0, piv0 = run()
     finally:
-        del os.environ["MVF_SOLVE_SMALL"]
+        _lib.debug_option("solve_small_off", 0)
     Aref = G + ls2 * K
     Aref = Aref + jitter * np.trace(Aref) / m * np.eye(m)
     Cr = np.linalg.solve(Aref, R)

@@ -151,6 +151,34 @@ def test_solve_policy_cholesky_while_certified_then_minimum_norm(cpu_kernels):
         # well conditioned system: every path gives the same field
         np.testing.assert_allclose(eng2.results()[0], _two_steps(Xv, Yv, ctrl, beta, cpu_kernels), rtol=1e-9, atol=1e-12)
 
+    # the second witness of the full-rank certificate: pivots that look fine over a lambda_min far below eps lambda_max
+    # (what a Kahan-type matrix does to an unpivoted Cholesky factorisation) - the inverse-iteration probes riding along as
+    # extra right-hand sides see 1 / lambda_min and refuse the certificate
+    class HiddenNullDirection(CpuKernels):
+        chol = mn = 0
+        widths = []
+
+        def solve(self, G, K, ls2, jitter, R, C_out, info, pivots=None):
+            HiddenNullDirection.chol += 1
+            HiddenNullDirection.widths.append(R.shape[1])
+            super().solve(G, K, ls2, jitter, R, C_out, info, pivots)
+            if pivots is not None:
+                q = torch.ones(len(C_out), 1, dtype=torch.float64) / np.sqrt(len(C_out))
+                C_out[:, 3:] += 1e19 * float(pivots[1]) ** -1 * q * (q.T @ R[:, 3:])  # = a component along lambda_min ~ 1e-19 lambda_max
+
+        def solve_minnorm(self, *a, **kw):
+            HiddenNullDirection.mn += 1
+            super().solve_minnorm(*a, **kw)
+
+    import torch
+
+    eng3 = SparseVFCEngine(Xv, Yv, ctrl, beta, kernels=HiddenNullDirection())
+    eng3.mn_method = "full"
+    eng3.init_state()
+    eng3.em_step(lambda_=3.0)
+    assert HiddenNullDirection.widths == [5]            # 3 field columns + the 2 probe columns in ONE factorisation
+    assert eng3.rank_deficient and (HiddenNullDirection.chol, HiddenNullDirection.mn) == (1, 1)
+
     class ShiftTooSmall(CpuKernels):
         shifts = []
 
