@@ -227,6 +227,13 @@ int mvf_solve_minnorm_lr(const double* G, const double* K, double lambda_sigma2,
                          const double* R, int64_t m, int nrhs, double* C, int* info, double* einfo, int max_sweeps,
                          int reuse, int rank_hint, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The pivot order of the factorisation the last mvf_solve_minnorm_lr call left in `workspace` (same m): order_out (HOST,
+ * room for m ints) receives the r pivots in the order they were taken, *r_out = r.  These are the control points that
+ * carry the numerical rank of  U^T P U + lambda sigma^2 K;  the host's optional "pivot" Gram mode restricts the rest of
+ * a fit to them.  Synchronises `stream`. */
+int mvf_lr_pivot_order(const void* workspace, size_t workspace_bytes, int64_t m, int* order_out, int64_t* r_out,
+                       void* stream);
+
 /* diag_out[n] = (U pinv(A) U^T)_nn, U = con_K(x, ctrl, beta), with the decomposition of A that the previous
  * mvf_solve_minnorm_lr (lowrank != 0) / mvf_solve_minnorm (lowrank == 0) call left in `workspace` (same m, same rcond
  * semantics: eigenvalues below rcond * max|lambda| dropped).  Replaces the last statement of

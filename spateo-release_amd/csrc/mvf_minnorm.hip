@@ -1634,6 +1634,23 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
     return 0;
 }
 
+extern "C" int mvf_lr_pivot_order(const void* workspace, size_t workspace_bytes, int64_t m, int* order_out, int64_t* r_out,
+                                  void* stream) {
+    MVF_REQUIRE(m > 0 && workspace && order_out && r_out, "mvf_lr_pivot_order: bad arguments");
+    const LrPlan p = lr_plan(m);
+    MVF_REQUIRE(workspace_bytes >= p.total, "mvf_lr_pivot_order: not the workspace of mvf_solve_minnorm_lr for this m");
+    hipStream_t st = (hipStream_t)stream;
+    const char* ws = (const char*)workspace;
+    PcholState hs;
+    MVF_CHECK_HIP(hipMemcpyAsync(&hs, ws + p.off_state, sizeof(hs), hipMemcpyDeviceToHost, st));
+    MVF_CHECK_HIP(hipStreamSynchronize(st));
+    MVF_REQUIRE(hs.magic == PCHOL_MAGIC && hs.r >= 0 && hs.r <= m, "mvf_lr_pivot_order: the workspace holds no finished factorisation");
+    MVF_CHECK_HIP(hipMemcpyAsync(order_out, ws + p.off_order, (size_t)hs.r * sizeof(int), hipMemcpyDeviceToHost, st));
+    MVF_CHECK_HIP(hipStreamSynchronize(st));
+    *r_out = hs.r;
+    return 0;
+}
+
 extern "C" int mvf_pinv_diag(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, double rcond,
                              int lowrank, double* diag_out, void* workspace, size_t workspace_bytes, mvf_dtype dtype,
                              void* stream) {

@@ -345,6 +345,19 @@ class HipKernels:
                                                  self._lr_ws.numel(), self._stream()), "mvf_solve_minnorm_lr")
 
     @_on_device
+    def lr_pivot_order(self, m):
+        """Host int array: the pivots (control-point indices, in the order taken) of the last solve_minnorm_lr call."""
+        import ctypes
+
+        if self._lr_ws is None:
+            raise RuntimeError("lr_pivot_order without a previous solve_minnorm_lr")
+        order = (ctypes.c_int * int(m))()
+        r = ctypes.c_int64(0)
+        _lib.check(self.lib.mvf_lr_pivot_order(_ptr(self._lr_ws), self._lr_ws.numel(), int(m), order, ctypes.byref(r),
+                                               self._stream()), "mvf_lr_pivot_order")
+        return np.frombuffer(order, dtype=np.int32, count=int(r.value)).astype(np.int64)
+
+    @_on_device
     def minnorm_basis(self, m):
         """Uninitialised eigenvector-basis buffer for solve_minnorm's warm start (m x m padded to multiples of 64)."""
         return torch.empty(int(self.lib.mvf_solve_minnorm_basis_bytes(m)) // 8, dtype=torch.float64, device=self.device)

@@ -291,7 +291,7 @@ class SparseVFCEngine:
     """
 
     def __init__(self, X, Y, ctrl, beta, *, dtype=None, device=None, distributed=False, group=None, n_total=None,
-                 kernels=None, cache_u="auto", shard_sizes=None):
+                 kernels=None, cache_u="auto", shard_sizes=None, gram_mode="full"):
         dtype = dtype or _DEFAULT_DTYPE
         X = np.asarray(X, dtype=np.float64)
         Y = np.asarray(Y, dtype=np.float64)
@@ -327,26 +327,19 @@ class SparseVFCEngine:
         k = self.k
         self.x4 = k.to_x4(X, self.center)
         self.y4 = [k.to_x4(Y[:, 3 * g : 3 * g + 3]) for g in range(self.ng)]
-        self.ctrl4 = k.to_x4(ctrl, self.center)
         f64 = torch.float64
-        M = self.M
-        # K = con_K(ctrl, ctrl) (regulariser + energy), stored float64 but GENERATED IN THE CELL DTYPE: K must be the
-        # same function of the control points as U is of the cells.  With float32 kernel values in U and an exact float64
-        # K the null spaces of U^T P U and of lambda sigma^2 K no longer line up and the field moves by 1e-3 (M = 2000,
-        # lambda = 3); generated consistently it moves by 1.4e-5, the float32 rounding level (measured on the oracle).
-        self.K = _consistent_K(k, ctrl, self.center, self.beta)
-        # one contiguous float64 buffer for THE all-reduce of an EM step: [packed upper triangle of G (M (M + 1) / 2;
-        # only when there is more than one rank) | R_g (M * 3) per column group | stats (5)]
         ng = self.ng
-        self.G = k.zeros(M, M, dtype=f64)
-        ntri = M * (M + 1) // 2 if self.world > 1 else 0
-        self.red = k.zeros(ntri + 3 * M * ng + 5, dtype=f64)
-        self.tri = self.red[:ntri]
-        self.R = [self.red[ntri + 3 * M * g : ntri + 3 * M * (g + 1)].view(M, 3) for g in range(ng)]
-        self.st = self.red[ntri + 3 * M * ng :]
+        if gram_mode not in ("full", "pivot"):
+            raise ValueError("gram_mode must be 'full' or 'pivot'")
+        # "pivot" (extension, default off): once the rank-revealing solve has run, the rest of the fit works on the control
+        # points its pivoted factorisation selected (`_restrict_to_pivots`)
+        self.gram_mode = gram_mode
+        self.ctrl_full, self.subset, self._quad_carry = ctrl, None, None
+        self.pivot_max_fraction = 0.75   # no switch unless the factor keeps at most this share of the control points
         self.comm_events = None  # bench.py: list of (start, end) events around the collectives
-        self.C = [k.zeros(M, 3, dtype=f64) for _ in range(ng)]
-        self.C_new = [k.zeros(M, 3, dtype=f64) for _ in range(ng)]
+        self._cache_u_wanted = cache_u
+        self._setup_control_points(ctrl)
+        M = self.M
         self.quad = k.zeros(ng, dtype=f64)
         # the step's LAST collective: [sum P r | failed | solver signature (6) | its squares (6)], summed over the ranks
         self.fin = k.zeros(14, dtype=f64)
@@ -357,16 +350,7 @@ class SparseVFCEngine:
         self.r = None
         # U = con_K(X, ctrl) is constant across EM iterations: cache its values (cell dtype) for the Gram kernel when HBM
         # has room ("auto": sizeof(dtype) n M bytes plus headroom), else the Gram kernel regenerates them every iteration
-        self.cached_u = False
-        if cache_u and hasattr(k, "build_ublk") and self.n_local and M:
-            need = k.ublk_bytes(self.n_local, M)
-            free = torch.cuda.mem_get_info(k.device)[0] if cache_u == "auto" else None
-            # "auto": the cache must fit with 8 GB of headroom.  Measured at the largest case (float64 cells, 8 M x 3000
-            # on ONE GPU = 197 GB): streaming the cache runs the Gram kernel at 47 TF, regenerating the operands
-            # (software float64 exp) at 38 TF; the float32 cache (98 GB) and the per-rank caches run at 60 / 53 TF.
-            if free is None or need + (8 << 30) < free:
-                k.build_ublk(self.x4, self.ctrl4, self.beta)
-                self.cached_u = True
+        self._build_u_cache()
         # Coefficient solve (lstsq_method "scipy" = the reference's gelsd semantics): Cholesky with NO regularisation
         # while the pivots certify full numerical rank (then nothing is truncated and it IS the gelsd solution), else
         # the truncated minimum-norm solve (mvf_solve_minnorm).  Rank deficiency is sticky within a fit: sigma^2 only
@@ -395,6 +379,76 @@ class SparseVFCEngine:
         self.E = 1.0
         self.tecr = 1.0
         self.iteration = 0
+
+    def _setup_control_points(self, ctrl):
+        """Everything whose shape follows the control points: ctrl4, K, G, the all-reduce buffer, the coefficients."""
+        k, f64, ng = self.k, torch.float64, self.ng
+        self.M = M = len(ctrl)
+        self.ctrl = ctrl
+        self.ctrl4 = k.to_x4(ctrl, self.center)
+        # K = con_K(ctrl, ctrl) (regulariser + energy), stored float64 but GENERATED IN THE CELL DTYPE: K must be the
+        # same function of the control points as U is of the cells.  With float32 kernel values in U and an exact float64
+        # K the null spaces of U^T P U and of lambda sigma^2 K no longer line up and the field moves by 1e-3 (M = 2000,
+        # lambda = 3); generated consistently it moves by 1.4e-5, the float32 rounding level (measured on the oracle).
+        self.K = _consistent_K(k, ctrl, self.center, self.beta)
+        # one contiguous float64 buffer for the all-reduces of an EM step: [packed upper triangle of G (M (M + 1) / 2;
+        # only when there is more than one rank) | R_g (M * 3) per column group | stats (5)]
+        self.G = k.zeros(M, M, dtype=f64)
+        ntri = M * (M + 1) // 2 if self.world > 1 else 0
+        self.red = k.zeros(ntri + 3 * M * ng + 5, dtype=f64)
+        self.tri = self.red[:ntri]
+        self.R = [self.red[ntri + 3 * M * g : ntri + 3 * M * (g + 1)].view(M, 3) for g in range(ng)]
+        self.st = self.red[ntri + 3 * M * ng :]
+        self.C = [k.zeros(M, 3, dtype=f64) for _ in range(ng)]
+        self.C_new = [k.zeros(M, 3, dtype=f64) for _ in range(ng)]
+        self._probes = None
+
+    def _build_u_cache(self):
+        """U = con_K(X, ctrl) is constant across EM iterations: cache its values (cell dtype) for the Gram kernel when HBM
+        has room ("auto": sizeof(dtype) n M bytes plus headroom), else the Gram kernel regenerates them every iteration."""
+        k, cache_u = self.k, self._cache_u_wanted
+        self.cached_u = False
+        if cache_u and hasattr(k, "build_ublk") and self.n_local and self.M:
+            if hasattr(k, "drop_ublk"):
+                k.drop_ublk()
+            need = k.ublk_bytes(self.n_local, self.M)
+            free = torch.cuda.mem_get_info(k.device)[0] if cache_u == "auto" else None
+            # "auto": the cache must fit with 8 GB of headroom.  Measured at the largest case (float64 cells, 8 M x 3000
+            # on ONE GPU = 197 GB): streaming the cache runs the Gram kernel at 47 TF, regenerating the operands
+            # (software float64 exp) at 38 TF; the float32 cache (98 GB) and the per-rank caches run at 60 / 53 TF.
+            if free is None or need + (8 << 30) < free:
+                k.build_ublk(self.x4, self.ctrl4, self.beta)
+                self.cached_u = True
+
+    def _restrict_to_pivots(self):
+        """gram_mode="pivot": continue the fit on the control points that carry the numerical rank.
+
+        The rank-revealing solve of the iteration that just ended factored  A = U^T P U + lambda sigma^2 K  by a greedy
+        diagonally pivoted Cholesky stopped at 0.25 eps lambda_max: r pivots (r ~ 0.3 M at M = 3000), the remaining columns
+        of [P^1/2 U; (lambda sigma^2 K)^1/2] being linear combinations of the selected ones to the rounding level of A.
+        From the next iteration on the model is  v(x) = sum over the r selected control points:  C is zero elsewhere, so
+        `V = con_K(X, X_ctrl) C` holds exactly for the returned (M x Dy) coefficients, and the M-step costs N r^2 instead of
+        N M^2.  sigma^2 only shrinks afterwards, so the numerical rank of A does not grow back.  This is NOT the
+        reference's arithmetic (its minimum-norm solution spreads over all M columns): measured against the oracle the
+        field stays at the reference's own noise floor (1.07 - 1.12 x at 200 k x 3000) but sigma^2 / P reach 2 - 2.7 x the
+        floor at 10 cells per control point (profiles/r04_pivot_subset.md) - hence an option, default off."""
+        k = self.k
+        if not hasattr(k, "lr_pivot_order"):
+            return False
+        p = np.asarray(k.lr_pivot_order(self.M), dtype=np.int64)
+        if len(p) < 2 or len(p) > self.pivot_max_fraction * self.M:
+            return False
+        # the regulariser of the NEXT energy value belongs to the coefficients of the full model
+        for g in range(self.ng):
+            k.quadform(self.K, self.C[g], self.quad[g : g + 1])
+        self._quad_carry = float(self.quad.cpu().sum())
+        self.subset = p
+        self._setup_control_points(self.ctrl_full[p])
+        self._build_u_cache()
+        self.rank_hint, self.basis, self.basis_valid = 0, None, False
+        self.mn_method = "lowrank" if hasattr(k, "solve_minnorm_lr") else self.mn_method
+        self.solver_stats["pivot_subset"] = int(len(p))
+        return True
 
     # ------------------------------------------------------------------ collectives
     def _all_reduce(self, t, op="sum", wait=True):
@@ -443,6 +497,7 @@ class SparseVFCEngine:
         self.rank_deficient = False
         self.basis_valid = False
         self.rank_hint = 0
+        self._lr_ran = False
 
     def _apply_all(self, ctrl4):
         """V_g = U C_g for every column group; r = sum_g ||Y_g - V_g||^2; spr += sum P r."""
@@ -495,6 +550,8 @@ class SparseVFCEngine:
         if host is not None:
             s_pr, s_p, s_pf, s_cnt = (float(host[i]) for i in range(4))
             quad = float(sum(host[5:]))
+            if self._quad_carry is not None:  # first iteration on the pivot subset: the old coefficients were the full model's
+                quad, self._quad_carry = self._quad_carry, None
             E_old = self.E
             E = s_pr / (2 * self.sigma2) + s_p * math.log(self.sigma2) * self.Dy / 2 + lambda_ / 2 * quad
             self.tecr = abs((E - E_old) / E)
@@ -507,6 +564,8 @@ class SparseVFCEngine:
         g = s_cnt / self.n_total
         self.gamma = 0.95 if g > 0.95 else (0.05 if g < 0.05 else g)
         self.iteration += 1
+        if self.gram_mode == "pivot" and self.subset is None and self._lr_ran:
+            self._restrict_to_pivots()
         return self.E, self.tecr
 
     def _rhs_batches(self):
@@ -555,7 +614,7 @@ class SparseVFCEngine:
         rank-revealing / full-width, retries, sweeps) - the kernels are deterministic, so they do.  That is VERIFIED every
         step (`_finish_step`): the signature of this rank's solver decisions, or its failure, travels in the step's last
         collective; here a failure is only recorded (returns None) so that this rank still takes part in it."""
-        self._step_error, self._solver_signature = None, (0.0,) * 6
+        self._step_error, self._solver_signature, self._lr_ran = None, (0.0,) * 6, False
         if self.world == 1:
             return self._solve_all_local(ls2)
         try:
@@ -660,6 +719,7 @@ class SparseVFCEngine:
             self.solver_stats["sweeps"].append(float(h[1]))
             self.solver_stats["rank"].append(int(h[2]))
             self.solver_stats.setdefault("factor_rank", []).append(self.rank_hint)
+            self._lr_ran = True
             self._solver_signature = (3.0, 0.0, float(h[1]), float(h[2]), float(self.rank_hint), 0.0)
             return h[1 + 12:]
         # mn_method = "full": Jacobi on all M columns of the shifted Cholesky factor; the shift only has to make the
@@ -737,6 +797,10 @@ class SparseVFCEngine:
         V = self._gather_rows(Vloc, gather == "root").to(torch.float64).cpu().numpy()
         P = self._gather_rows(self.P[:, None].contiguous(), gather == "root").to(torch.float64).cpu().numpy()
         C = torch.cat(self.C, dim=1)[:, : self.Dy].cpu().numpy().copy()
+        if self.subset is not None:  # pivot mode: coefficients of the full control-point set, zero off the subset
+            Cf = np.zeros((len(self.ctrl_full), C.shape[1]))
+            Cf[self.subset] = C
+            C = Cf
         return V, P, C
 
 
@@ -889,6 +953,7 @@ def SparseVFC(
     group=None,
     sharded_input=False,
     gather="root",
+    gram_mode="full",
     _kernels=None,
 ) -> dict:
     """Drop-in for ``dynamo.vectorfield.scVectorField.SparseVFC`` (defaults identical).
@@ -902,7 +967,10 @@ def SparseVFC(
     ``valid_ind`` that this rank's ``V`` / ``P`` rows correspond to (``VFCIndex`` counts from ``lo``).
     ``lstsq_method``: "scipy" (what Spateo passes) = minimum-norm solve with gelsd's eps * s_max cut-off on the
     device (Cholesky while the pivots certify full numerical rank, else the hand-written symmetric eigensolver);
-    "drouin" maps to the same solve with a warning; "cholesky" is a non-reference fast mode.  The coefficients ``C`` are
+    "drouin" maps to the same solve with a warning; "cholesky" is a non-reference fast mode.  ``gram_mode``: "full" (default,
+    the reference's M-step on all M control points) | "pivot" (extension: after the first rank-revealing solve the fit
+    continues on the r control points its pivoted factorisation selected, ``C`` zero elsewhere; N r^2 instead of N M^2 work
+    per iteration; field at the reference's noise floor, see ``SparseVFCEngine._restrict_to_pivots``).  The coefficients ``C`` are
     NOT a parity quantity (the reference's own solver only fixes them up to the numerical null space of the Gram
     system) - the field ``V`` / ``grid_V``, ``sigma2`` and ``P`` are.
     Returns the reference's dict with host NumPy float64 arrays.
@@ -977,13 +1045,15 @@ def SparseVFC(
         # and the energy term C.T.dot(K).dot(C) then fails with a ValueError
         raise ValueError("SparseVFC needs at least 2 control points (shapes (3,) and (1,3) not aligned in the reference)")
     eng = SparseVFCEngine(Xv[lo:hi], Yv[lo:hi], ctrl_pts, beta, dtype=dtype, device=device, distributed=distributed,
-                          group=group, n_total=N, kernels=_kernels, shard_sizes=shard_sizes)
+                          group=group, n_total=N, kernels=_kernels, shard_sizes=shard_sizes, gram_mode=gram_mode)
     tecr_vec, E_vec = eng.fit(a=a, gamma=gamma, lambda_=lambda_, minP=minP, MaxIter=MaxIter, theta=theta, ecr=ecr,
                               lstsq_method=lstsq_method)
     V, P, C = eng.results(gather=gather)
     grid_V = eng.predict(Grid) if Grid is not None else None
     i = eng.iteration
     extra = {}
+    if eng.subset is not None:
+        extra["ctrl_subset"] = eng.subset  # pivot mode: rows of X_ctrl / C that carry the field (C is zero elsewhere)
     if world > 1:
         # which rows of the finite-row sequence (positions in `valid_ind`) the per-cell outputs V / P / VFCIndex of THIS
         # rank cover: all of them on rank 0 and with gather="all", this rank's block otherwise (VFCIndex is relative to it)

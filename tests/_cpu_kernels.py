@@ -149,6 +149,7 @@ class CpuKernels:
             L = np.zeros((m, m))
             used = np.zeros(m, bool)
             r = 0
+            order = []
             while r < m:
                 dm = np.where(used, -np.inf, dg)
                 p = int(np.argmax(dm))
@@ -161,7 +162,9 @@ class CpuKernels:
                     L[:, r] = c
                     dg -= c * c
                 used[p] = True
+                order.append(p)
                 r += 1
+            self._order = np.array(order, dtype=np.int64)
             u, s, _ = np.linalg.svd(L[:, :r], full_matrices=False) if r else (np.zeros((m, 0)), np.zeros(0), None)
             self._lr = (u, s * s, r)
         u, lam, r = self._lr
@@ -178,6 +181,9 @@ class CpuKernels:
         if not reuse:
             einfo[0] = 1.0
             einfo[6] = float(r)
+
+    def lr_pivot_order(self, m):
+        return self._order.copy()
 
     def pinv_diag(self, x4, ctrl4, beta, rcond=None, lowrank=False):
         """diag(U pinv(A) U^T) from the decomposition of the last solve_minnorm_lr / solve_minnorm call."""

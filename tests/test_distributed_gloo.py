@@ -22,6 +22,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _pivot_kw(vfm, X, V):
+    """A small problem that IS numerically rank deficient (kernel 20 x wider than the bandwidth rule's): pivot mode."""
+    beta = 0.05 * vfm.sparsevfc_preprocess(X, V, M=120, seed=0)[5]
+    return dict(M=120, lambda_=0.02, lstsq_method="scipy", MaxIter=7, ecr=0.0, seed=0, beta=beta, gram_mode="pivot")
+
+
 def _worker(rank, world, port, case, out_dir, mode="all"):
     for p in (ROOT, os.path.join(ROOT, "spateo-release_amd"), HERE):
         if p not in sys.path:
@@ -66,6 +72,11 @@ def _worker(rank, world, port, case, out_dir, mode="all"):
             _v.MINNORM_METHOD = "lowrank"  # the rank-revealing solve regardless of M
         Grid = X[::30]
         kw = dict(M=25, lambda_=3.0, lstsq_method="scipy", MaxIter=6, seed=0)
+        if case == "pivot":
+            import spateo_amd.vectorfield as _v
+
+            _v.MINNORM_METHOD = "lowrank"
+            kw = _pivot_kw(_v, X, V)
         if case == "wide":
             V = np.column_stack([V, np.sin(X[:, 0] / 70), np.cos(X[:, 1] / 50)])  # Dy = 5: two column groups
         calls = {"unique": 0}
@@ -96,7 +107,7 @@ def _worker(rank, world, port, case, out_dir, mode="all"):
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), V=got["V"], P=got["P"], C=got["C"], grid_V=got["grid_V"],
                  sigma2=got["sigma2"], iteration=got["iteration"], E=got["E_traj"], fills=np.array(Recording.fills),
                  unique_calls=calls["unique"], valid_ind=got["valid_ind"], vfc=got["VFCIndex"],
-                 hints=np.array(Recording.hints, dtype=np.int64))
+                 hints=np.array(Recording.hints, dtype=np.int64), subset=got.get("ctrl_subset", np.zeros(0, dtype=np.int64)))
     finally:
         dist.destroy_process_group()
 
@@ -136,6 +147,39 @@ def test_two_rank_gloo_matches_single_process(tmp_path, case):
         # (the first call has none; afterwards the previous factor's 25 rows)
         np.testing.assert_array_equal(r0["hints"], r1["hints"])
         assert len(r0["hints"]) == int(r0["iteration"]) + 1 and r0["hints"][0] == 0 and (r0["hints"][1:] == 25).all()
+
+
+def test_two_rank_gloo_pivot_mode_matches_single_process(tmp_path):
+    """gram_mode="pivot" with cells sharded over two ranks: both ranks read the same pivot order off their (identical,
+    all-reduced) system, switch in the same iteration and end with the single-process pivot-mode result."""
+    sys.path.insert(0, HERE)
+    import spateo_amd as st
+    import spateo_amd.vectorfield as vfm
+    from _cpu_kernels import CpuKernels
+    from spateo_amd._synthetic import make_config
+
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, "pivot", str(tmp_path)), nprocs=2, join=True)
+    X, V, _ = make_config("C2", N=601)
+    old = vfm.MINNORM_METHOD
+    vfm.MINNORM_METHOD = "lowrank"
+    try:
+        ref = st.SparseVFC(X, V, X[::30], _kernels=CpuKernels(), **_pivot_kw(vfm, X, V))
+    finally:
+        vfm.MINNORM_METHOD = old
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert 2 <= len(ref["ctrl_subset"]) <= 90 and 2 <= len(r0["subset"]) <= 90
+    # the two ranks hold the same all-reduced system bit for bit, so they select the SAME control points and end identical
+    np.testing.assert_array_equal(r0["subset"], r1["subset"])
+    for k in ("V", "P", "C", "grid_V", "sigma2", "E"):
+        np.testing.assert_array_equal(r0[k], r1[k])
+    assert np.all(r0["C"][np.setdiff1d(np.arange(120), r0["subset"])] == 0.0)
+    # against the single-process run only to the noise level of this toy: the pivot order among near-equal diagonal entries
+    # follows the rounding of the Gram sums (one sum here, two partial sums all-reduced there), so the subsets differ in a
+    # few members (90 vs 87 control points when this was written)
+    assert len(np.intersect1d(r0["subset"], ref["ctrl_subset"])) >= 0.85 * len(ref["ctrl_subset"])
+    scale = np.abs(ref["V"]).max()
+    assert np.abs(r0["V"] - ref["V"]).max() / scale < 3e-2 and abs(float(r0["sigma2"]) / ref["sigma2"] - 1) < 3e-2
 
 
 @pytest.mark.parametrize("mode,case", [("root", "plain"), ("sharded", "plain"), ("sharded", "wide"), ("root", "wide")])

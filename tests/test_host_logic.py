@@ -760,3 +760,40 @@ def test_jacobian_with_det_in_two_dimensions(cpu_kernels):
     J, det = vf.jacobian_with_det(X)
     assert J.shape == (2, 2, 50)
     np.testing.assert_allclose(det, np.linalg.det(np.moveaxis(J, 2, 0)), rtol=1e-12, atol=1e-15)
+
+
+# ------------------------------------------------------------------------------------------------ gram_mode = "pivot"
+def test_pivot_mode_continues_on_the_selected_control_points(cpu_kernels, monkeypatch):
+    """gram_mode="pivot" (extension, default off): after the first rank-revealing solve the engine works on the r control
+    points the pivoted factorisation selected - M-step matrices r x r, coefficients zero off the subset so that
+    ``V == con_K(X, X_ctrl) @ C`` holds for the returned full-size C, energy continuous across the switch, same dict
+    contract; the default mode is untouched; a factor that keeps more than 75 % of the control points does not switch."""
+    monkeypatch.setattr(vfm, "MINNORM_METHOD", "lowrank")
+    X, V = _data(1500)
+    # a kernel 20 x wider than the bandwidth rule's makes 120 control points numerically rank deficient at this small size
+    beta = 0.05 * vfm.sparsevfc_preprocess(X, V, M=120, seed=0)[5]
+    kw = dict(M=120, lambda_=0.02, lstsq_method="scipy", MaxIter=8, ecr=0.0, seed=0, beta=beta, _kernels=cpu_kernels)
+    full = st.SparseVFC(X, V, X[:40], **kw)
+    piv = st.SparseVFC(X, V, X[:40], gram_mode="pivot", **kw)
+    assert "ctrl_subset" not in full and "ctrl_subset" in piv
+    sub = piv["ctrl_subset"]
+    assert 2 <= len(sub) <= 0.75 * 120 and len(set(sub.tolist())) == len(sub)
+    off = np.setdiff1d(np.arange(120), sub)
+    assert piv["C"].shape == (120, 3) and np.all(piv["C"][off] == 0.0) and np.abs(piv["C"][sub]).max() > 0
+    np.testing.assert_array_equal(piv["X_ctrl"], full["X_ctrl"])
+    Xv = X[piv["valid_ind"]]
+    U = svo.con_K(Xv, piv["X_ctrl"], piv["beta"])
+    np.testing.assert_allclose(U @ piv["C"], piv["V"], rtol=0, atol=1e-9 * np.abs(piv["V"]).max())
+    np.testing.assert_allclose(svo.con_K(X[:40], piv["X_ctrl"], piv["beta"]) @ piv["C"], piv["grid_V"], rtol=0,
+                               atol=1e-9 * np.abs(piv["V"]).max())
+    # the restricted model is another truncation of the same ill-posed system: the same field to the noise level of this
+    # deliberately extreme toy (12 cells per control point, 20 x the rule's kernel width; parity at the sizes the mode is
+    # meant for is measured on the GPU, tests/test_gpu_scale.py)
+    assert _rel(piv["V"], full["V"]) < 3e-2 and abs(piv["sigma2"] / full["sigma2"] - 1) < 3e-2
+    assert piv["iteration"] == full["iteration"] == 7
+    assert np.all(np.isfinite(piv["E_traj"])) and np.abs(piv["E_traj"] / full["E_traj"] - 1).max() < 3e-2
+    # well-regularised system (the factor keeps every control point): no switch
+    reg = st.SparseVFC(X, V, None, gram_mode="pivot", **dict(kw, lambda_=3.0, M=40, beta=None))
+    assert "ctrl_subset" not in reg
+    with pytest.raises(ValueError, match="gram_mode"):
+        st.SparseVFC(X, V, None, gram_mode="nonsense", **kw)
