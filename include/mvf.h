@@ -139,8 +139,11 @@ int mvf_estep_p(const void* r, int64_t n, double sigma2, double gamma, double a,
  * exact Gram matrix of those values; per-slice partial tiles are summed in a fixed order (deterministic).  No
  * process-global state: the library's behaviour depends on its arguments only.
  * Outputs are float64: G (m x m, full symmetric), R (m x 3).  They hold THIS rank's partial sums.  The collective is
- * the CALLER's: the library holds no communicator; the host all-reduces the contiguous [G | R | scalars] buffer with
- * torch.distributed (RCCL over xGMI) - one all-reduce per EM step. */
+ * the CALLER's: the library holds no communicator; the host all-reduces the packed triangle of G (asynchronously, while
+ * the rhs kernels run) and then [R | scalars] with torch.distributed (RCCL over xGMI).
+ * SURVEY.md 8(b)'s `mvf_allreduce_stats(ctx, buf)` - an opaque context holding an RCCL communicator - is INTENTIONALLY
+ * ABSENT: nothing in this build pool can execute RCCL between two devices, so such an entry point could not be tested; a
+ * C / C++ host calls ncclAllReduce on the same two device pointers between the stages below. */
 size_t mvf_gram_workspace_bytes(int64_t n, int64_t m, mvf_dtype dtype);
 int mvf_gram(const void* x4, const void* P, const void* y4, int64_t n, const void* ctrl4, int64_t m, double beta,
              double* G, double* R, void* workspace, size_t workspace_bytes, mvf_dtype dtype, void* stream);
