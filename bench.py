@@ -429,7 +429,7 @@ def main():
 
     del X, V
     try:
-        main_rec = run_mode(args.dtype, args.steps, max(args.warmup, 3) if args.gram_mode == "pivot" else args.warmup,
+        main_rec = run_mode(args.dtype, args.steps, max(args.warmup, 5) if args.gram_mode == "pivot" else args.warmup,
                             args.gram_mode)
     except Exception as exc:
         # one JSON line per failing rank on stderr (which rank, what, where), then the error itself
@@ -490,7 +490,7 @@ def main():
 
     # ---------------------------------------------------------------- the same workload in pivot mode (N = 1; NOT the headline)
     if world == 1 and args.gram_mode == "full" and args.dtype == "float32" and not args.no_pivot:
-        kp, wp = max(2, min(args.steps, 5)), 3  # the switch happens at the end of the first rank-revealing iteration
+        kp, wp = max(2, min(args.steps, 5)), 5  # the switch happens at the end of the third rank-revealing iteration
         rp = run_mode("float32", kp, wp, "pivot")
         out["pivot_subset"] = {"metric": out["metric"], "unit": "cells/s", "dtype": "f32", "value": rp["value"],
                                "ms_per_step": rp["ms_per_step"], "steps": kp, "warmup": wp, "ctrl_used": rp["ctrl_used"],

@@ -329,8 +329,16 @@ class SparseVFCEngine:
         self.y4 = [k.to_x4(Y[:, 3 * g : 3 * g + 3]) for g in range(self.ng)]
         f64 = torch.float64
         ng = self.ng
+        # switch at the end of this many rank-revealing iterations ("pivot:K" sets K).  Measured on the oracle fixtures
+        # (tools/pivot_mode_probe.py, profiles/r04_pivot_subset.md): K = 1 selects the subset while lambda sigma^2 K still
+        # dominates the small eigenvalues - field 1.06 - 1.16 x the reference floor but sigma^2 1.4 - 9 x; from K = 3 on
+        # sigma^2 has nearly converged, the subset fits the final system (and is a third smaller): sigma^2 / energy
+        # 0.1 - 1.1 x, field 0.9 - 1.5 x
+        self.pivot_after = 3
+        if isinstance(gram_mode, str) and gram_mode.startswith("pivot:") and gram_mode[6:].isdigit() and int(gram_mode[6:]) >= 1:
+            gram_mode, self.pivot_after = "pivot", int(gram_mode[6:])
         if gram_mode not in ("full", "pivot"):
-            raise ValueError("gram_mode must be 'full' or 'pivot'")
+            raise ValueError("gram_mode must be 'full', 'pivot' or 'pivot:K' (K >= 1)")
         # "pivot" (extension, default off): once the rank-revealing solve has run, the rest of the fit works on the control
         # points its pivoted factorisation selected (`_restrict_to_pivots`)
         self.gram_mode = gram_mode
@@ -429,15 +437,24 @@ class SparseVFCEngine:
         From the next iteration on the model is  v(x) = sum over the r selected control points:  C is zero elsewhere, so
         `V = con_K(X, X_ctrl) C` holds exactly for the returned (M x Dy) coefficients, and the M-step costs N r^2 instead of
         N M^2.  sigma^2 only shrinks afterwards, so the numerical rank of A does not grow back.  This is NOT the
-        reference's arithmetic (its minimum-norm solution spreads over all M columns): measured against the oracle the
-        field stays at the reference's own noise floor (1.07 - 1.12 x at 200 k x 3000) but sigma^2 / P reach 2 - 2.7 x the
-        floor at 10 cells per control point (profiles/r04_pivot_subset.md) - hence an option, default off."""
+        reference's arithmetic (its minimum-norm solution spreads over all M columns) but another truncation of the same
+        ill-posed system: measured against the oracle fixtures the field sits at 0.9 - 1.5 x the reference's own noise floor,
+        sigma^2 and the energy at 0.1 - 1.1 x, max |dP| at 0.5 - 1.4 x (3 x at 10 cells per control point in float32 mode;
+        profiles/r04_pivot_subset.md) - hence an option, default off."""
         k = self.k
         if not hasattr(k, "lr_pivot_order"):
             return False
         p = np.asarray(k.lr_pivot_order(self.M), dtype=np.int64)
         if len(p) < 2 or len(p) > self.pivot_max_fraction * self.M:
             return False
+        # The Gram kernel works in 128-wide tile columns: a subset that ends just behind a tile boundary pays for a whole
+        # column of tile pairs (897 control points = 8 columns, 36 pairs; 896 = 7 columns, 28 pairs).  The pivots come in
+        # order of decreasing diagonal weight and the last ones sit at the stopping tolerance, i.e. at the rounding level of
+        # the matrix: up to 2 % of them are dropped when that frees a tile column.
+        tile = 128
+        down = (len(p) // tile) * tile
+        if down >= 2 and len(p) - down <= max(1, int(0.02 * len(p))):
+            p = p[:down]
         # the regulariser of the NEXT energy value belongs to the coefficients of the full model
         for g in range(self.ng):
             k.quadform(self.K, self.C[g], self.quad[g : g + 1])
@@ -497,7 +514,7 @@ class SparseVFCEngine:
         self.rank_deficient = False
         self.basis_valid = False
         self.rank_hint = 0
-        self._lr_ran = False
+        self._lr_ran, self._lr_iterations = False, 0
 
     def _apply_all(self, ctrl4):
         """V_g = U C_g for every column group; r = sum_g ||Y_g - V_g||^2; spr += sum P r."""
@@ -565,7 +582,9 @@ class SparseVFCEngine:
         self.gamma = 0.95 if g > 0.95 else (0.05 if g < 0.05 else g)
         self.iteration += 1
         if self.gram_mode == "pivot" and self.subset is None and self._lr_ran:
-            self._restrict_to_pivots()
+            self._lr_iterations += 1
+            if self._lr_iterations >= self.pivot_after:
+                self._restrict_to_pivots()
         return self.E, self.tecr
 
     def _rhs_batches(self):
@@ -969,8 +988,9 @@ def SparseVFC(
     device (Cholesky while the pivots certify full numerical rank, else the hand-written symmetric eigensolver);
     "drouin" maps to the same solve with a warning; "cholesky" is a non-reference fast mode.  ``gram_mode``: "full" (default,
     the reference's M-step on all M control points) | "pivot" (extension: after the first rank-revealing solve the fit
-    continues on the r control points its pivoted factorisation selected, ``C`` zero elsewhere; N r^2 instead of N M^2 work
-    per iteration; field at the reference's noise floor, see ``SparseVFCEngine._restrict_to_pivots``).  The coefficients ``C`` are
+    three rank-revealing iterations ("pivot:K": after K) the fit continues on the r control points the pivoted factorisation
+    selected, ``C`` zero elsewhere; N r^2 instead of N M^2 work per iteration; field at 0.9 - 1.5 x the reference's noise
+    floor, see ``SparseVFCEngine._restrict_to_pivots``).  The coefficients ``C`` are
     NOT a parity quantity (the reference's own solver only fixes them up to the numerical null space of the Gram
     system) - the field ``V`` / ``grid_V``, ``sigma2`` and ``P`` are.
     Returns the reference's dict with host NumPy float64 arrays.

@@ -436,24 +436,22 @@ def test_one_em_iteration_of_the_benchmark_workload_against_the_streamed_oracle(
 
 # ------------------------------------------------------------------------------------------- gram_mode = "pivot" (extension)
 # How far the pivot-subset mode (SparseVFCEngine._restrict_to_pivots; NOT the reference's arithmetic, default off) sits
-# from the oracle, per quantity.  It is a different truncation of the same ill-posed M-step, so it is not held to the
-# 1.25 x-floor rule of the default mode; what it IS held to, and what was measured on one MI355X (round 4,
-# profiles/r04_pivot_subset.md; float64 / float32 mode):
-#   field on the cells   <= 1.5 x the reference's own floor (measured 1.06 - 1.16 x; 1.48 x once, 20 k x 2000 float32)
-#   P (max |dP|)         <= 1.5 x floor at >= 60 cells per control point (0.9 - 1.1 x), 3 x at 10 cells (0.3 - 2.4 x)
-#   energy trajectory    <= 1.5 x / 3 x floor or the mode's base tolerance (measured <= 1.2e-4 relative)
-#   sigma^2              <= 1e-3 relative in either mode (measured 6e-5 ... 8.2e-4): the restricted model's residual differs
-#                        SYSTEMATICALLY from the reference's truncated minimum-norm fit - 1.4 - 3.2 x the reference's own
-#                        floor at 200 k x 3000, 8.5 x at 20 k x 3000 in float64 mode - which is why the mode is an option.
-PIVOT_ALLOW_LARGE, PIVOT_ALLOW_SMALL, PIVOT_SIGMA2 = 1.5, 3.0, 1e-3
+# from the oracle, per quantity.  It is a different truncation of the same ill-posed M-step, so the field is not held to the
+# 1.25 x-floor rule of the default mode; what the mode IS held to, and what was measured on one MI355X (round 4,
+# tools/pivot_mode_probe.py -> profiles/r04_pivot_subset.md; float64 / float32 mode, switch after 3 iterations):
+#   field on the cells   <= 1.75 x the reference's own floor         (measured 0.91 - 1.55 x)
+#   sigma^2, energy      <= 1.25 x floor or the mode's base tolerance (measured 0.13 - 1.12 x): as the default mode
+#   P (max |dP|)         <= 1.5 x floor at >= 60 cells per control point (0.81 - 1.22 x); 3.5 x at 10 cells per control
+#                        point (0.5 - 3.05 x; the default mode itself measures 1.68 x there in float32 mode)
+PIVOT_V, PIVOT_P_LARGE, PIVOT_P_SMALL = 1.75, 1.5, 3.5
 
 
-def _pivot_check(tag, dtype, dev, table, allow):
+def _pivot_check(tag, dtype, dev, table, allow_p):
     base = _base_tolerances(dtype)
     fl = {k: table[k][0 if dtype == "float64" else 1] for k in dev}
-    lim = {k: max(allow * fl[k], base[k]) for k in dev}
-    lim["V"] = max(PIVOT_ALLOW_LARGE * fl["V"], base["V"])
-    lim["sigma2"] = PIVOT_SIGMA2
+    lim = {k: F.tol(dtype, table, k, base[k]) for k in dev}
+    lim["V"] = max(PIVOT_V * fl["V"], base["V"])
+    lim["P"] = max(allow_p * fl["P"], base["P"])
     print(f"PIVOT {tag} {dtype}: " + "; ".join(
         f"{k} gpu {dev[k]:.2e} / floor {fl[k]:.2e} (x{dev[k] / max(fl[k], 1e-300):.2f}, limit {lim[k]:.2e})" for k in dev))
     bad = {k: (dev[k], lim[k]) for k in dev if not dev[k] <= lim[k]}
@@ -476,16 +474,16 @@ def test_pivot_mode_against_the_oracle(st, case, dtype):
 
     if case == "c4_200k":
         X, V, kw, ref, table = _c4_sample_case()
-        stride, allow = _C4_SAMPLE["stride"], PIVOT_ALLOW_LARGE
+        stride, allow = _C4_SAMPLE["stride"], PIVOT_P_LARGE
     elif case in ("c4_rank", "c3_full"):
         fx, ref, table = _stream_fixture(case)
         cfg, n, M = _STREAM_CASES[case]
         X, V, _ = make_config(cfg, N=n)
         kw = dict(M=M, lambda_=0.02, lstsq_method="scipy", MaxIter=int(fx["steps"]), ecr=0.0, seed=0)
-        stride, allow = int(fx["stride"]), PIVOT_ALLOW_LARGE
+        stride, allow = int(fx["stride"]), PIVOT_P_LARGE
     else:
         X, V, kw, ref, table = _large_m_case(3000 if case == "m3000_20k" else 2000, 0.02)
-        stride, allow = 1, PIVOT_ALLOW_SMALL
+        stride, allow = 1, PIVOT_P_SMALL
     got = st.SparseVFC(X, V, None, dtype=dtype, device="cuda:0", gram_mode="pivot", **kw)
     assert got["iteration"] == ref["iteration"]
     sub = got["ctrl_subset"]
