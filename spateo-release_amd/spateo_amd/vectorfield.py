@@ -25,6 +25,7 @@ from . import _lib
 from ._kernels import HipKernels
 
 __all__ = [
+    "clear_eval_cache",
     "SparseVFC_many",
     "integrate_field",
     "genesis_states",
@@ -192,7 +193,8 @@ def sparsevfc_preprocess(X, Y, M=100, beta=None, velocity_based_sampling=True, s
 
 def _sparsevfc_preprocess(X, Y, M, beta, velocity_based_sampling, seed, device=None):
     valid_ind = np.where(np.isfinite(Y.sum(1)))[0]
-    Xv, Yv = X[valid_ind], Y[valid_ind]
+    # (all rows finite - the usual case: no gather copies; callers treat Xv / Yv as read-only)
+    Xv, Yv = (X, Y) if len(valid_ind) == len(X) else (X[valid_ind], Y[valid_ind])
     if len(Xv) == 0:
         raise ValueError("SparseVFC: no row of Y is finite - nothing to fit.")
     tmp_X, uid = unique_rows(Xv, device)
