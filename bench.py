@@ -9,7 +9,7 @@ application, sigma^2 / gamma update - SURVEY.md Appendix A step 5) over the whol
 inputs resident in HBM.  Workload: BASELINE config 4 = 8 M cells, M = 3000 control points, float32 cells; it fits one
 MI355X, so the same total problem is run at every N (cells block-sharded across ranks: strong scaling).
 Rank 0 prints ONE JSON line.  Extra objects: ``roofline`` (dominant kernel = the MFMA Gram kernel, timed with HIP
-events on its launch stream; ``traffic`` = the PMC figure parsed from the committed ``profiles/r03_pmc_traffic.json``),
+events on its launch stream; ``traffic`` = the PMC figure parsed from the committed ``profiles/r04_pmc_traffic.json``),
 ``solve`` (the coefficient solve: path, Jacobi sweeps, ms, MFMA-tile TFLOP/s), ``f64`` (the SAME workload in float64
 mode - the mode the 1e-5 parity clause is about - with its own roofline; N = 1 only), ``con_k`` (the materialised-kernel
 HBM-write bandwidth), ``cpu_baseline`` (the float64 NumPy oracle on the host cores at N_cpu = 200 k and 100 k cells; its
@@ -34,12 +34,12 @@ for _p in (ROOT, os.path.join(ROOT, "spateo-release_amd")):
 
 PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X datasheet: FP64 matrix (v_mfma_f64_16x16x4_f64) dense peak
 PEAK_HBM_GBPS = 8000.0
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 
 
 def pmc_traffic(dtype, gram_mode, cached_u, gpus, cells_per_rank, ctrl):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE, gfx950 corrections applied; profiles/r03_pmc/ and profiles/r02_hbm_traffic_pmc.md explain the entries).  None if this
+    WRITE_SIZE, gfx950 corrections applied; profiles/r04_pmc/, profiles/r03_pmc/ and profiles/r02_hbm_traffic_pmc.md explain the entries).  None if this
     configuration was not measured."""
     try:
         with open(PMC_TRAFFIC_FILE) as f:
@@ -345,7 +345,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
                 # HBM bytes per launch (FETCH_SIZE + WRITE_SIZE PMC passes with the gfx950 corrections) parsed from the
-                # committed profiles/r03_pmc_traffic.json for exactly this (dtype, cells per rank, M); null otherwise
+                # committed profiles/r04_pmc_traffic.json for exactly this (dtype, cells per rank, M); null otherwise
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "traffic_from_committed_profile": traffic is not None,  # a PMC pass of this build, not of this run
