@@ -109,8 +109,7 @@ class HipKernels:
         stage = [torch.empty(chunk, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
         events = [torch.cuda.Event(), torch.cuda.Event()]
         for t in tensors:
-            out = np.empty(tuple(t.shape), dtype={torch.float64: np.float64, torch.float32: np.float32,
-                                                  torch.int64: np.int64, torch.uint8: np.uint8}[t.dtype])
+            out = np.empty(tuple(t.shape), dtype=torch.empty(0, dtype=t.dtype).numpy().dtype)
             flat_d = t.view(-1).view(torch.uint8)
             flat_h = out.reshape(-1).view(np.uint8)
             nb = flat_d.numel()

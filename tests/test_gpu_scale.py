@@ -500,6 +500,54 @@ def test_pivot_mode_against_the_oracle(st, case, dtype):
     torch.cuda.empty_cache()
 
 
+def _pivot_two_rank_worker(rank, world, port, out_dir):
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    for p in (root, os.path.join(root, "spateo-release_amd"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks on cuda:0 (RCCL refuses that; gloo does not)
+    try:
+        import spateo_amd as st
+        from spateo_amd._synthetic import make_config
+
+        X, V, _ = make_config("C3", N=20_000)
+        kw = dict(M=2000, lambda_=0.02, lstsq_method="scipy", MaxIter=10, ecr=0.0, seed=0)
+        got = st.SparseVFC(X, V, None, dtype="float64", device="cuda:0", distributed=True, gather="all",
+                           gram_mode="pivot", **kw)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), V=got["V"], P=got["P"], C=got["C"], sigma2=got["sigma2"],
+                 E=got["E_traj"], iteration=got["iteration"], subset=got["ctrl_subset"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pivot_mode_with_two_ranks_sharing_one_gpu(st, tmp_path):
+    """gram_mode="pivot" with the cells sharded over two processes (real kernels, gloo collectives on device tensors): both
+    ranks read the same pivot order off their bit-identical all-reduced system, rebuild the same restricted model, pass the
+    per-step agreement check and end bit-identical - at the pivot mode's distance from the oracle (20 k x 2000 fixture)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_pivot_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in ("V", "P", "C", "sigma2", "E", "subset"):
+        np.testing.assert_array_equal(r0[k], r1[k])
+    X, V, kw, ref, table = _large_m_case(2000, 0.02)
+    assert int(r0["iteration"]) == ref["iteration"] and 2 <= len(r0["subset"]) <= 1500
+    got = dict(V=r0["V"], P=r0["P"], sigma2=float(r0["sigma2"]), E_traj=r0["E"])
+    _pivot_check("2 ranks, 20 k x 2000", "float64", _fixture_devs(got, ref, 1), table, PIVOT_P_SMALL)
+
+
 # ------------------------------------------------------------------------------------------- BASELINE config 5 organ
 @functools.lru_cache(maxsize=None)
 def _c5_case():
