@@ -149,13 +149,17 @@ def main():
     t0 = time.perf_counter()
     seq = [SparseVFC(*o, **kw) for o in organs]
     t_seq = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    par = SparseVFC_many(organs, n_streams=4, **kw)
-    t_par = time.perf_counter() - t0
+    t_pars = []
+    for _ in range(3):  # the first parallel call also pays every thread's first-use costs (kernel objects, workspaces, streams)
+        t0 = time.perf_counter()
+        par = SparseVFC_many(organs, n_streams=4, **kw)
+        t_pars.append(time.perf_counter() - t0)
+    t_par = min(t_pars[1:])
     iters = [int(v["iteration"]) for v in par]
     same = all(np.allclose(a["C"], b["C"], rtol=1e-9, atol=1e-12) for a, b in zip(seq, par))
     r = engine_steps(organs[0][0], organs[0][1], 500, "float32", steps=30)
-    res["C5_4organs_250k_M500_float32"] = dict(sequential_wall_s=t_seq, four_streams_wall_s=t_par, iterations=iters,
+    res["C5_4organs_250k_M500_float32"] = dict(sequential_wall_s=t_seq, four_streams_wall_s=t_par,
+                                               four_streams_first_call_wall_s=t_pars[0], iterations=iters,
                                                identical_to_sequential=bool(same), single_organ=r)
     print("C5", json.dumps(res["C5_4organs_250k_M500_float32"]), flush=True)
 
