@@ -337,10 +337,15 @@ class SparseVFCEngine:
         # sigma^2 has nearly converged, the subset fits the final system (and is a third smaller): sigma^2 / energy
         # 0.1 - 1.1 x, field 0.9 - 1.5 x
         self.pivot_after = 3
-        if isinstance(gram_mode, str) and gram_mode.startswith("pivot:") and gram_mode[6:].isdigit() and int(gram_mode[6:]) >= 1:
-            gram_mode, self.pivot_after = "pivot", int(gram_mode[6:])
+        self.pivot_nested = False        # "pivot:K+": keep restricting while the restricted factor still sheds control points
+        if isinstance(gram_mode, str) and gram_mode.startswith("pivot:"):
+            spec = gram_mode[6:]
+            nested = spec.endswith("+")
+            spec = spec[:-1] if nested else spec
+            if spec.isdigit() and int(spec) >= 1:
+                gram_mode, self.pivot_after, self.pivot_nested = "pivot", int(spec), nested
         if gram_mode not in ("full", "pivot"):
-            raise ValueError("gram_mode must be 'full', 'pivot' or 'pivot:K' (K >= 1)")
+            raise ValueError("gram_mode must be 'full', 'pivot', 'pivot:K' or 'pivot:K+' (K >= 1)")
         # "pivot" (extension, default off): once the rank-revealing solve has run, the rest of the fit works on the control
         # points its pivoted factorisation selected (`_restrict_to_pivots`)
         self.gram_mode = gram_mode
@@ -447,7 +452,8 @@ class SparseVFCEngine:
         if not hasattr(k, "lr_pivot_order"):
             return False
         p = np.asarray(k.lr_pivot_order(self.M), dtype=np.int64)
-        if len(p) < 2 or len(p) > self.pivot_max_fraction * self.M:
+        limit = self.pivot_max_fraction if self.subset is None else 0.94   # nested: only while >= 6 % more can go
+        if len(p) < 2 or len(p) > limit * self.M:
             return False
         # The Gram kernel works in 128-wide tile columns: a subset that ends just behind a tile boundary pays for a whole
         # column of tile pairs (897 control points = 8 columns, 36 pairs; 896 = 7 columns, 28 pairs).  The pivots come in
@@ -461,11 +467,12 @@ class SparseVFCEngine:
         for g in range(self.ng):
             k.quadform(self.K, self.C[g], self.quad[g : g + 1])
         self._quad_carry = float(self.quad.cpu().sum())
-        self.subset = p
-        self._setup_control_points(self.ctrl_full[p])
+        self.subset = p if self.subset is None else self.subset[p]
+        self._setup_control_points(self.ctrl_full[self.subset])
         self._build_u_cache()
         self.rank_hint, self.basis, self.basis_valid = 0, None, False
         self.mn_method = "lowrank" if hasattr(k, "solve_minnorm_lr") else self.mn_method
+        self.solver_stats.setdefault("pivot_subsets", []).append(int(len(p)))
         self.solver_stats["pivot_subset"] = int(len(p))
         return True
 
@@ -583,7 +590,7 @@ class SparseVFCEngine:
         g = s_cnt / self.n_total
         self.gamma = 0.95 if g > 0.95 else (0.05 if g < 0.05 else g)
         self.iteration += 1
-        if self.gram_mode == "pivot" and self.subset is None and self._lr_ran:
+        if self.gram_mode == "pivot" and self._lr_ran and (self.subset is None or self.pivot_nested):
             self._lr_iterations += 1
             if self._lr_iterations >= self.pivot_after:
                 self._restrict_to_pivots()

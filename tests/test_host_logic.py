@@ -792,6 +792,15 @@ def test_pivot_mode_continues_on_the_selected_control_points(cpu_kernels, monkey
     assert _rel(piv["V"], full["V"]) < 3e-2 and abs(piv["sigma2"] / full["sigma2"] - 1) < 3e-2
     assert piv["iteration"] == full["iteration"] == 7
     assert np.all(np.isfinite(piv["E_traj"])) and np.abs(piv["E_traj"] / full["E_traj"] - 1).max() < 3e-2
+    # "pivot:K" switches after K rank-revealing iterations, "pivot:K+" keeps restricting while the restricted factor still
+    # sheds >= 6 % of its control points: nested subsets, composed into indices of the full control-point set
+    nest = st.SparseVFC(X, V, X[:40], gram_mode="pivot:1+", **kw)
+    ns = nest["ctrl_subset"]
+    assert len(set(ns.tolist())) == len(ns) and ns.max() < 120 and len(ns) <= len(sub) + 30
+    assert np.all(nest["C"][np.setdiff1d(np.arange(120), ns)] == 0.0)
+    np.testing.assert_allclose(svo.con_K(Xv, nest["X_ctrl"], nest["beta"]) @ nest["C"], nest["V"], rtol=0,
+                               atol=1e-9 * np.abs(nest["V"]).max())
+    assert _rel(nest["V"], full["V"]) < 3e-2
     # well-regularised system (the factor keeps every control point): no switch
     reg = st.SparseVFC(X, V, None, gram_mode="pivot", **dict(kw, lambda_=3.0, M=40, beta=None))
     assert "ctrl_subset" not in reg

@@ -14,7 +14,7 @@ import spateo_amd as st  # noqa: E402
 import test_gpu_scale as T  # noqa: E402
 
 cases = sys.argv[1].split(",") if len(sys.argv) > 1 else ["c4_200k", "m3000_20k", "m2000_20k"]
-Ks = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "1,2,3,4".split(","))]
+Ks = sys.argv[2].split(",") if len(sys.argv) > 2 else "1,2,3,4".split(",")
 out = []
 for case in cases:
     if case == "c4_200k":
