@@ -479,7 +479,7 @@ def test_two_ranks_sharing_one_gpu_match_the_oracle(st, tmp_path, case):
 def test_four_ranks_sharing_one_gpu_minimum_norm_path(st, tmp_path):
     """4 ranks (all on cuda:0, gloo collectives), lambda_ = 0.02: the system goes numerically rank deficient, every rank
     runs the minimum-norm eigensolver redundantly on the all-reduced Gram system and the per-step agreement check
-    (SparseVFCEngine._agree) passes on every step; all ranks end bit-identical and at the reference's floor."""
+    (SparseVFCEngine._finish_step) passes on every step; all ranks end bit-identical and at the reference's floor."""
     import socket
 
     import _floors as F

@@ -322,3 +322,25 @@ def test_stream_fixture_writer_plumbing():
     assert out["sigma2"] == out["sigma2_traj"][-1]
     for q in ("V", "sigma2", "P", "E"):
         assert out[f"floor_{q}"] == max(out[f"var_eigh_{q}"], out[f"var_sumorder_{q}"]) and 0 < out[f"floor_{q}"] < 1e-3
+
+
+def test_the_reference_noise_floor_is_not_a_builder_artifact():
+    """The yardstick of the parity tests - how far the float64 oracle moves under changes that leave its mathematics untouched
+    (tests/_floors.py: LAPACK driver -> truncated eigh; Gram summed in pieces) - against a witness that contains no code of
+    this repository at all: ``scipy.linalg.lstsq(..., lapack_driver="gelss")``, LAPACK's other SVD least-squares driver with
+    the same minimum-norm semantics and the same eps cut-off.  On a numerically rank-deficient case the three move the
+    field by the same order of magnitude (measured here 4.6e-6 / 4.0e-6 / 2.7e-6; at 20 k x 2000, lambda_ = 0.02, 10 iterations:
+    gelss 1.37e-3 where the asserted floor is 2.5e-3 - i.e. swapping one LAPACK driver for the other inside the reference
+    itself already exceeds north_star's 1e-5 by two orders of magnitude)."""
+    import _floors as F
+    from spateo_amd._synthetic import make_config
+
+    X, V, _ = make_config("C3", N=4000)
+    kw = dict(M=300, lambda_=0.02, lstsq_method="scipy", MaxIter=8, ecr=0.0, seed=0)
+    ref = F.oracle_fit(X, V, None, **kw)
+    dev = {v: F.deviations(F.oracle_fit(X, V, None, variant=v, **kw), ref) for v in ("gelss", "eigh", "sumorder")}
+    print({v: {q: f"{x:.2e}" for q, x in d.items()} for v, d in dev.items()})
+    for q in ("V", "P"):
+        floor = max(dev["eigh"][q], dev["sumorder"][q])
+        assert dev["gelss"][q] > 1e-7                      # LAPACK's own driver swap moves the reference visibly
+        assert 0.2 < floor / dev["gelss"][q] < 5.0, (q, floor, dev["gelss"][q])   # the asserted floor measures the same thing
