@@ -1,0 +1,40 @@
+"""bench.py's output contract on a small workload (subprocess, one GPU): ONE JSON line on stdout with the driver's keys, the
+`roofline` and `cpu_baseline` objects of this tier, and this repository's extras (`parity`, `f64`, `pivot_subset`, `env`)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_contract():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--cells", "150000",
+           "--ctrl", "1100", "--cpu-cells", "6000", "--no-conk"]
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MVF_")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str)):
+        assert isinstance(d[key], typ), key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["cells"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert 0.0 < r["frac"] < 1.0 and "traffic" in r and r["avg_kernel_ms"] * 0.999 <= d["ms_per_step"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "cells/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    par = d["parity"]
+    assert par["em_steps"] == 10 and set(par["f64"]) >= {"V_rel_err", "sigma2_rel_err", "P_max_abs_err", "E_rel_err"}
+    assert par["f64"]["V_rel_err"] < max(2.0 * par["floor"]["V"], 1e-5) and par["f32"]["V_rel_err"] < max(2.0 * par["floor"]["V"], 1e-3)
+    assert d["f64"]["dtype"] == "f64" and d["f64"]["value"] > 0
+    assert d["env"] == {} and d["developer_options"] == {}
+    pv = d["pivot_subset"]
+    assert pv["value"] > 0 and pv["ctrl_used"] <= 1100 and "NOT" in pv["note"].upper()
