@@ -233,9 +233,11 @@ int mvf_solve_minnorm_lr(const double* G, const double* K, double lambda_sigma2,
 /* The pivot order of the factorisation the last mvf_solve_minnorm_lr call left in `workspace` (same m): order_out (HOST,
  * room for m ints) receives the r pivots in the order they were taken, *r_out = r.  These are the control points that
  * carry the numerical rank of  U^T P U + lambda sigma^2 K;  the host's optional "pivot" Gram mode restricts the rest of
- * a fit to them.  Synchronises `stream`. */
-int mvf_lr_pivot_order(const void* workspace, size_t workspace_bytes, int64_t m, int* order_out, int64_t* r_out,
-                       void* stream);
+ * a fit to them.  pivots_out (HOST, m float64, may be NULL): the diagonal value each pivot had when it was taken (falling,
+ * the last ones at the stopping tolerance); tol_out (HOST, may be NULL): that tolerance, tolf * eps * lambda_max.
+ * Synchronises `stream`. */
+int mvf_lr_pivot_order(const void* workspace, size_t workspace_bytes, int64_t m, int* order_out, double* pivots_out,
+                       double* tol_out, int64_t* r_out, void* stream);
 
 /* diag_out[n] = (U pinv(A) U^T)_nn, U = con_K(x, ctrl, beta), with the decomposition of A that the previous
  * mvf_solve_minnorm_lr (lowrank != 0) / mvf_solve_minnorm (lowrank == 0) call left in `workspace` (same m, same rcond

@@ -1634,8 +1634,8 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
     return 0;
 }
 
-extern "C" int mvf_lr_pivot_order(const void* workspace, size_t workspace_bytes, int64_t m, int* order_out, int64_t* r_out,
-                                  void* stream) {
+extern "C" int mvf_lr_pivot_order(const void* workspace, size_t workspace_bytes, int64_t m, int* order_out, double* pivots_out,
+                                  double* tol_out, int64_t* r_out, void* stream) {
     MVF_REQUIRE(m > 0 && workspace && order_out && r_out, "mvf_lr_pivot_order: bad arguments");
     const LrPlan p = lr_plan(m);
     MVF_REQUIRE(workspace_bytes >= p.total, "mvf_lr_pivot_order: not the workspace of mvf_solve_minnorm_lr for this m");
@@ -1646,7 +1646,10 @@ extern "C" int mvf_lr_pivot_order(const void* workspace, size_t workspace_bytes,
     MVF_CHECK_HIP(hipStreamSynchronize(st));
     MVF_REQUIRE(hs.magic == PCHOL_MAGIC && hs.r >= 0 && hs.r <= m, "mvf_lr_pivot_order: the workspace holds no finished factorisation");
     MVF_CHECK_HIP(hipMemcpyAsync(order_out, ws + p.off_order, (size_t)hs.r * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (pivots_out)
+        MVF_CHECK_HIP(hipMemcpyAsync(pivots_out, ws + p.off_piv, (size_t)hs.r * sizeof(double), hipMemcpyDeviceToHost, st));
     MVF_CHECK_HIP(hipStreamSynchronize(st));
+    if (tol_out) *tol_out = hs.tol;
     *r_out = hs.r;
     return 0;
 }

@@ -344,17 +344,23 @@ class HipKernels:
                                                  self._lr_ws.numel(), self._stream()), "mvf_solve_minnorm_lr")
 
     @_on_device
-    def lr_pivot_order(self, m):
-        """Host int array: the pivots (control-point indices, in the order taken) of the last solve_minnorm_lr call."""
+    def lr_pivot_order(self, m, with_values=False):
+        """Host int array: the pivots (control-point indices, in the order taken) of the last solve_minnorm_lr call; with
+        with_values also (the diagonal value of each pivot when it was taken, the stopping tolerance)."""
         import ctypes
 
         if self._lr_ws is None:
             raise RuntimeError("lr_pivot_order without a previous solve_minnorm_lr")
         order = (ctypes.c_int * int(m))()
+        vals = (ctypes.c_double * int(m))()
+        tol = ctypes.c_double(0.0)
         r = ctypes.c_int64(0)
-        _lib.check(self.lib.mvf_lr_pivot_order(_ptr(self._lr_ws), self._lr_ws.numel(), int(m), order, ctypes.byref(r),
-                                               self._stream()), "mvf_lr_pivot_order")
-        return np.frombuffer(order, dtype=np.int32, count=int(r.value)).astype(np.int64)
+        _lib.check(self.lib.mvf_lr_pivot_order(_ptr(self._lr_ws), self._lr_ws.numel(), int(m), order, vals, ctypes.byref(tol),
+                                               ctypes.byref(r), self._stream()), "mvf_lr_pivot_order")
+        idx = np.frombuffer(order, dtype=np.int32, count=int(r.value)).astype(np.int64)
+        if with_values:
+            return idx, np.frombuffer(vals, dtype=np.float64, count=int(r.value)).copy(), float(tol.value)
+        return idx
 
     @_on_device
     def minnorm_basis(self, m):

@@ -62,7 +62,8 @@ SIGNATURES = {
     "mvf_solve_minnorm_basis_bytes": (_sz, [_i64]),
     "mvf_solve_minnorm_lr_workspace_bytes": (_sz, [_i64, _i]),
     "mvf_solve_minnorm_lr": (_i, [_p, _p, _d, _d, _d, _p, _i64, _i, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
-    "mvf_lr_pivot_order": (_i, [_p, _sz, _i64, C.POINTER(C.c_int), C.POINTER(C.c_int64), _p]),
+    "mvf_lr_pivot_order": (_i, [_p, _sz, _i64, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                C.POINTER(C.c_int64), _p]),
     "mvf_pinv_diag": (_i, [_p, _i64, _p, _i64, _d, _d, _i, _p, _p, _sz, _i, _p]),
     "mvf_lincomb3": (_i, [_p, _d, _p, _d, _p, _d, _p, _i64, _p]),
     "mvf_quadform": (_i, [_p, _p, _i64, _i, _p, _p, _p]),

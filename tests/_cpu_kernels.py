@@ -149,7 +149,7 @@ class CpuKernels:
             L = np.zeros((m, m))
             used = np.zeros(m, bool)
             r = 0
-            order = []
+            order, pvals = [], []
             while r < m:
                 dm = np.where(used, -np.inf, dg)
                 p = int(np.argmax(dm))
@@ -163,8 +163,10 @@ class CpuKernels:
                     dg -= c * c
                 used[p] = True
                 order.append(p)
+                pvals.append(float(dm[p]))
                 r += 1
             self._order = np.array(order, dtype=np.int64)
+            self._pivot_values, self._pivot_tol = np.array(pvals), float(tol)
             u, s, _ = np.linalg.svd(L[:, :r], full_matrices=False) if r else (np.zeros((m, 0)), np.zeros(0), None)
             self._lr = (u, s * s, r)
         u, lam, r = self._lr
@@ -182,7 +184,9 @@ class CpuKernels:
             einfo[0] = 1.0
             einfo[6] = float(r)
 
-    def lr_pivot_order(self, m):
+    def lr_pivot_order(self, m, with_values=False):
+        if with_values:
+            return self._order.copy(), self._pivot_values.copy(), self._pivot_tol
         return self._order.copy()
 
     def pinv_diag(self, x4, ctrl4, beta, rcond=None, lowrank=False):
