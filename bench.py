@@ -12,7 +12,7 @@ Rank 0 prints ONE JSON line.  Extra objects: ``roofline`` (dominant kernel = the
 events on its launch stream; ``traffic`` = the PMC figure parsed from the committed ``profiles/r04_pmc_traffic.json``),
 ``solve`` (the coefficient solve: path, Jacobi sweeps, ms, MFMA-tile TFLOP/s), ``f64`` (the SAME workload in float64
 mode - the mode the 1e-5 parity clause is about - with its own roofline; N = 1 only), ``con_k`` (the materialised-kernel
-HBM-write bandwidth), ``cpu_baseline`` (the float64 NumPy oracle on the host cores at N_cpu = 200 k and 100 k cells; its
+HBM-write bandwidth), ``eval`` (the fused evaluator kernel and the wall time of Jacobian + curl on a 64^3 grid at the API), ``cpu_baseline`` (the float64 NumPy oracle on the host cores at N_cpu = 200 k and 100 k cells; its
 ``value`` is the rate its fitted t(N) = a N + b gives at the bench's own cell count; N = 1 only) and ``parity`` (the GPU
 engine, float64 and float32, on exactly the 100 k-cell arrays of that CPU sample against the oracle's field after the
 same 10 EM iterations, with the oracle's own lstsq-vs-eigh noise floor beside it; N = 1 only).
@@ -503,7 +503,8 @@ def main():
 
     # ---------------------------------------------------------------- con_K HBM bandwidth (N = 1, rank 0)
     if rank == 0 and world == 1 and not args.no_conk:
-        nk, mk = 2_000_000, 2000  # BASELINE config 3: con_K roofline run (16 GB of float32 output)
+        # BASELINE config 3: con_K roofline run (16 GB of float32 output); clipped to the workload when a developer run is smaller
+        nk, mk = min(2_000_000, len(Xv)), min(2000, len(ctrl))
         xs = torch.from_numpy((Xv[:nk] - ctrl.mean(0)).astype(np.float32)).to(device)
         cs = torch.from_numpy((ctrl[:mk] - ctrl.mean(0)).astype(np.float32)).to(device)
         kf = HipKernels(device, "float32")
@@ -532,6 +533,46 @@ def main():
         out["con_k"] = {"n": nk, "m": mk, "dtype": "f32", "ms": ms, "algorithmic_bytes": nbytes,
                         "GBps": nbytes / (ms * 1e-3) / 1e9, "peak_GBps": PEAK_HBM_GBPS,
                         "frac": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, "bound": "hbm (write)"}
+
+    # ---------------------------------------------------------------- evaluator path (N = 1, rank 0): BASELINE config 2's shape
+    if rank == 0 and world == 1 and not args.no_conk:
+        from spateo_amd import _lib as _l
+        from spateo_amd.vectorfield import SvcVectorField, _EVAL_ALL, clear_eval_cache
+
+        me = 500  # Jacobian + curl on a 64^3 grid against 500 control points (the kernel's rate does not depend on C)
+        rng = np.random.default_rng(0)
+        lo_b, hi_b = Xv[:100_000].min(0), Xv[:100_000].max(0)
+        grid = np.stack([g_.ravel() for g_ in np.meshgrid(*[np.linspace(lo_b[c_], hi_b[c_], 64) for c_ in range(3)],
+                                                         indexing="ij")], axis=1)
+        vfd = {"X_ctrl": ctrl[:me], "C": rng.standard_normal((me, 3)), "beta": float(beta)}
+        out["eval"] = {"grid_points": len(grid), "ctrl": me, "pairs": len(grid) * me}
+        for dt in ("float32", "float64"):
+            vf = SvcVectorField(dtype=dt, device=device)
+            vf.vf_dict = vfd
+            walls = []
+            for _ in range(5):
+                clear_eval_cache()
+                torch.cuda.synchronize()
+                t_e = time.perf_counter()
+                vf.get_Jacobian()(grid)
+                vf.compute_curl(X=grid)
+                walls.append(1e3 * (time.perf_counter() - t_e))
+            ke = HipKernels(device, dt)
+            cen = vfd["X_ctrl"].mean(0)
+            x4e, c4e = ke.to_x4(grid, cen), ke.to_x4(vfd["X_ctrl"], cen)
+            Cd = torch.from_numpy(np.ascontiguousarray(vfd["C"])).to(device)
+            ke.eval(x4e, c4e, float(beta), Cd, _EVAL_ALL)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ke.eval(x4e, c4e, float(beta), Cd, _EVAL_ALL)
+            e1.record()
+            torch.cuda.synchronize()
+            kms = e0.elapsed_time(e1) / 20
+            out["eval"][dt] = {"kernel_ms_all_quantities": kms, "Gpairs_per_s": len(grid) * me / kms / 1e6,
+                               "jacobian_plus_curl_api_wall_ms": float(np.median(walls[1:])),
+                               "first_call_api_wall_ms": walls[0]}
+        clear_eval_cache()
 
     # ---------------------------------------------------------------- CPU baseline (N = 1, rank 0, bounded sample)
     if rank == 0 and world == 1 and args.cpu_cells > 0:

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_contract():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--cells", "150000",
-           "--ctrl", "1100", "--cpu-cells", "6000", "--no-conk"]
+           "--ctrl", "1100", "--cpu-cells", "6000"]
     env = {k: v for k, v in os.environ.items() if not k.startswith("MVF_")}
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -36,5 +36,9 @@ def test_bench_line_contract():
     assert par["f64"]["V_rel_err"] < max(2.0 * par["floor"]["V"], 1e-5) and par["f32"]["V_rel_err"] < max(2.0 * par["floor"]["V"], 1e-3)
     assert d["f64"]["dtype"] == "f64" and d["f64"]["value"] > 0
     assert d["env"] == {} and d["developer_options"] == {}
+    assert d["con_k"]["bound"].startswith("hbm") and 0 < d["con_k"]["frac"] < 1
+    ev = d["eval"]
+    assert ev["grid_points"] == 64**3 and ev["float32"]["kernel_ms_all_quantities"] < 5.0
+    assert ev["float64"]["jacobian_plus_curl_api_wall_ms"] < 100.0
     pv = d["pivot_subset"]
     assert pv["value"] > 0 and pv["ctrl_used"] <= 1100 and "NOT" in pv["note"].upper()
