@@ -523,13 +523,14 @@ class SparseVFCEngine:
         self.rank_deficient = False
         self.basis_valid = False
         self.rank_hint = 0
-        self._lr_ran, self._lr_iterations = False, 0
+        self._lr_ran, self._lr_iterations, self._spr_spec = False, 0, None
 
-    def _apply_all(self, ctrl4):
+    def _apply_all(self, ctrl4, C=None):
         """V_g = U C_g for every column group; r = sum_g ||Y_g - V_g||^2; spr += sum P r."""
         k = self.k
+        C = self.C if C is None else C
         for g in range(self.ng):
-            self.V4[g], rg = k.apply(self.x4, ctrl4, self.beta, self.C[g], self.y4[g], self.P, self.spr)
+            self.V4[g], rg = k.apply(self.x4, ctrl4, self.beta, C[g], self.y4[g], self.P, self.spr)
             if g == 0:
                 self.r = rg
             else:
@@ -572,7 +573,9 @@ class SparseVFCEngine:
             self._wait(big)
             k.sym_unpack(self.tri, self.G)
         host = self._solve_all(lambda_ * self.sigma2)
-        self.fin.zero_()
+        spec = self._spr_spec   # not None: the Cholesky branch already applied the new coefficients (see _solve_all_local)
+        if spec is None:
+            self.fin.zero_()
         if host is not None:
             s_pr, s_p, s_pf, s_cnt = (float(host[i]) for i in range(4))
             quad = float(sum(host[5:]))
@@ -584,8 +587,9 @@ class SparseVFCEngine:
             self.E = E
             self.C, self.C_new = self.C_new, self.C
             # ---- field + sigma^2 + gamma
-            self._apply_all(self.ctrl4)
-        spr = self._finish_step()
+            if spec is None:
+                self._apply_all(self.ctrl4)
+        spr = spec if spec is not None else self._finish_step()
         self.sigma2 = spr / (s_pf * self.Dy)
         g = s_cnt / self.n_total
         self.gamma = 0.95 if g > 0.95 else (0.05 if g < 0.05 else g)
@@ -642,7 +646,7 @@ class SparseVFCEngine:
         rank-revealing / full-width, retries, sweeps) - the kernels are deterministic, so they do.  That is VERIFIED every
         step (`_finish_step`): the signature of this rank's solver decisions, or its failure, travels in the step's last
         collective; here a failure is only recorded (returns None) so that this rank still takes part in it."""
-        self._step_error, self._solver_signature, self._lr_ran = None, (0.0,) * 6, False
+        self._step_error, self._solver_signature, self._lr_ran, self._spr_spec = None, (0.0,) * 6, False, None
         if self.world == 1:
             return self._solve_all_local(ls2)
         try:
@@ -717,7 +721,15 @@ class SparseVFCEngine:
                     Z = Ccat[:, 3 * len(gs):]
                 else:
                     self._solve_batch(gs, lambda R, C: k.solve(self.G, self.K, ls2, 0.0, R, C, self.info, None))
-            h = self._host_stats(self.info, self.pivots, Z)
+            # Single rank: the field update with the NEW coefficients is enqueued speculatively, so that its sum P r comes back
+            # in the same device -> host copy as the certificate - one host round trip per EM iteration instead of two in the
+            # regime of Spateo's stock call (M = 100: full rank certified in every iteration).  If the certificate fails the
+            # truncated solve below recomputes C_new and em_step applies it again.
+            spec = self.world == 1
+            if spec:
+                self.fin.zero_()
+                self._apply_all(self.ctrl4, self.C_new)
+            h = self._host_stats(self.info, self.pivots, Z, *([self.spr] if spec else []))
             nz = Z.numel()
             z = h[3 : 3 + nz].numpy().reshape(self.M, -1)
             with np.errstate(all="ignore"):
@@ -727,6 +739,9 @@ class SparseVFCEngine:
             if certified:
                 self.solver_stats["cholesky"] += 1
                 self._solver_signature = (2.0, 0.0, 0.0, float(self.M), 0.0, 0.0)
+                if spec:
+                    self._spr_spec = float(h[3 + nz])
+                    return h[3 + nz + 1:]
                 return h[3 + nz:]
             self.rank_deficient = True
         # truncated minimum-norm solve (gelsd cut-off eps * max|lambda|)
