@@ -100,15 +100,20 @@ def _base_tolerances(dtype, tight=TIGHT):
     return {"V": TOL[dtype], "grid": TOL[dtype], "hull": TOL[dtype], "sigma2": se, "E": se, "P": 10 * TOL[dtype]}
 
 
+P_ALLOW, GRID_ALLOW = 1.75, 1.75
+
+
 def _limits(dtype, table, dev, base):
     """max(1.25 x floor, base tolerance) per quantity.  One explained exception besides the bounding-box grid: P is
     reported as the MAXIMUM over cells of |P_gpu - P_ref|, and P is a logistic function of r / sigma^2 whose slope reaches
     1 / (8 sigma^2) ~ 50 per unit of squared residual for the cells at the inlier / outlier boundary - the statistic is
     set by the single worst boundary cell and scatters more than the field deviation it derives from (measured 0.24 -
-    1.68 x floor while the field of the same runs is 0.44 - 1.02 x): 2 x floor for max |dP|."""
+    1.68 x floor while the field of the same runs is 0.44 - 1.02 x; `profiles/r03_parity_table.md`, `r04_parity_table.md`):
+    1.75 x floor for max |dP| in the 20 k-cell and C2 / C5 cases (2 x until round 3).  At the benchmark's sizes (1 M x 3000,
+    2 M x 2000: `_strict_fixture_check`) P is held to the 1.25 x of every other quantity and measures 0.26 - 0.32 x."""
     lim = {k: F.tol(dtype, table, k, base[k]) for k in dev}
     if "P" in lim:
-        lim["P"] = max(2.0 * table["P"][0 if dtype == "float64" else 1], base["P"])
+        lim["P"] = max(P_ALLOW * table["P"][0 if dtype == "float64" else 1], base["P"])
     return lim
 
 
@@ -123,8 +128,9 @@ def _check_fit(tag, dtype, got, ref, table, in_hull=None, tight=TIGHT):
     if "grid" in lim:
         # the whole bounding-box grid reaches far outside the data hull (its corners are ~1.7 hull radii out): there grid_V is
         # extrapolation through the ill-determined part of C, and a deviation of the field ON the data is amplified by a
-        # case-dependent factor - 2 x floor for this one quantity (measured: 0.97 - 1.67 x), 1.25 x for everything else
-        lim["grid"] = max(2.0 * table["grid"][0 if dtype == "float64" else 1], base["grid"])
+        # case-dependent factor - 1.75 x floor for this one quantity (measured: 0.97 - 1.67 x; 2 x until round 3), 1.25 x for
+        # everything else
+        lim["grid"] = max(GRID_ALLOW * table["grid"][0 if dtype == "float64" else 1], base["grid"])
     fl = {k: table[k][0 if dtype == "float64" else 1] for k in dev}
     print(f"{tag} {dtype}: iterations {got['iteration'] + 1}; " + "; ".join(
         f"{k} gpu {dev[k]:.2e} / floor {fl[k]:.2e} (x{dev[k] / max(fl[k], 1e-300):.2f}, limit {lim[k]:.2e})" for k in dev))
