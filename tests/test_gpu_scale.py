@@ -447,9 +447,9 @@ def test_one_em_iteration_of_the_benchmark_workload_against_the_streamed_oracle(
 # tools/pivot_mode_probe.py -> profiles/r04_pivot_subset.md; float64 / float32 mode, switch after 3 iterations):
 #   field on the cells   <= 1.75 x the reference's own floor         (measured 0.91 - 1.55 x)
 #   sigma^2, energy      <= 1.25 x floor or the mode's base tolerance (measured 0.13 - 1.12 x): as the default mode
-#   P (max |dP|)         <= 1.5 x floor at >= 60 cells per control point (0.81 - 1.22 x); 3.5 x at 10 cells per control
+#   P (max |dP|)         <= 1.75 x floor at >= 60 cells per control point (0.65 - 1.46 x); 3.5 x at 10 cells per control
 #                        point (0.5 - 3.05 x; the default mode itself measures 1.68 x there in float32 mode)
-PIVOT_V, PIVOT_P_LARGE, PIVOT_P_SMALL = 1.75, 1.5, 3.5
+PIVOT_V, PIVOT_P_LARGE, PIVOT_P_SMALL = 1.75, 1.75, 3.5
 
 
 def _pivot_check(tag, dtype, dev, table, allow_p):
