@@ -23,7 +23,7 @@ static void run(int64_t n, int64_t m, mvf_dtype dt) {
     const double beta = 2.7e-6;
     if (mvf_ublk_build(x, n, c, m, beta, ub, ubb, dt, nullptr)) { printf("build failed: %s\n", mvf_last_error()); return; }
     hipDeviceSynchronize();
-    mvf::GramPlan pl = mvf::make_plan(n, m);
+    mvf::GramPlan pl = mvf::make_plan(n, m, dt);
     printf("n=%lld m=%lld %s: pairs=%d slices=%lld slice_len=%lld jobs=%lld (%.2f rounds) ublk=%.1f GB\n", (long long)n, (long long)m,
            dt == MVF_F32 ? "f32" : "f64", pl.npairs, (long long)pl.nslices, (long long)pl.slice_len,
            (long long)(pl.nslices * pl.npairs), pl.nslices * pl.npairs / (double)mvf::gram_slots(), ubb / 1e9);
