@@ -15,7 +15,8 @@ mode - the mode the 1e-5 parity clause is about - with its own roofline; N = 1 o
 HBM-write bandwidth), ``eval`` (the fused evaluator kernel and the wall time of Jacobian + curl on a 64^3 grid at the API), ``cpu_baseline`` (the float64 NumPy oracle on the host cores at N_cpu = 200 k and 100 k cells; its
 ``value`` is the rate its fitted t(N) = a N + b gives at the bench's own cell count; N = 1 only) and ``parity`` (the GPU
 engine, float64 and float32, on exactly the 100 k-cell arrays of that CPU sample against the oracle's field after the
-same 10 EM iterations, with the oracle's own lstsq-vs-eigh noise floor beside it; N = 1 only).
+same 10 EM iterations, with the oracle's own lstsq-vs-eigh noise floor beside it; N = 1 only) and ``pivot_subset`` (the same
+workload with gram_mode="pivot": an extension that is not the reference's arithmetic and never the headline ``value``).
 """
 from __future__ import annotations
 

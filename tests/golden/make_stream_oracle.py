@@ -12,7 +12,7 @@ the control-point draw and beta, and the reference's own noise floors per quanti
 variants, evaluated on ALL cells): `eigh` (scipy.linalg.lstsq -> truncated symmetric eigendecomposition with the same
 eps cut-off) and `sumorder` (the sums over cells made of a different number of sequential pieces).
 
-    python tests/golden/make_stream_oracle.py c3_full|c4_rank|c4_step     (8 cores: about 25 / 30 / 30 minutes, < 8 GB)
+    python tests/golden/make_stream_oracle.py c3_full|c4_rank|c4_step     (8 cores, round 4: 75 / 75 / 87 minutes, < 8 GB)
 """
 import os
 import sys

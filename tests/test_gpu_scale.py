@@ -5,7 +5,10 @@
 * M = 2000 and M = 3000 control points (the 24 x 24-tile Gram plan, the 47-panel Cholesky, the eigensolver) with
   N = 20 k cells: single EM step and a 10-step fit, lambda_ = 3 and Spateo's default 0.02;
 * one BASELINE config 5 organ at its size (250 k cells x 500);
-* float32 mode vs float64 mode at 1 M x 3000 (the per-rank workload of the 8-GPU run), where the oracle cannot run.
+* the benchmark's own sizes against the STREAMED oracle's fixtures (round 4): one EM iteration at 8 M x 3000, five at
+  1 M x 3000 (one rank's share) and at 2 M x 2000 (BASELINE config 3 at its stated size), every quantity at 1.25 x its floor;
+* the optional pivot-subset mode against the same fixtures, held to its own (documented) limits;
+* float32 mode vs float64 mode at 1 M x 3000 (supplement).
 
 Tolerances (BASELINE.json north_star): field within 1e-5 relative in float64 mode, 1e-3 in float32 mode, wherever the
 reference's own solve is stable.  It rarely is at these sizes: with the 20 %-nearest-neighbour bandwidth rule the
