@@ -67,7 +67,8 @@ int mvf_device_count(int* count);      /* number of visible HIP devices (0 witho
  * call in-tree: spateo/alignment/methods/morpho_class.py:845).  X: n x d float64 row-major (finite).  Outputs (device,
  * caller-allocated for n rows): uid[0..count) = index of the FIRST occurrence of each distinct row, in lexicographic row
  * order; rows[0..count) = those rows; count[0] = number of distinct rows.  Stable LSD radix sort over the columns
- * (rocPRIM's device radix sort and select - library primitives, not hand-written kernels) + run flags + compaction; bit-identical to NumPy for finite input. */
+ * (hand-written from round 4 on: 8-bit passes of per-chunk histograms, a table scan and a ballot-ranked stable scatter;
+ * rounds 2 - 3 called rocPRIM here) + run flags + a ballot-ranked compaction; bit-identical to NumPy for finite input. */
 size_t mvf_unique_rows_workspace_bytes(int64_t n, int d);
 int mvf_unique_rows(const double* X, int64_t n, int d, int64_t* uid, double* rows, int64_t* count, void* workspace,
                     size_t workspace_bytes, void* stream);

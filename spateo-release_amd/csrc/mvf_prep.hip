@@ -6,16 +6,17 @@
 // occurrence; at 8 M cells that is 2-5 s of single-threaded host time.  Here: an LSD pass over the d columns (last
 // column first), each a stable device radix sort of (order-preserving 64-bit image of the double, row index) - stable,
 // so equal rows stay in ascending index order and the first of each run is the first occurrence - then run-start flags
-// and a stream compaction.  The radix sort and the compaction are rocPRIM's device primitives (header-only part of
-// ROCm; this is a one-off O(N) preprocessing step, not a kernel of the EM loop); the key transform, gather, flag and
-// row-gather kernels are this file's.  Bit-identical to np.unique for finite input (-0.0 and +0.0 compare equal there
-// and are given the same key here; the host routes non-finite input to NumPy).
+// and a stream compaction.  Everything is this file's (round 4; rounds 2 - 3 called rocPRIM's device sort / select here):
+//   * radix sort: 8 bits per pass, 8 passes per column.  Per pass: per-workgroup digit histograms of 4096-element chunks
+//     (LDS integer atomics) -> exclusive scan of the [digit][chunk] table (three small launches) -> stable scatter: a
+//     workgroup walks its chunk in sub-tiles of 256 consecutive elements, a lane's rank among the equal digits before it is
+//     a wavefront match (8 ballots) plus the counts of the lower waves;
+//   * compaction: per-chunk flag counts -> the same scan -> ballot-ranked scatter.
+// Bit-identical to np.unique for finite input (-0.0 and +0.0 compare equal there and are given the same key here; the host
+// routes non-finite input to NumPy).
 #include <cstring>
 
 #include "mvf_common.h"
-
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_select.hpp>
 
 namespace mvf {
 
@@ -62,27 +63,251 @@ __global__ __launch_bounds__(256) void prep_gather_rows_kernel(const double* __r
     for (int c = 0; c < d; ++c) rows[i * d + c] = X[uid[i] * d + c];
 }
 
+// ---- hand-written stable LSD radix sort of (uint64 key, int64 value) pairs and flag compaction ----------------------------
+constexpr int RS_BINS = 256;          // 8 bits per pass
+constexpr int RS_CHUNK = 4096;        // elements per workgroup (16 sub-tiles of 256 consecutive elements)
+constexpr int SCAN_SEG = 4096;        // entries per workgroup of the table scan
+
+// hist[bin * nblocks + block] = number of keys of this chunk whose digit is `bin`
+__global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned long long* __restrict__ keys, int64_t n, int shift,
+                                                      int64_t nblocks, unsigned int* __restrict__ hist) {
+    __shared__ unsigned int h[RS_BINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * RS_CHUNK;
+    for (int it = 0; it < RS_CHUNK / 256; ++it) {
+        const int64_t i = i0 + it * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & (RS_BINS - 1)], 1u);  // integer atomics: order-independent result
+    }
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of a uint32 table of L entries, in place, in three launches: segment sums, scan of the segment sums (one
+// workgroup), per-segment exclusive scan shifted by its segment's offset.  Totals stay below 2^32 (n < 2^32 keys).
+__global__ __launch_bounds__(256) void scan_segsum_kernel(const unsigned int* __restrict__ t, int64_t L,
+                                                          unsigned int* __restrict__ segsum) {
+    __shared__ unsigned int red[256];
+    const int64_t i0 = (int64_t)blockIdx.x * SCAN_SEG;
+    unsigned int s_ = 0;
+    for (int k = 0; k < SCAN_SEG / 256; ++k) {
+        const int64_t i = i0 + (int64_t)threadIdx.x * (SCAN_SEG / 256) + k;
+        if (i < L) s_ += t[i];
+    }
+    red[threadIdx.x] = s_;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) segsum[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void scan_segoff_kernel(unsigned int* __restrict__ segsum, int64_t nseg,
+                                                          unsigned int* __restrict__ total) {
+    // one workgroup: exclusive scan of the segment sums (each thread a contiguous range, then a scan of the 256 partials)
+    __shared__ unsigned int part[256];
+    const int64_t per = (nseg + 255) / 256;
+    const int64_t lo = (int64_t)threadIdx.x * per, hi = min(nseg, lo + per);
+    unsigned int s_ = 0;
+    for (int64_t i = lo; i < hi; ++i) s_ += segsum[i];
+    part[threadIdx.x] = s_;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int run = 0;
+        for (int k = 0; k < 256; ++k) {
+            const unsigned int v = part[k];
+            part[k] = run;
+            run += v;
+        }
+        if (total) *total = run;
+    }
+    __syncthreads();
+    unsigned int run = part[threadIdx.x];
+    for (int64_t i = lo; i < hi; ++i) {
+        const unsigned int v = segsum[i];
+        segsum[i] = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(unsigned int* __restrict__ t, int64_t L,
+                                                         const unsigned int* __restrict__ segoff) {
+    __shared__ unsigned int part[256];
+    constexpr int PER = SCAN_SEG / 256;
+    const int64_t i0 = (int64_t)blockIdx.x * SCAN_SEG + (int64_t)threadIdx.x * PER;
+    unsigned int v[PER], s_ = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        v[k] = (i0 + k < L) ? t[i0 + k] : 0u;
+        s_ += v[k];
+    }
+    part[threadIdx.x] = s_;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int run = segoff[blockIdx.x];
+        for (int k = 0; k < 256; ++k) {
+            const unsigned int w = part[k];
+            part[k] = run;
+            run += w;
+        }
+    }
+    __syncthreads();
+    unsigned int run = part[threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (i0 + k < L) t[i0 + k] = run;
+        run += v[k];
+    }
+}
+
+// lanes of this wavefront (among `valid`) that hold the same 8-bit digit as this lane
+__device__ __forceinline__ unsigned long long wave_match8(unsigned int g, bool valid) {
+    unsigned long long mask = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+        const bool one = (g >> bit) & 1u;
+        const unsigned long long b = __ballot(one);
+        mask &= one ? b : ~b;
+    }
+    return mask;
+}
+
+// stable scatter of one pass: element i of the chunk goes to offs[digit][block] + (number of equal digits before it in the
+// chunk).  Sub-tiles of 256 consecutive elements keep the input order: lane order inside a wavefront, wave order inside
+// the sub-tile, sub-tile order inside the chunk.
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned long long* __restrict__ kin,
+                                                         const long long* __restrict__ vin,
+                                                         unsigned long long* __restrict__ kout, long long* __restrict__ vout,
+                                                         int64_t n, int shift, int64_t nblocks,
+                                                         const unsigned int* __restrict__ offs) {
+    __shared__ unsigned int base[RS_BINS];
+    __shared__ unsigned int wcnt[4][RS_BINS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    base[tid] = offs[(int64_t)tid * nblocks + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0;
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * RS_CHUNK;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int it = 0; it < RS_CHUNK / 256; ++it) {
+        const int64_t i = i0 + it * 256 + tid;
+        const bool valid = i < n;
+        const unsigned long long key = valid ? kin[i] : 0ull;
+        const long long val = valid ? vin[i] : 0ll;
+        const unsigned int g = (unsigned int)((key >> shift) & (RS_BINS - 1));
+        const unsigned long long same = wave_match8(g, valid) & (valid ? ~0ull : 0ull);
+        const int rank = __popcll(same & lt);
+        if (valid && rank == 0) wcnt[wave][g] = (unsigned int)__popcll(same);
+        __syncthreads();
+        if (valid) {
+            unsigned int pre = 0;
+            for (int w = 0; w < wave; ++w) pre += wcnt[w][g];
+            const unsigned int pos = base[g] + pre + (unsigned int)rank;
+            kout[pos] = key;
+            vout[pos] = val;
+        }
+        __syncthreads();
+        base[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0;
+        __syncthreads();
+    }
+}
+
+// compaction: cnt[block] = number of set flags of the chunk
+__global__ __launch_bounds__(256) void sel_count_kernel(const unsigned char* __restrict__ flag, int64_t n,
+                                                        unsigned int* __restrict__ cnt) {
+    __shared__ unsigned int red[256];
+    const int64_t i0 = (int64_t)blockIdx.x * RS_CHUNK;
+    unsigned int s_ = 0;
+    for (int it = 0; it < RS_CHUNK / 256; ++it) {
+        const int64_t i = i0 + it * 256 + threadIdx.x;
+        if (i < n) s_ += flag[i] ? 1u : 0u;
+    }
+    red[threadIdx.x] = s_;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cnt[blockIdx.x] = red[0];
+}
+
+// out[offs[block] + (set flags before i in the chunk)] = vals[i] for every set flag (input order kept)
+__global__ __launch_bounds__(256) void sel_scatter_kernel(const long long* __restrict__ vals,
+                                                          const unsigned char* __restrict__ flag, int64_t n,
+                                                          const unsigned int* __restrict__ offs, long long* __restrict__ out) {
+    __shared__ unsigned int wc[4];
+    __shared__ unsigned int run;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) run = offs[blockIdx.x];
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * RS_CHUNK;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int it = 0; it < RS_CHUNK / 256; ++it) {
+        const int64_t i = i0 + it * 256 + tid;
+        const bool f = i < n && flag[i] != 0;
+        const unsigned long long b = __ballot(f);
+        if (lane == 0) wc[wave] = (unsigned int)__popcll(b);
+        __syncthreads();
+        if (f) {
+            unsigned int pre = 0;
+            for (int w = 0; w < wave; ++w) pre += wc[w];
+            out[run + pre + (unsigned int)__popcll(b & lt)] = vals[i];
+        }
+        __syncthreads();
+        if (tid == 0) run += wc[0] + wc[1] + wc[2] + wc[3];
+        __syncthreads();
+    }
+}
+
+__global__ void count_widen_kernel(const unsigned int* __restrict__ total, long long* __restrict__ count) { *count = (long long)*total; }
+
 struct PrepPlan {
-    size_t off_keys_a, off_keys_b, off_idx_a, off_idx_b, off_flag, off_tmp, tmp_bytes, total;
+    int64_t nblocks, L, nseg;
+    size_t off_keys_a, off_keys_b, off_idx_a, off_idx_b, off_flag, off_hist, off_seg, off_cnt, off_total, total;
 };
 
 static PrepPlan prep_plan(int64_t n) {
     PrepPlan p;
-    size_t sort_bytes = 0, sel_bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                    (const long long*)nullptr, (long long*)nullptr, (size_t)n, 0, 64, (hipStream_t)0);
-    (void)rocprim::select(nullptr, sel_bytes, (const long long*)nullptr, (const unsigned char*)nullptr, (long long*)nullptr,
-                          (long long*)nullptr, (size_t)n, (hipStream_t)0);
-    p.tmp_bytes = std::max(sort_bytes, sel_bytes);
+    p.nblocks = cdiv(n, RS_CHUNK);
+    p.L = p.nblocks * RS_BINS;
+    p.nseg = cdiv(p.L, SCAN_SEG);
     size_t o = 0;
     p.off_keys_a = o, o += align_up((size_t)n * 8, 256);
     p.off_keys_b = o, o += align_up((size_t)n * 8, 256);
     p.off_idx_a = o, o += align_up((size_t)n * 8, 256);
     p.off_idx_b = o, o += align_up((size_t)n * 8, 256);
     p.off_flag = o, o += align_up((size_t)n, 256);
-    p.off_tmp = o, o += align_up(p.tmp_bytes, 256);
+    p.off_hist = o, o += align_up((size_t)p.L * 4, 256);
+    p.off_seg = o, o += align_up((size_t)std::max<int64_t>(p.nseg, cdiv(p.nblocks, SCAN_SEG)) * 4 + 4, 256);
+    p.off_cnt = o, o += align_up((size_t)p.nblocks * 4, 256);
+    p.off_total = o, o += 256;
     p.total = o + 256;
     return p;
+}
+
+// exclusive scan of t[0 .. L) in place (segsum: >= cdiv(L, SCAN_SEG) entries of scratch; total: optional, the sum)
+static void exclusive_scan_u32(hipStream_t st, unsigned int* t, int64_t L, unsigned int* segsum, unsigned int* total) {
+    const int64_t nseg = cdiv(L, SCAN_SEG);
+    hipLaunchKernelGGL(scan_segsum_kernel, dim3((unsigned)nseg), dim3(256), 0, st, t, L, segsum);
+    hipLaunchKernelGGL(scan_segoff_kernel, dim3(1), dim3(256), 0, st, segsum, nseg, total);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nseg), dim3(256), 0, st, t, L, segsum);
+}
+
+// stable sort of (keys, vals) by all 64 key bits; result in (*ka, *ia) - the buffers are swapped as the passes go
+static void radix_sort_pairs_u64(hipStream_t st, const PrepPlan& p, int64_t n, unsigned long long*& ka,
+                                 unsigned long long*& kb, long long*& ia, long long*& ib, unsigned int* hist,
+                                 unsigned int* segsum) {
+    for (int shift = 0; shift < 64; shift += 8) {
+        hipLaunchKernelGGL(rs_hist_kernel, dim3((unsigned)p.nblocks), dim3(256), 0, st, ka, n, shift, p.nblocks, hist);
+        exclusive_scan_u32(st, hist, p.L, segsum, nullptr);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3((unsigned)p.nblocks), dim3(256), 0, st, ka, ia, kb, ib, n, shift,
+                           p.nblocks, hist);
+        std::swap(ka, kb);
+        std::swap(ia, ib);
+    }
 }
 
 
@@ -161,18 +386,22 @@ extern "C" int mvf_unique_rows(const double* X, int64_t n, int d, int64_t* uid, 
     long long* ia = (long long*)(ws + p.off_idx_a);
     long long* ib = (long long*)(ws + p.off_idx_b);
     unsigned char* flag = (unsigned char*)(ws + p.off_flag);
-    void* tmp = ws + p.off_tmp;
+    unsigned int* hist = (unsigned int*)(ws + p.off_hist);
+    unsigned int* segsum = (unsigned int*)(ws + p.off_seg);
+    unsigned int* cnt = (unsigned int*)(ws + p.off_cnt);
+    unsigned int* total = (unsigned int*)(ws + p.off_total);
+    MVF_REQUIRE(n < (int64_t)1 << 32, "mvf_unique_rows: more than 2^32 - 1 rows");
     const dim3 grid((unsigned)cdiv(n, 256));
     hipLaunchKernelGGL(prep_iota_kernel, grid, dim3(256), 0, st, ia, n);
     for (int c = d - 1; c >= 0; --c) {  // LSD over the columns: the first column is the primary key
         hipLaunchKernelGGL(prep_keys_kernel, grid, dim3(256), 0, st, X, n, d, c, ia, ka);
-        size_t bytes = p.tmp_bytes;
-        MVF_CHECK_HIP(rocprim::radix_sort_pairs(tmp, bytes, ka, kb, ia, ib, (size_t)n, 0, 64, st));
-        std::swap(ia, ib);
+        radix_sort_pairs_u64(st, p, n, ka, kb, ia, ib, hist, segsum);
     }
     hipLaunchKernelGGL(prep_flags_kernel, grid, dim3(256), 0, st, X, n, d, ia, flag);
-    size_t bytes = p.tmp_bytes;
-    MVF_CHECK_HIP(rocprim::select(tmp, bytes, ia, flag, (long long*)uid, (long long*)count, (size_t)n, st));
+    hipLaunchKernelGGL(sel_count_kernel, dim3((unsigned)p.nblocks), dim3(256), 0, st, flag, n, cnt);
+    exclusive_scan_u32(st, cnt, p.nblocks, segsum, total);
+    hipLaunchKernelGGL(sel_scatter_kernel, dim3((unsigned)p.nblocks), dim3(256), 0, st, ia, flag, n, cnt, (long long*)uid);
+    hipLaunchKernelGGL(count_widen_kernel, dim3(1), dim3(1), 0, st, total, (long long*)count);
     hipLaunchKernelGGL(prep_gather_rows_kernel, grid, dim3(256), 0, st, X, d, (const long long*)uid,
                        (const long long*)count, rows);
     MVF_LAUNCH_CHECK();
