@@ -141,10 +141,14 @@ def sample_by_velocity(V: np.ndarray, n: int, seed: int = 19491001) -> np.ndarra
     (``np.random.seed(seed)``) and draws from it; here the draw comes from a private ``RandomState(seed)`` - the same
     MT19937 stream, so the same indices - and the global RNG is then left in the state dynamo would leave it in, so
     concurrent fits (``SparseVFC_many``) cannot interleave their draws."""
+    return _sample_by_norms(np.linalg.norm(V, axis=1), n, seed)
+
+
+def _sample_by_norms(tmp_V: np.ndarray, n: int, seed: int = 19491001) -> np.ndarray:
+    """The draw of ``sample_by_velocity`` from the row norms themselves (same values in the same order: same indices)."""
     rs = np.random.RandomState(seed)
-    tmp_V = np.linalg.norm(V, axis=1)
     p = tmp_V / np.sum(tmp_V)
-    idx = rs.choice(np.arange(len(V)), size=n, p=p, replace=False)
+    idx = rs.choice(np.arange(len(tmp_V)), size=n, p=p, replace=False)
     with _RNG_LOCK:
         np.random.set_state(rs.get_state())
     return idx
@@ -202,7 +206,9 @@ def _sparsevfc_preprocess(X, Y, M, beta, velocity_based_sampling, seed, device=N
     if velocity_based_sampling:
         # (dynamo seeds the global RNG with `seed` here and sample_by_velocity immediately re-seeds it with its own
         # default, so `seed` has no effect on this branch - SURVEY App. A [VERIFY]; kept as is)
-        idx = sample_by_velocity(Yv[uid], M)
+        # (= sample_by_velocity(Yv[uid], M): the norms are taken row by row BEFORE the gather into sorted-unique order, so
+        # the 8 M-row random gather moves one double per row instead of a whole row - 0.3 of the 0.86 s at 8 M cells)
+        idx = _sample_by_norms(np.linalg.norm(Yv, axis=1)[uid], M)
     else:
         idx = np.random.RandomState(seed=seed).permutation(tmp_X.shape[0])
         idx = idx[range(M)]
