@@ -18,8 +18,9 @@
  *     4 elements (x, y, z, 0) so that one lane loads one cell with a single 16/32-byte access; 2-D data sets z = 0.
  *   - Return value: 0 = ok; non-zero = error, message in mvf_last_error() (thread-local).  No exceptions cross
  *     the boundary.  The Python host raises RuntimeError on a non-zero status.
- *   - State: the library has no global or per-process state (mvf_last_error's thread-local buffer and a per-device
- *     cache of the CU count aside).  Whatever must survive between calls lives in CALLER-provided memory and is named at
+ *   - State: the library has no global or per-process state (mvf_last_error's thread-local buffer, a per-device cache
+ *     of the CU count and the developer options of mvf_debug_option - all at their defaults unless that entry point is
+ *     called - aside), and it never reads the environment.  Whatever must survive between calls lives in CALLER-provided memory and is named at
  *     the entry point that uses it: the workspace of mvf_solve_minnorm_lr keeps the pivot order of its last finished
  *     factorisation (the next call's hint), the workspaces of the two minimum-norm solves keep their decomposition for
  *     `reuse` calls and mvf_pinv_diag, `basis` keeps the eigenvectors of mvf_solve_minnorm for its warm start.  A fresh
