@@ -14,7 +14,9 @@ def _in_hull(p: np.ndarray, hull) -> np.ndarray:
     data.  With a GPU the test runs on the device from the hull's facet equations (``mvf_hull_mask``: a point is inside a
     convex polytope iff it is on the inner side of every facet; tolerance 100 eps x the hull's extent, the scale of
     find_simplex's own barycentric tolerance) - 262 144 grid points x ~2 k facets in well under a millisecond instead of
-    a Delaunay triangulation + point location on the host.  Without a GPU: the reference's own host formulation."""
+    a Delaunay triangulation + point location on the host.  Without a GPU: the reference's own host formulation.  With a GPU but
+    without a built ``libmvf.so`` this raises like every other entry point of the package (no silent host fallback on a GPU box -
+    ADVICE r3 suggested one; the tier's rule is to fail loudly).  Non-finite points are outside, as for ``find_simplex``."""
     import torch
 
     if torch.cuda.is_available():
