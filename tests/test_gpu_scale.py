@@ -103,7 +103,9 @@ def _base_tolerances(dtype, tight=TIGHT):
     return {"V": TOL[dtype], "grid": TOL[dtype], "hull": TOL[dtype], "sigma2": se, "E": se, "P": 10 * TOL[dtype]}
 
 
-P_ALLOW, GRID_ALLOW = 1.75, 1.75
+# (the grid exception carries 10 % of headroom over the measured maximum: the oracle of the C2 cases runs live on the GPU
+# box's host BLAS, whose thread count moves the reference itself by a percent or two between boxes)
+P_ALLOW, GRID_ALLOW = 1.75, 1.85
 
 
 def _limits(dtype, table, dev, base):
@@ -131,7 +133,7 @@ def _check_fit(tag, dtype, got, ref, table, in_hull=None, tight=TIGHT):
     if "grid" in lim:
         # the whole bounding-box grid reaches far outside the data hull (its corners are ~1.7 hull radii out): there grid_V is
         # extrapolation through the ill-determined part of C, and a deviation of the field ON the data is amplified by a
-        # case-dependent factor - 1.75 x floor for this one quantity (measured: 0.97 - 1.67 x; 2 x until round 3), 1.25 x for
+        # case-dependent factor - 1.85 x floor for this one quantity (measured: 0.97 - 1.67 x; 2 x until round 3), 1.25 x for
         # everything else
         lim["grid"] = max(GRID_ALLOW * table["grid"][0 if dtype == "float64" else 1], base["grid"])
     fl = {k: table[k][0 if dtype == "float64" else 1] for k in dev}
