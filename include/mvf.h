@@ -52,12 +52,12 @@ enum {
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
 const char* mvf_last_error(void);
-int mvf_version(void);                 /* ABI version, currently 3 */
+int mvf_version(void);                 /* ABI version, currently 4 */
 /* Developer options, process-wide: which kernel variant / launch plan is taken in A/B measurements and in the tests that
  * compare the variants bit for bit.  The library NEVER reads the environment (rounds 1 - 3 had getenv knobs in launch
  * paths); nothing but this call changes its behaviour.  value 0 = default.  Names: "conk_form" (1 rows, 2 flat, 3 2d),
  * "conk_rows" (rows per workgroup of the rows form), "slice_len" (cells per Gram slice), "solve_small_off" (1: the blocked
- * multi-launch Cholesky at every m), "jac_gram_wgs" (workgroups per Jacobi Gram launch), "lr_timing" (1: phase times of
+ * multi-launch Cholesky at every m), "jac_gram_wgs" (workgroups per Jacobi Gram launch), "lr_no_deflate" (1: mvf_solve_minnorm_lrd always takes the Jacobi path), "lr_timing" (1: phase times of
  * mvf_solve_minnorm_lr on stderr).  Unknown name: non-zero return.  mvf_debug_option_get returns -1 for an unknown name. */
 int mvf_debug_option(const char* name, long long value);
 long long mvf_debug_option_get(const char* name);
@@ -231,6 +231,27 @@ size_t mvf_solve_minnorm_lr_workspace_bytes(int64_t m, int nrhs);
 int mvf_solve_minnorm_lr(const double* G, const double* K, double lambda_sigma2, double tolf, double rcond,
                          const double* R, int64_t m, int nrhs, double* C, int* info, double* einfo, int max_sweeps,
                          int reuse, int rank_hint, void* workspace, size_t workspace_bytes, void* stream);
+
+/* mvf_solve_minnorm_lrd: the same truncated minimum-norm solve (same reference call, same eps * lambda_max cut-off, same
+ * arguments, same pivot-order / rank_hint / reuse behaviour and the same einfo layout as mvf_solve_minnorm_lr) WITHOUT the
+ * eigendecomposition of the whole factor: after the pivoted Cholesky has dropped everything below tolf * eps * lambda_max,
+ * the eigenvalues gelsd truncates are the few smallest ones of S2 = L^T L (r x r) and lie within 1 / tolf of the cut.
+ * S2 = Rc Rc^T (Cholesky; the inverse factor rides along as extra rows), block inverse iteration on 256 vectors started on
+ * the smallest pivots (two applications of S2^-1, Cholesky-QR in between), Rayleigh-Ritz on the 256 x 256 projection (the
+ * Jacobi kernels; einfo[0] = ITS sweeps), W = Ritz vectors with theta <= rcond * lambda_max, Pc = I - W^T W, and
+ *     C = L Pc S2^-1 Pc S2^-1 Pc L^T R
+ * (the projections between the inverse applications keep the amplified rounding error of the dropped directions out).
+ * lambda_max (einfo[2]) is the Rayleigh quotient of 12 power-iteration steps (relative error ~1e-8), einfo[3] the smallest
+ * Ritz value above the cut inside the block.  When the factor has fewer than 512 columns, when more than 224 Ritz values
+ * fall below the cut, or a factorisation meets a non-positive pivot, the call continues on mvf_solve_minnorm_lr's Jacobi
+ * path and returns its result.  Measured at m = 3000 in the EM's steady state (r = 869): 9.0 ms against 22.9 ms, the field
+ * within 1e-6 of the Jacobi path's on the same factor.  The workspace is larger (the r x r scratch); mvf_pinv_diag does not
+ * accept a workspace left by this call (it needs every eigenpair): use mvf_solve_minnorm_lr for that.  No reference
+ * interface changes: this is how `lstsq_solver(lhs, rhs, "scipy")` is evaluated. */
+size_t mvf_solve_minnorm_lrd_workspace_bytes(int64_t m, int nrhs);
+int mvf_solve_minnorm_lrd(const double* G, const double* K, double lambda_sigma2, double tolf, double rcond,
+                          const double* R, int64_t m, int nrhs, double* C, int* info, double* einfo, int max_sweeps,
+                          int reuse, int rank_hint, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The pivot order of the factorisation the last mvf_solve_minnorm_lr call left in `workspace` (same m): order_out (HOST,
  * room for m ints) receives the r pivots in the order they were taken, *r_out = r.  These are the control points that

@@ -523,15 +523,17 @@ __global__ __launch_bounds__(256) void assemble_kernel(const double* __restrict_
     A[i * mp + j] = (i < m && j < m) ? G[i * m + j] + ls2 * K[i * m + j] : 0.0;
 }
 
-// C = A op(B), all n x n row-major (n a multiple of 64), f64 MFMA, 64 x 64 output tile per workgroup, K in stages of 32
-// through LDS.  TB = false: C = A B (B staged k-major);  TB = true: C = A B^T (B staged row-major like A).
+// C (rows x cols, leading dimension ldc) = op(A) op(B) over K, row-major, f64 MFMA, one 64 x 64 output tile per workgroup
+// (grid = cols / 64, rows / 64), K (a multiple of 32) in stages of 32 through LDS.
+//   TA = false: A is rows x K (lda);   TA = true: A is given transposed, K x rows (lda) - C = A^T op(B)
+//   TB = false: B is K x cols (ldb);   TB = true: B is cols x K (ldb)                   - C = op(A) B^T
 constexpr int GK = 32;
 constexpr int GLR = GK + 2;   // row-major stage stride: [64 rows][32 k]
 constexpr int GLK = JP + 16;  // k-major stage stride:   [32 k][64 cols]
-template <bool TB>
-__global__ __launch_bounds__(256) void gemm64_kernel(const double* __restrict__ A, const double* __restrict__ B,
-                                                     double* __restrict__ C, int64_t n) {
-    __shared__ double sa[64 * GLR];
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B,
+                                                   int64_t ldb, double* __restrict__ C, int64_t ldc, int64_t K) {
+    __shared__ double sa[TA ? GK * GLK : 64 * GLR];
     __shared__ double sb[TB ? 64 * GLR : GK * GLK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
@@ -547,22 +549,21 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const double* __restrict__ 
     const int rr = tid >> 2, rc = (tid & 3) * 8;
     const int kr = tid >> 3, kc = (tid & 7) * 8;
     double va[8], vb[8];
-    for (int64_t k0 = 0; k0 < n; k0 += GK) {
-        const double* ap = A + (i0 + rr) * n + k0 + rc;
+    for (int64_t k0 = 0; k0 < K; k0 += GK) {
+        const double* ap = TA ? A + (k0 + kr) * lda + i0 + kc : A + (i0 + rr) * lda + k0 + rc;
 #pragma unroll
         for (int q = 0; q < 8; ++q) va[q] = ap[q];
-        if (TB) {
-            const double* bp = B + (j0 + rr) * n + k0 + rc;
+        const double* bp = TB ? B + (j0 + rr) * ldb + k0 + rc : B + (k0 + kr) * ldb + j0 + kc;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) vb[q] = bp[q];
-        } else {
-            const double* bp = B + (k0 + kr) * n + j0 + kc;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) vb[q] = bp[q];
-        }
+        for (int q = 0; q < 8; ++q) vb[q] = bp[q];
         __syncthreads();  // the previous stage has been consumed
+        if (TA) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) sa[rr * GLR + rc + q] = va[q];
+            for (int q = 0; q < 8; ++q) sa[kr * GLK + kc + q] = va[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sa[rr * GLR + rc + q] = va[q];
+        }
         if (TB) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) sb[rr * GLR + rc + q] = vb[q];
@@ -576,7 +577,8 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const double* __restrict__ 
             double fa[2], fb[2];
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                fa[a] = sa[(wr + a * 16 + li) * GLR + kk + lk];  // A[i][k]
+                fa[a] = TA ? sa[(kk + lk) * GLK + wr + a * 16 + li]   // A^T given: At[k][i]
+                           : sa[(wr + a * 16 + li) * GLR + kk + lk];  // A[i][k]
                 fb[a] = TB ? sb[(wc + a * 16 + li) * GLR + kk + lk]   // B^T: B[j][k]
                            : sb[(kk + lk) * GLK + wc + a * 16 + li];  // B[k][j]
             }
@@ -595,8 +597,15 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const double* __restrict__ 
             for (int r = 0; r < 4; ++r) {
                 const int row = wr + a * 16 + lk + 4 * r;
                 const int col = wc + b * 16 + li;
-                C[(i0 + row) * n + j0 + col] = acc[a][b][r];
+                C[(i0 + row) * ldc + j0 + col] = acc[a][b][r];
             }
+}
+
+template <bool TA, bool TB>
+static void gemm(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                 int64_t rows, int64_t cols, int64_t K) {
+    hipLaunchKernelGGL((gemm_kernel<TA, TB>), dim3((unsigned)(cols / 64), (unsigned)(rows / 64)), dim3(256), 0, st, A, lda, B,
+                       ldb, C, ldc, K);
 }
 
 // Wt[i][:] = Y[i][:] / sigma_i  (row i = eigenvector i);  the zero rows of the padding become unit vectors
@@ -621,8 +630,9 @@ __global__ __launch_bounds__(256) void basis_extract_kernel(const double* __rest
 // kernels want.
 struct PcholState {
     int done, r, panels, hint_broken;  // panels = hint panels accepted so far (the next panel's index)
-    double tol, lmax_est, maxdiag, pad2;
+    double tol, lmax_est, maxdiag, lmax_prev;  // lmax_prev: the Rayleigh quotient one power step earlier
     int panel_nvalid, magic, order_len, pad3;  // magic / order_len: the workspace holds the pivot order of a finished call
+    int defl, defl_block, pad4, pad5;           // defl = 1: the workspace holds the DEFLATED decomposition (mvf_solve_minnorm_lrd)
 };
 
 // y = A x, one wave per row (the power iteration that estimates lambda_max for the stopping tolerance)
@@ -647,7 +657,7 @@ __global__ __launch_bounds__(256) void lr_power_kernel(double* __restrict__ x, c
     if (first) {
         const double v = 1.0 / sqrt((double)m);
         for (int64_t i = threadIdx.x; i < mp; i += 256) x[i] = i < m ? v : 0.0;
-        if (threadIdx.x == 0) stt->lmax_est = 0.0;
+        if (threadIdx.x == 0) stt->lmax_est = stt->lmax_prev = 0.0;
         return;
     }
     double xy = 0.0, yy = 0.0;
@@ -664,7 +674,10 @@ __global__ __launch_bounds__(256) void lr_power_kernel(double* __restrict__ x, c
     __syncthreads();
     const double inv = bc[1] > 0.0 ? 1.0 / sqrt(bc[1]) : 0.0;
     for (int64_t i = threadIdx.x; i < mp; i += 256) x[i] = y[i] * inv;
-    if (threadIdx.x == 0) stt->lmax_est = bc[0];
+    if (threadIdx.x == 0) {
+        stt->lmax_prev = stt->lmax_est;
+        stt->lmax_est = bc[0];
+    }
 }
 
 constexpr int PC_T = 128;  // threads (= columns of A) per workgroup of the pivot step
@@ -1112,11 +1125,110 @@ __global__ __launch_bounds__(PC_T) void pchol_panel_rows_kernel(const double* __
     }
 }
 
+// ================= deflated truncated solve: the gelsd cut-off without the full eigendecomposition ======================
+// The pivoted factor A = L L^T (r columns, rows of Y) has dropped everything below tolf eps lambda_max already, so the
+// eigenvalues of L L^T that gelsd truncates (<= eps lambda_max) are the FEW smallest ones of the r x r matrix S2 = L^T L -
+// about a tenth of r in the EM's systems - and they sit within 1 / tolf of the cut.  Instead of orthogonalising all r
+// columns (Jacobi, ~13 sweeps) only that invariant subspace is computed:
+//   S2 = Rc Rc^T (Cholesky: accurate although cond(S2) ~ 1 / (tolf eps), because the pivoted factor is graded), the
+//   inverse factor rides along as extra rows of the same factorisation, Minv = S2^-1;
+//   block inverse iteration on DEFL_B vectors started on the trailing (smallest pivot) rows: Z <- orth(Minv Z), two
+//   applications; Rayleigh-Ritz H = Z S2 Z^T (DEFL_B x DEFL_B, condition ~ 1e2: a small well-conditioned eigenproblem for
+//   the Jacobi kernels above); W = the Ritz vectors with theta <= rcond lambda_max, Pc = I - W^T W.
+//   C = L Pc Minv Pc Minv Pc L^T R   - the projections BETWEEN the two inverse applications are what keeps the
+//   amplified rounding error of the dropped directions out of the result (subtracting their terms afterwards cancels
+//   catastrophically).  tools/lrproto_partial2.py: field within 4e-7 ... 2e-6 of the exact truncated solve.
+// Falls back to the Jacobi path when more than DEFL_B - DEFL_GUARD Ritz values lie below the cut, when r < 2 DEFL_B or a
+// factorisation meets a non-positive pivot.
+constexpr int DEFL_B = 256;
+constexpr int DEFL_GUARD = 32;
+
+struct DeflBuf {
+    size_t s2, cw, za, zb, wsel, g, h, yh, cwb, ta, tb, cb, dummy, part, theta, total;
+};
+
+static DeflBuf defl_layout(int64_t rp) {
+    DeflBuf d;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o += align_up(bytes, 256);
+        return at;
+    };
+    const size_t b = DEFL_B;
+    d.s2 = take((size_t)rp * rp * sizeof(double));
+    d.cw = take(chol_inv_workspace_bytes(rp));
+    d.za = take(b * rp * sizeof(double));
+    d.zb = take(b * rp * sizeof(double));
+    d.wsel = take(b * rp * sizeof(double));
+    d.g = take(b * b * sizeof(double));
+    d.h = take(b * b * sizeof(double));
+    d.yh = take(b * b * sizeof(double));
+    d.cwb = take(chol_inv_workspace_bytes(b));
+    d.ta = take((size_t)rp * 8 * sizeof(double));
+    d.tb = take((size_t)rp * 8 * sizeof(double));
+    d.cb = take(b * 8 * sizeof(double));
+    d.dummy = take((size_t)std::max<int64_t>(rp, b) * 8 * sizeof(double));
+    d.part = take((size_t)16 * rp * 8 * sizeof(double));
+    d.theta = take(b * sizeof(double));
+    d.total = o;
+    return d;
+}
+
+static size_t defl_scratch_bytes(int64_t mp) { return defl_layout(mp).total; }
+
+// theta_i = ||Yh_i||^2 (rows of the orthogonalised factor of H = sigma_i u_i^T).  Rows with theta <= rcond lambda_max become
+// u_i^T (the directions to deflate), the others zero.  Diagnostics in einfo's layout (see jac_scale_kernel); einfo[4] = the
+// number of deflated directions.
+__global__ __launch_bounds__(256) void defl_select_kernel(const double* __restrict__ theta, int b,
+                                                          const PcholState* __restrict__ stt, double rcond, int64_t r,
+                                                          double* __restrict__ Yh, double* __restrict__ einfo) {
+    __shared__ double red[4];
+    const double lmax = stt->lmax_est, cut = rcond * lmax;
+    {   // this workgroup's rows: blockIdx.x * 4 + wave
+        const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (i < b) {
+            const double t = theta[i];
+            const double g = (!(t > cut) && t > 0.0) ? 1.0 / sqrt(t) : 0.0;
+            for (int c = threadIdx.x & 63; c < b; c += 64) Yh[(int64_t)i * b + c] *= g;
+        }
+    }
+    if (blockIdx.x != 0) return;
+    double nsel = 0.0, mink = INFINITY, minl = INFINITY;
+    for (int i = threadIdx.x; i < b; i += 256) {
+        const double t = theta[i];
+        const bool sel = !(t > cut);
+        nsel += sel ? 1.0 : 0.0;
+        if (!sel) mink = fmin(mink, t);
+        minl = fmin(minl, t);
+    }
+    const double k1 = block_sum<256>(nsel, red);
+    const double k2 = block_min<256>(mink, red);
+    const double k3 = block_min<256>(minl, red);
+    if (threadIdx.x == 0) {
+        einfo[1] = (double)r - k1;
+        einfo[2] = lmax;
+        einfo[3] = k2;
+        einfo[4] = k1;
+        einfo[5] = k3;
+    }
+}
+
+// T[n][d] -= sum over the splits of part[split][n][d]   (the second half of  T -= W^T (W T))
+__global__ __launch_bounds__(256) void defl_sub_kernel(const double* __restrict__ part, int nsplit, int64_t n,
+                                                       double* __restrict__ T) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * 8) return;
+    double s = 0.0;
+    for (int q = 0; q < nsplit; ++q) s += part[(int64_t)q * n * 8 + e];
+    T[e] -= s;
+}
+
 struct LrPlan {
     int64_t mp;
     int nbmax, npmax, nwg, spart_tiles;
     size_t off_s, off_y, off_dg, off_pm, off_x, off_state, off_order, off_piv, off_spart, off_j, off_flags, off_stamps,
-        off_sig2, off_t, off_part, off_rot, off_scal, off_hint, off_lcc, off_cand, total;
+        off_sig2, off_t, off_part, off_rot, off_scal, off_hint, off_lcc, off_cand, total, off_d, total_d;
 };
 
 constexpr int LR_GRAM_WGS = 512;  // upper bound of the workgroups per Jacobi Gram launch (pairs x K splits)
@@ -1156,6 +1268,9 @@ static LrPlan lr_plan(int64_t m) {
     p.off_lcc = take((size_t)64 * 64 * sizeof(double));
     p.off_cand = take(256);
     p.total = o;
+    // scratch of the deflated solve (mvf_solve_minnorm_lrd only; sized for a factor of full width)
+    p.off_d = take(defl_scratch_bytes(p.mp));
+    p.total_d = o;
     return p;
 }
 
@@ -1340,12 +1455,11 @@ extern "C" int mvf_solve_minnorm(const double* G, const double* K, double lambda
     CholPlan cp;
     double* aux = (double*)(ws + p.off_aux);
     MVF_REQUIRE(!warm || basis, "mvf_solve_minnorm: warm start without a basis");
-    const dim3 ggrid((unsigned)(mp / 64), (unsigned)(mp / 64));
     if (warm) {
         hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)cdiv(mp, 256), (unsigned)mp), dim3(256), 0, st, G, K,
                            lambda_sigma2, m, mp, aux);
-        hipLaunchKernelGGL(gemm64_kernel<true>, ggrid, dim3(256), 0, st, aux, basis, Y, mp);   // T1 = A Wt^T
-        hipLaunchKernelGGL(gemm64_kernel<false>, ggrid, dim3(256), 0, st, basis, Y, aux, mp);  // A' = Wt T1
+        gemm<false, true>(st, aux, mp, basis, mp, Y, mp, mp, mp, mp);   // T1 = A Wt^T
+        gemm<false, false>(st, basis, mp, Y, mp, aux, mp, mp, mp, mp);  // A' = Wt T1
         MVF_LAUNCH_CHECK();
         if (int rc = chol_factor_mat(st, aux, mp, shift, m, workspace, &cp, info)) return rc;
     } else if (int rc = chol_factor(st, G, K, lambda_sigma2, shift, nullptr, m, 0, workspace, &cp, info)) {
@@ -1390,7 +1504,7 @@ extern "C" int mvf_solve_minnorm(const double* G, const double* K, double lambda
 
     if (warm) {
         // back to the original coordinates: row i of Y (= sigma_i x eigenvector i of A') -> Y Wt
-        hipLaunchKernelGGL(gemm64_kernel<false>, ggrid, dim3(256), 0, st, Y, basis, aux, mp);
+        gemm<false, false>(st, Y, mp, basis, mp, aux, mp, mp, mp, mp);
         MVF_LAUNCH_CHECK();
         MVF_CHECK_HIP(hipMemcpyAsync(Y, aux, (size_t)mp * mp * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
@@ -1418,10 +1532,9 @@ extern "C" size_t mvf_solve_minnorm_lr_workspace_bytes(int64_t m, int nrhs) {
     return lr_plan(m).total;
 }
 
-extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lambda_sigma2, double tolf, double rcond,
-                                    const double* R, int64_t m, int nrhs, double* C, int* info, double* einfo,
-                                    int max_sweeps, int reuse, int rank_hint, void* workspace, size_t workspace_bytes,
-                                    void* stream) {
+static int lr_solve(const double* G, const double* K, double lambda_sigma2, double tolf, double rcond, const double* R,
+                    int64_t m, int nrhs, double* C, int* info, double* einfo, int max_sweeps, int reuse, int rank_hint,
+                    void* workspace, size_t workspace_bytes, void* stream, bool deflate) {
     MVF_REQUIRE(m >= 0 && nrhs >= 1 && nrhs <= 8,
                 "mvf_solve_minnorm_lr: need m >= 0 and 1 <= nrhs <= 8 (got m=%lld nrhs=%d)", (long long)m, nrhs);
     MVF_REQUIRE(info && einfo, "mvf_solve_minnorm_lr: null info / einfo");
@@ -1436,8 +1549,8 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
     MVF_REQUIRE(m <= 65535 - 64, "mvf_solve_minnorm_lr: m too large (%lld)", (long long)m);
     if (max_sweeps <= 0) max_sweeps = 60;
     const LrPlan p = lr_plan(m);
-    MVF_REQUIRE(workspace && workspace_bytes >= p.total, "mvf_solve_minnorm_lr: workspace too small (%zu < %zu)",
-                workspace_bytes, p.total);
+    MVF_REQUIRE(workspace && workspace_bytes >= (deflate ? p.total_d : p.total),
+                "mvf_solve_minnorm_lr: workspace too small (%zu < %zu)", workspace_bytes, deflate ? p.total_d : p.total);
     char* ws = (char*)workspace;
     double* S = (double*)(ws + p.off_s);
     double* Y = (double*)(ws + p.off_y);
@@ -1479,14 +1592,53 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
         return 0;
     };
 
+    // the deflated truncated solve from (Y, Minv in S, the deflation vectors): C = Y^T Pc Minv Pc Minv Pc (Y R)
+    auto defl_apply = [&](int64_t rp) -> int {
+        const DeflBuf d = defl_layout(rp);
+        char* dw = ws + p.off_d;
+        double *Ta = (double*)(dw + d.ta), *Tb = (double*)(dw + d.tb), *cb = (double*)(dw + d.cb);
+        double *dummy = (double*)(dw + d.dummy), *dpart = (double*)(dw + d.part), *Wsel = (double*)(dw + d.wsel);
+        const double* Minv = S;
+        const int b = DEFL_B;
+        auto project = [&](double* T) {  // T -= Wsel^T (Wsel T)
+            hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, Wsel, (int64_t)b, rp, rp, T, 8,
+                               dummy, cb);
+            hipLaunchKernelGGL(jac_back_kernel, dim3((unsigned)(rp / 64), 4u), dim3(256), 0, st, Wsel, (int64_t)b, rp, rp, cb,
+                               b / 4, dpart);
+            hipLaunchKernelGGL(defl_sub_kernel, dim3((unsigned)cdiv(rp * 8, 256)), dim3(256), 0, st, dpart, 4, rp, T);
+        };
+        auto apply_inv = [&](const double* Tin, double* Tout) {  // Tout = Minv Tin (Minv symmetric: rows dot Tin)
+            hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(rp, 4)), dim3(256), 0, st, Minv, rp, rp, rp, Tin, 8,
+                               dummy, Tout);
+        };
+        hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(rp, 4)), dim3(256), 0, st, Y, rp, mp, m, R, nrhs, dummy, Ta);
+        project(Ta);
+        apply_inv(Ta, Tb);
+        project(Tb);
+        apply_inv(Tb, Ta);
+        project(Ta);
+        const int bsplit = (int)std::min<int64_t>(16, rp / 64);
+        const int rows_per_split = (int)cdiv(rp, bsplit);
+        hipLaunchKernelGGL(jac_back_kernel, dim3((unsigned)cdiv(mp, 64), (unsigned)bsplit), dim3(256), 0, st, Y, rp, mp, m,
+                           Ta, rows_per_split, part);
+        hipLaunchKernelGGL(jac_back_reduce_kernel, dim3((unsigned)cdiv(m * nrhs, 256)), dim3(256), 0, st, part, bsplit, m,
+                           nrhs, C);
+        MVF_LAUNCH_CHECK();
+        return 0;
+    };
+
     if (reuse) {
-        // the workspace still holds the orthogonalised factor of the previous call for this matrix
+        // the workspace still holds the decomposition of the previous call for this matrix
         MVF_CHECK_HIP(hipMemcpyAsync(&hs, stt, sizeof(hs), hipMemcpyDeviceToHost, st));
         MVF_CHECK_HIP(hipStreamSynchronize(st));
         MVF_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
         if (hs.r <= 0) {
             MVF_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)m * nrhs * sizeof(double), st));
             return 0;
+        }
+        if (hs.defl) {
+            MVF_REQUIRE(workspace_bytes >= p.total_d, "mvf_solve_minnorm_lr: reuse of a deflated decomposition needs its workspace");
+            return defl_apply(cdiv(hs.r, 64) * 64);
         }
         return backsolve(cdiv(hs.r, 64) * 64, einfo + 6);
     }
@@ -1496,7 +1648,7 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
                        m, mp, S);
     MVF_CHECK_HIP(hipMemsetAsync(scal, 0, 256, st));
     hipLaunchKernelGGL(lr_power_kernel, dim3(1), dim3(256), 0, st, xv, xv + mp, m, mp, 1, stt);
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < (deflate ? 12 : 8); ++it) {  // the deflated solve takes its cut-off from this estimate
         hipLaunchKernelGGL(lr_symv_kernel, dim3((unsigned)cdiv(mp, 4)), dim3(256), 0, st, S, mp, xv, xv + mp);
         hipLaunchKernelGGL(lr_power_kernel, dim3(1), dim3(256), 0, st, xv, xv + mp, m, mp, 0, stt);
     }
@@ -1559,7 +1711,7 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
         if (hs.done || j >= msteps) break;
         upto = std::min(msteps, upto + (tail_only ? 32 : 128));
     }
-    const int tag[2] = {PCHOL_MAGIC, (int)hs.r};  // this workspace now holds a finished order of hs.r rows
+    const int tag[6] = {PCHOL_MAGIC, (int)hs.r, 0, 0, 0, 0};  // this workspace now holds a finished order of hs.r rows
     MVF_CHECK_HIP(hipMemcpyAsync(&stt->magic, tag, sizeof(tag), hipMemcpyHostToDevice, st));  // (tag lives until the
                                                                                                 // final synchronise)
     const int64_t r = hs.r;
@@ -1574,6 +1726,124 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
     }
     const int64_t rp = cdiv(r, 64) * 64;
     if (rp > r) MVF_CHECK_HIP(hipMemsetAsync(Y + r * mp, 0, (size_t)(rp - r) * mp * sizeof(double), st));
+
+    // 2'. deflated solve: only the invariant subspace below the cut-off is computed (see DEFL_B above)
+    if (deflate && r >= 2 * DEFL_B && debug_opt(DBG_LR_NO_DEFLATE) == 0) {
+        const int b = DEFL_B;
+        const DeflBuf d = defl_layout(rp);
+        char* dw = ws + p.off_d;
+        double *S2 = (double*)(dw + d.s2), *Za = (double*)(dw + d.za), *Zb = (double*)(dw + d.zb);
+        double *Wsel = (double*)(dw + d.wsel), *Gb = (double*)(dw + d.g), *H = (double*)(dw + d.h), *Yh = (double*)(dw + d.yh);
+        double *theta = (double*)(dw + d.theta), *dummy = (double*)(dw + d.dummy);
+        double* Minv = S;  // the assembled matrix is used up: S now holds S2^-1 (rp x rp)
+        MVF_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+        gemm<false, true>(st, Y, mp, Y, mp, S2, rp, rp, rp, mp);  // S2 = L^T L (identity-free zero padding)
+        // the cut-off is rcond x the power iteration's Rayleigh quotient: converged after the 12 steps when lambda_2 /
+        // lambda_1 <~ 0.5 (kernel Gram matrices: 0.45); a clustered top of the spectrum gets more steps, on S2 (same
+        // non-zero eigenvalues as L L^T), until two successive quotients agree to 1e-7 or 512 steps are spent
+        if (!(std::fabs(hs.lmax_est - hs.lmax_prev) <= 1e-7 * hs.lmax_est)) {
+            const double before = hs.lmax_est;
+            PcholState h2 = hs;
+            hipLaunchKernelGGL(lr_power_kernel, dim3(1), dim3(256), 0, st, xv, xv + mp, r, rp, 1, stt);
+            for (int batch = 0; batch < 32; ++batch) {
+                for (int it = 0; it < 16; ++it) {
+                    hipLaunchKernelGGL(lr_symv_kernel, dim3((unsigned)cdiv(rp, 4)), dim3(256), 0, st, S2, rp, xv, xv + mp);
+                    hipLaunchKernelGGL(lr_power_kernel, dim3(1), dim3(256), 0, st, xv, xv + mp, r, rp, 0, stt);
+                }
+                MVF_LAUNCH_CHECK();
+                MVF_CHECK_HIP(hipMemcpyAsync(&h2, stt, sizeof(h2), hipMemcpyDeviceToHost, st));
+                MVF_CHECK_HIP(hipStreamSynchronize(st));
+                if (std::fabs(h2.lmax_est - h2.lmax_prev) <= 1e-7 * h2.lmax_est) break;
+            }
+            const double best[1] = {std::max(before, h2.lmax_est)};  // both are lower bounds of lambda_max
+            MVF_CHECK_HIP(hipMemcpyAsync(&stt->lmax_est, best, sizeof(best), hipMemcpyHostToDevice, st));
+            MVF_CHECK_HIP(hipStreamSynchronize(st));
+        }
+        CholPlan cs, cq;
+        if (int rc = chol_factor_mat_inv(st, S2, rp, r, dw + d.cw, &cs, info, 1)) return rc;
+        const double* E = cs.W + rp * rp;                      // Rc^-T (upper triangular, identity on the padding)
+        gemm<false, true>(st, E, rp, E, rp, Minv, rp, rp, rp, rp);  // Minv = Rc^-T Rc^-1
+        auto orthonormalise = [&](const double* Zin, double* Zout) -> int {  // Cholesky QR on the rows
+            gemm<false, true>(st, Zin, rp, Zin, rp, Gb, b, b, b, rp);
+            if (int rc = chol_factor_mat_inv(st, Gb, b, b, dw + d.cwb, &cq, info, 1)) return rc;
+            gemm<true, false>(st, cq.W + (size_t)b * b, b, Zin, rp, Zout, rp, b, rp, b);  // Lg^-1 Zin
+            return 0;
+        };
+        // inverse iteration, started on the unit vectors of the b smallest pivots: Minv e_j = rows r-b .. r-1 of Minv
+        if (int rc = orthonormalise(Minv + (r - b) * rp, Za)) return rc;
+        gemm<false, false>(st, Za, rp, Minv, rp, Zb, rp, b, rp, rp);
+        // (one Cholesky-QR pass per application leaves the rows orthonormal to ~1e-13: tools/lrproto_partial2.py's
+        // pass-count comparison - the Ritz decision and the projector do not need more)
+        if (int rc = orthonormalise(Zb, Za)) return rc;  // Za = the block
+        // Rayleigh-Ritz: H = Za S2 Za^T, its eigenvectors by the Jacobi kernels on the Cholesky factor of H
+        gemm<false, false>(st, Za, rp, S2, rp, Zb, rp, b, rp, rp);
+        gemm<false, true>(st, Zb, rp, Za, rp, H, b, b, b, rp);
+        if (int rc = chol_factor_mat_inv(st, H, b, b, dw + d.cwb, &cq, info, 0)) return rc;
+        hipLaunchKernelGGL(jac_init_kernel, dim3((unsigned)(b / 64), (unsigned)(b / 64)), dim3(256), 0, st, cq.W, (int64_t)b,
+                           (int64_t)b, Yh);
+        MVF_LAUNCH_CHECK();
+        const int hnb = b / JB, hnp = hnb / 2, hnk = b / 64;
+        const double htol = std::sqrt((double)b) * 2.220446049250313e-16;
+        int* hclean = mod + hnb;
+        MVF_CHECK_HIP(hipMemsetAsync(mod, 0, (size_t)(hnb + (size_t)hnb * hnb) * sizeof(int), st));
+        int hsweeps = 0;
+        unsigned int hrot2 = 1;
+        while (hsweeps < max_sweeps) {
+            MVF_CHECK_HIP(hipMemsetAsync(rot, 0, sizeof(unsigned int), st));
+            for (int rd = 0; rd < hnb - 1; ++rd) {
+                const int stamp = 1 + hsweeps * (hnb - 1) + rd;
+                hipLaunchKernelGGL(jac_gram_kernel, dim3((unsigned)hnp, (unsigned)hnk), dim3(256), 0, st, Yh, (int64_t)b, hnb,
+                                   rd, hnk, 1, mod, hclean, Spart);
+                if (rd == 0)
+                    hipLaunchKernelGGL(jac_eig_kernel<true>, dim3((unsigned)hnp), dim3(EIG_THREADS), 0, st, Spart, hnk, htol,
+                                       hnb, rd, stamp, mod, hclean, Jbuf, flags, rot);
+                else
+                    hipLaunchKernelGGL(jac_eig_kernel<false>, dim3((unsigned)hnp), dim3(EIG_THREADS), 0, st, Spart, hnk, htol,
+                                       hnb, rd, stamp, mod, hclean, Jbuf, flags, rot);
+                hipLaunchKernelGGL(jac_update_kernel, dim3((unsigned)hnp, (unsigned)(b / 64)), dim3(256), 0, st, Yh,
+                                   (int64_t)b, hnb, rd, Jbuf, flags);
+            }
+            MVF_LAUNCH_CHECK();
+            ++hsweeps;
+            MVF_CHECK_HIP(hipMemcpyAsync(&hrot2, rot, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+            MVF_CHECK_HIP(hipStreamSynchronize(st));
+            if (hrot2 == 0) break;
+        }
+        hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, Yh, (int64_t)b, (int64_t)b,
+                           (int64_t)b, R, 0, theta, dummy);
+        hipLaunchKernelGGL(defl_select_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, theta, b, stt, rcond, r, Yh, einfo);
+        gemm<false, false>(st, Yh, b, Za, rp, Wsel, rp, b, rp, b);  // rows = the Ritz vectors to deflate (zero rows else)
+        MVF_LAUNCH_CHECK();
+        if (timing) MVF_CHECK_HIP(hipEventRecord(ev[2], st));
+        if (int rc = defl_apply(rp)) return rc;
+        double he[6];
+        MVF_CHECK_HIP(hipMemcpyAsync(he, einfo, sizeof(he), hipMemcpyDeviceToHost, st));
+        MVF_CHECK_HIP(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, st));
+        MVF_CHECK_HIP(hipStreamSynchronize(st));
+        const bool ok = hinfo == 0 && hrot2 == 0 && he[4] <= (double)(b - DEFL_GUARD) && std::isfinite(he[5]) && he[5] > 0.0;
+        if (timing) {
+            MVF_CHECK_HIP(hipEventRecord(ev[3], st));
+            MVF_CHECK_HIP(hipEventSynchronize(ev[3]));
+            float t01 = 0, t12 = 0, t23 = 0;
+            (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
+            (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
+            (void)hipEventElapsedTime(&t23, ev[2], ev[3]);
+            fprintf(stderr, "[mvf_solve_minnorm_lrd] m %lld rows %lld: factor %.2f ms, subspace %.2f ms (%d sweeps on %d, %d below the cut, info %d)%s, solve %.2f ms\n",
+                    (long long)m, (long long)r, t01, t12, hsweeps, b, (int)he[4], hinfo, ok ? "" : " -> Jacobi path", t23);
+        }
+        if (ok) {
+            const int dtag[2] = {1, b};
+            MVF_CHECK_HIP(hipMemcpyAsync(&stt->defl, dtag, sizeof(dtag), hipMemcpyHostToDevice, st));
+            const double hsw[5] = {(double)hsweeps, he[1], he[2], he[3], 0.0};  // [4] = delta = 0 as on the Jacobi path
+            MVF_CHECK_HIP(hipMemcpyAsync(einfo, hsw, sizeof(hsw), hipMemcpyHostToDevice, st));
+            MVF_CHECK_HIP(hipStreamSynchronize(st));
+            if (timing)
+                for (auto& e : ev) (void)hipEventDestroy(e);
+            return 0;
+        }
+        MVF_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));  // the Jacobi path below starts clean (Y is untouched)
+        if (timing) MVF_CHECK_HIP(hipEventRecord(ev[1], st));
+    }
 
     // 2. one-sided block Jacobi on the r rows of Y
     const int nb = (int)(rp / JB), npairs = nb / 2, nk = (int)(mp / 64);
@@ -1634,6 +1904,28 @@ extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lam
     return 0;
 }
 
+extern "C" int mvf_solve_minnorm_lr(const double* G, const double* K, double lambda_sigma2, double tolf, double rcond,
+                                    const double* R, int64_t m, int nrhs, double* C, int* info, double* einfo,
+                                    int max_sweeps, int reuse, int rank_hint, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    return lr_solve(G, K, lambda_sigma2, tolf, rcond, R, m, nrhs, C, info, einfo, max_sweeps, reuse, rank_hint, workspace,
+                    workspace_bytes, stream, false);
+}
+
+extern "C" size_t mvf_solve_minnorm_lrd_workspace_bytes(int64_t m, int nrhs) {
+    (void)nrhs;
+    if (m <= 0) return 0;
+    return lr_plan(m).total_d;
+}
+
+extern "C" int mvf_solve_minnorm_lrd(const double* G, const double* K, double lambda_sigma2, double tolf, double rcond,
+                                     const double* R, int64_t m, int nrhs, double* C, int* info, double* einfo,
+                                     int max_sweeps, int reuse, int rank_hint, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    return lr_solve(G, K, lambda_sigma2, tolf, rcond, R, m, nrhs, C, info, einfo, max_sweeps, reuse, rank_hint, workspace,
+                    workspace_bytes, stream, true);
+}
+
 extern "C" int mvf_lr_pivot_order(const void* workspace, size_t workspace_bytes, int64_t m, int* order_out, double* pivots_out,
                                   double* tol_out, int64_t* r_out, void* stream) {
     MVF_REQUIRE(m > 0 && workspace && order_out && r_out, "mvf_lr_pivot_order: bad arguments");
@@ -1674,6 +1966,7 @@ extern "C" int mvf_pinv_diag(const void* x4, int64_t n, const void* ctrl4, int64
         MVF_CHECK_HIP(hipMemcpyAsync(&hs, ws + p.off_state, sizeof(hs), hipMemcpyDeviceToHost, st));
         MVF_CHECK_HIP(hipStreamSynchronize(st));
         MVF_REQUIRE(hs.magic == PCHOL_MAGIC && hs.r >= 0 && hs.r <= m, "mvf_pinv_diag: the workspace holds no finished decomposition");
+        MVF_REQUIRE(!hs.defl, "mvf_pinv_diag: the workspace holds a deflated decomposition (mvf_solve_minnorm_lrd); run mvf_solve_minnorm_lr");
         mp = p.mp;
         nrows = cdiv(hs.r, 64) * 64;
         Y = (const double*)(ws + p.off_y);

@@ -18,5 +18,8 @@ int chol_factor(hipStream_t st, const double* G, const double* K, double ls2, do
                 int nrhs, void* workspace, CholPlan* pl, int* info);
 int chol_factor_mat(hipStream_t st, const double* A, int64_t ld, double shift, int64_t m, void* workspace, CholPlan* pl,
                     int* info);
+size_t chol_inv_workspace_bytes(int64_t m);
+int chol_factor_mat_inv(hipStream_t st, const double* A, int64_t ld, int64_t m, void* workspace, CholPlan* pl, int* info,
+                        int inverse);
 
 }  // namespace mvf

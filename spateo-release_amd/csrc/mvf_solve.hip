@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void mat_diag_mean_kernel(const double* __rest
 
 __global__ __launch_bounds__(256) void chol_prepare_mat_kernel(const double* __restrict__ A, int64_t ld,
                                                                const double* __restrict__ scal, int64_t m, int64_t mp,
-                                                               double* __restrict__ W) {
+                                                               double* __restrict__ W, int ident) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = blockIdx.y;
     if (j >= mp) return;
@@ -577,6 +577,8 @@ __global__ __launch_bounds__(256) void chol_prepare_mat_kernel(const double* __r
         } else if (i == j) {
             v = 1.0;
         }
+    } else if (ident && i - mp == j) {
+        v = 1.0;  // the identity as right-hand-side rows: they leave the factorisation as L^-T
     }
     W[i * mp + j] = v;
 }
@@ -589,7 +591,36 @@ int chol_factor_mat(hipStream_t st, const double* A, int64_t ld, double shift, i
     MVF_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
     hipLaunchKernelGGL(mat_diag_mean_kernel, dim3(1), dim3(256), 0, st, A, ld, shift, m, pl->scal);
     hipLaunchKernelGGL(chol_prepare_mat_kernel, dim3((unsigned)cdiv(mp, 256), (unsigned)mr), dim3(256), 0, st, A, ld,
-                       pl->scal, m, mp, pl->W);
+                       pl->scal, m, mp, pl->W, 0);
+    MVF_LAUNCH_CHECK();
+    return chol_run(st, pl, info);
+}
+
+// Cholesky AND the inverse of the factor in one pass: the right-hand sides ride along as extra rows (x L^T = a), so mp rows
+// holding the identity come out as L^-T (row j = column j of L^-1): pl->W + mp * mp, leading dimension mp, upper triangular.
+// No shift; info is NOT reset (the caller chains several factorisations and reads it once).
+size_t chol_inv_workspace_bytes(int64_t m) {
+    if (m <= 0) return 0;
+    const int64_t mp = solve_mp(m);
+    return align_up((size_t)2 * mp * mp * sizeof(double), 256) + align_up((size_t)mp * sizeof(double), 256) + 256;
+}
+
+// inverse = 0: the factor only (one block row of zero right-hand sides keeps the kernels' trapezoidal layout)
+int chol_factor_mat_inv(hipStream_t st, const double* A, int64_t ld, int64_t m, void* workspace, CholPlan* pl, int* info,
+                        int inverse) {
+    const int64_t mp = solve_mp(m), mr = inverse ? 2 * mp : mp + NB;
+    MVF_REQUIRE(mr <= 65535, "coefficient solve: m too large (%lld)", (long long)m);
+    pl->mp = mp;
+    pl->mr = mr;
+    pl->nb = (int)(mp / NB);
+    pl->nbr = (int)(mr / NB);
+    pl->W = (double*)workspace;
+    pl->Cp = pl->Yw = nullptr;
+    pl->rdiag = (double*)((char*)workspace + align_up((size_t)mr * mp * sizeof(double), 256));
+    pl->scal = (double*)((char*)pl->rdiag + align_up((size_t)mp * sizeof(double), 256));
+    MVF_CHECK_HIP(hipMemsetAsync(pl->scal, 0, 2 * sizeof(double), st));
+    hipLaunchKernelGGL(chol_prepare_mat_kernel, dim3((unsigned)cdiv(mp, 256), (unsigned)mr), dim3(256), 0, st, A, ld,
+                       pl->scal, m, mp, pl->W, inverse);
     MVF_LAUNCH_CHECK();
     return chol_run(st, pl, info);
 }

@@ -326,22 +326,24 @@ class HipKernels:
 
     @_on_device
     def solve_minnorm_lr(self, G, K, lambda_sigma2, R, C_out, info, einfo, rcond=None, reuse=False, max_sweeps=60,
-                         rank_hint=0, tolf=0.25):
+                         rank_hint=0, tolf=0.25, deflate=False):
         """The same truncated minimum-norm solve through the rank-revealing factor (pivoted Cholesky stopped at
         tolf * eps * lambda_max, Jacobi on the r kept columns only).  einfo[6] = r; pass it back as ``rank_hint`` for
-        the next, nearby matrix.  Synchronises the stream."""
+        the next, nearby matrix.  deflate=True (mvf_solve_minnorm_lrd): only the invariant subspace below the cut-off
+        is computed and projected out - same truncation, no full eigendecomposition (no pinv_diag afterwards).
+        Synchronises the stream."""
         m, nrhs = R.shape
-        need = self.lib.mvf_solve_minnorm_lr_workspace_bytes(m, nrhs)
+        fn = self.lib.mvf_solve_minnorm_lrd if deflate else self.lib.mvf_solve_minnorm_lr
+        need = (self.lib.mvf_solve_minnorm_lrd_workspace_bytes if deflate else self.lib.mvf_solve_minnorm_lr_workspace_bytes)(m, nrhs)
         if self._lr_ws is None or self._lr_ws.numel() < need:
             if reuse:
                 raise RuntimeError("solve_minnorm_lr(reuse=True) without a previous decomposition")
             self._lr_ws = None
             self._lr_ws = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
         rc = float(np.finfo(np.float64).eps) if rcond is None else float(rcond)
-        _lib.check(self.lib.mvf_solve_minnorm_lr(_ptr(G), _ptr(K), float(lambda_sigma2), float(tolf), rc, _ptr(R), m,
-                                                 nrhs, _ptr(C_out), _ptr(info), _ptr(einfo), int(max_sweeps),
-                                                 1 if reuse else 0, int(rank_hint), _ptr(self._lr_ws),
-                                                 self._lr_ws.numel(), self._stream()), "mvf_solve_minnorm_lr")
+        _lib.check(fn(_ptr(G), _ptr(K), float(lambda_sigma2), float(tolf), rc, _ptr(R), m, nrhs, _ptr(C_out), _ptr(info),
+                      _ptr(einfo), int(max_sweeps), 1 if reuse else 0, int(rank_hint), _ptr(self._lr_ws),
+                      self._lr_ws.numel(), self._stream()), "mvf_solve_minnorm_lrd" if deflate else "mvf_solve_minnorm_lr")
 
     @_on_device
     def lr_pivot_order(self, m, with_values=False):

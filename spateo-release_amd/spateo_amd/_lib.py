@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # calls at load time.  Without the gate the environment changes nothing.
 DEV_KNOBS = os.environ.get("MVF_DEV_KNOBS") == "1"
 LIB_PATH = (DEV_KNOBS and os.environ.get("MVF_LIB_PATH")) or os.path.join(_HERE, "lib", "libmvf.so")
-DEBUG_OPTIONS = ("conk_form", "conk_rows", "slice_len", "solve_small_off", "jac_gram_wgs", "lr_timing")
+DEBUG_OPTIONS = ("conk_form", "conk_rows", "slice_len", "solve_small_off", "jac_gram_wgs", "lr_timing", "lr_no_deflate")
 _LEGACY_ENV = {  # environment name -> (option, value parser)
     "MVF_CONK": ("conk_form", lambda v: {"rows": 1, "flat": 2, "2d": 3}[v]),
     "MVF_CONK_ROWS": ("conk_rows", int),
@@ -62,6 +62,8 @@ SIGNATURES = {
     "mvf_solve_minnorm_basis_bytes": (_sz, [_i64]),
     "mvf_solve_minnorm_lr_workspace_bytes": (_sz, [_i64, _i]),
     "mvf_solve_minnorm_lr": (_i, [_p, _p, _d, _d, _d, _p, _i64, _i, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
+    "mvf_solve_minnorm_lrd_workspace_bytes": (_sz, [_i64, _i]),
+    "mvf_solve_minnorm_lrd": (_i, [_p, _p, _d, _d, _d, _p, _i64, _i, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "mvf_lr_pivot_order": (_i, [_p, _sz, _i64, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.POINTER(C.c_int64), _p]),
     "mvf_pinv_diag": (_i, [_p, _i64, _p, _i64, _d, _d, _i, _p, _p, _sz, _i, _p]),

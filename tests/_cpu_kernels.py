@@ -132,7 +132,7 @@ class CpuKernels:
                                   w.min()], dtype=torch.float64)
 
     def solve_minnorm_lr(self, G, K, lambda_sigma2, R, C_out, info, einfo, rcond=None, reuse=False, max_sweeps=60,
-                         rank_hint=0, tolf=0.25):
+                         rank_hint=0, tolf=0.25, deflate=False):  # deflate: another route to the same truncated solve
         """The device algorithm restated: greedy diagonally pivoted Cholesky stopped at tolf * eps * lambda_max, then the
         SVD of the m x r factor (what the one-sided Jacobi iteration converges to), truncated at rcond * sigma_max^2."""
         rc = np.finfo(float).eps if rcond is None else rcond

@@ -298,7 +298,9 @@ def _minnorm_ref(A, R, rcond=np.finfo(float).eps):
     return (q[:, keep] / w[keep]) @ (q[:, keep].T @ R), w, keep
 
 
-METHODS = ["lowrank", "full"]  # mvf_solve_minnorm_lr (pivoted-Cholesky factor) / mvf_solve_minnorm (all m columns)
+# mvf_solve_minnorm_lr (pivoted-Cholesky factor + Jacobi on its columns) / mvf_solve_minnorm_lrd (same factor, only the
+# subspace below the cut-off computed and deflated; the Jacobi path below 512 factor columns) / mvf_solve_minnorm (all m columns)
+METHODS = ["lowrank", "deflated", "full"]
 
 
 def _run_minnorm(k, G, K, ls2, R, shift=2.0 ** -36, reuse_R=None, rcond=None, method="full", rank_hint=0):
@@ -308,9 +310,10 @@ def _run_minnorm(k, G, K, ls2, R, shift=2.0 ** -36, reuse_R=None, rcond=None, me
     C = torch.empty(m, nrhs, dtype=torch.float64, device=dev)
     info = torch.zeros(1, dtype=torch.int32, device=dev)
     einfo = torch.zeros(12, dtype=torch.float64, device=dev)
-    if method == "lowrank":
+    if method in ("lowrank", "deflated"):
         def run(Rt, Ct, **kw):
-            k.solve_minnorm_lr(Gd, Kd, ls2, Rt, Ct, info, einfo, rcond=rcond, rank_hint=rank_hint, **kw)
+            k.solve_minnorm_lr(Gd, Kd, ls2, Rt, Ct, info, einfo, rcond=rcond, rank_hint=rank_hint,
+                               deflate=method == "deflated", **kw)
     else:
         def run(Rt, Ct, **kw):
             k.solve_minnorm(Gd, Kd, ls2, shift, Rt, Ct, info, einfo, rcond=rcond, **kw)
@@ -325,7 +328,7 @@ def _run_minnorm(k, G, K, ls2, R, shift=2.0 ** -36, reuse_R=None, rcond=None, me
 
 
 @pytest.mark.parametrize("method", METHODS)
-@pytest.mark.parametrize("m,nrhs", [(2, 1), (33, 3), (64, 3), (100, 6), (300, 2), (517, 8)])
+@pytest.mark.parametrize("m,nrhs", [(2, 1), (33, 3), (64, 3), (100, 6), (300, 2), (517, 8), (700, 3)])
 def test_solve_minnorm_full_rank_equals_the_inverse(st, m, nrhs, method):
     """Well conditioned SPD system: nothing is truncated, the minimum-norm solve is the ordinary solve; the reported
     extreme eigenvalues are LAPACK's."""
@@ -340,15 +343,22 @@ def test_solve_minnorm_full_rank_equals_the_inverse(st, m, nrhs, method):
     assert info == 0 and e[0] == np.floor(e[0]) and e[0] < 40, e  # converged (x.5 would mean the sweep cap was hit)
     w = np.linalg.eigvalsh(G + ls2 * K)
     assert int(e[1]) == m
-    if method == "lowrank":
+    if method != "full":
         assert int(e[6]) == m  # the factor keeps every column of a well-conditioned matrix
-    np.testing.assert_allclose([e[2], e[3]], [w.max(), w.min()], rtol=1e-10)
+    if method == "deflated" and m >= 512:
+        # the deflated solve knows lambda_max from its power iteration (stopped when two successive Rayleigh quotients agree
+        # to 1e-7: a few 1e-6 on this clustered Wishart spectrum, 1e-8 on kernel Gram matrices) and the smallest Ritz value
+        # of its block only
+        np.testing.assert_allclose(e[2], w.max(), rtol=2e-5)
+        assert w.min() * (1 - 1e-9) <= e[3]
+    else:
+        np.testing.assert_allclose([e[2], e[3]], [w.max(), w.min()], rtol=1e-10)
     assert _relmax(C, np.linalg.solve(G + ls2 * K, R)) < 1e-9
     assert _relmax(C2, 2.0 * C[:, :1]) < 1e-12  # reuse applies the same decomposition to another right-hand side
 
 
 @pytest.mark.parametrize("method", METHODS)
-@pytest.mark.parametrize("m,rank", [(96, 40), (200, 1), (257, 130)])
+@pytest.mark.parametrize("m,rank", [(96, 40), (200, 1), (257, 130), (1200, 700)])
 def test_solve_minnorm_exactly_rank_deficient(st, m, rank, method):
     """A = B B^T with B m x rank: with a cut-off above the rounding level of the null-space eigenvalues (rcond = 1e-12;
     at the default eps some of them land above it, for LAPACK just the same) the result is pinv(A) R."""
@@ -358,7 +368,7 @@ def test_solve_minnorm_exactly_rank_deficient(st, m, rank, method):
     R = G @ rng.standard_normal((m, 3))  # consistent right-hand sides, as U^T P Y is for U^T P U
     C, info, e = _run_minnorm(_k("float64"), G, np.zeros((m, m)), 0.0, R, rcond=1e-12, method=method)
     assert info == 0 and int(e[1]) == rank
-    if method == "lowrank":
+    if method != "full":
         assert rank <= int(e[6]) <= rank + 8  # the pivoted factor stops at the rounding level of the matrix
     Cr = np.linalg.pinv(G, rcond=1e-13, hermitian=True) @ R
     assert _relmax(C, Cr) < 1e-8
@@ -400,7 +410,48 @@ def test_solve_minnorm_kernel_gram_vs_scipy_lstsq(st, n, m, method):
     assert info == 0
     assert dev < max(2.0 * floor, 1e-9)
     assert abs(int(e[1]) - int(keep.sum())) <= max(2, m // 50)  # eigenvalues at the cut-off may fall either side
-    np.testing.assert_allclose(e[2], w.max(), rtol=1e-9)
+    np.testing.assert_allclose(e[2], w.max(), rtol=1e-6 if method == "deflated" else 1e-9)
+
+
+@pytest.mark.parametrize("n,m", [(20000, 2000), (30000, 3000)])
+def test_deflated_solve_is_the_truncated_solve(st, n, m):
+    """mvf_solve_minnorm_lrd at the sizes it is made for (factor rank ~ 0.3 - 0.6 m): the field against scipy.linalg.lstsq
+    within twice the reference's own lstsq-vs-eigh floor, against the Jacobi path of the same factor far below that floor
+    (both apply the same eps lambda_max cut-off to the same factor), the same kept rank, eight right-hand sides, reuse, and
+    mvf_pinv_diag refusing the workspace (it needs the full decomposition)."""
+    import scipy.linalg
+    from spateo_amd import _lib
+
+    U, G, K, R, ls2 = _kernel_system(n, m)
+    R = np.concatenate([R, R[:, ::-1] * 0.5, R[:, :2] - R[:, 1:3]], 1)[:, :8]
+    A = G + ls2 * K
+    F = U @ scipy.linalg.lstsq(A, R)[0]
+    sc = np.abs(F).max()
+    floor = np.abs(U @ _minnorm_ref(A, R)[0] - F).max() / sc
+    k = _k("float64")
+    Cj, info_j, ej = _run_minnorm(k, G, K, ls2, R, method="lowrank")
+    Cd, info_d, ed, Cd2 = _run_minnorm(k, G, K, ls2, R, method="deflated", reuse_R=R[:, 2:5] * 3.0)
+    assert info_j == 0 and info_d == 0 and int(ed[6]) >= 512
+    dev_d, dev_j, between = (np.abs(U @ a - b).max() / sc for a, b in ((Cd, F), (Cj, F), (Cd, U @ Cj)))
+    print(f"m={m}: factor rank {int(ed[6])} kept {int(ed[1])} (Jacobi path {int(ej[1])}), block sweeps {ed[0]}; floor {floor:.2e} "
+          f"deflated vs lstsq {dev_d:.2e} Jacobi vs lstsq {dev_j:.2e} deflated vs Jacobi {between:.2e}")
+    assert ed[0] == np.floor(ed[0]) and abs(int(ed[1]) - int(ej[1])) <= 1
+    assert dev_d < 2.0 * floor and between < 0.1 * floor
+    assert _relmax(Cd2, 3.0 * Cd[:, 2:5]) < 1e-11
+    with pytest.raises(_lib.MVFError, match="deflated decomposition"):
+        k.pinv_diag(torch.zeros(4, 4, dtype=torch.float64, device="cuda:0"), torch.zeros(m, 4, dtype=torch.float64, device="cuda:0"),
+                    1.0, lowrank=True)
+
+
+def test_deflated_solve_falls_back_when_the_block_is_too_small(st):
+    """With a cut-off far above eps more eigenvalues of the factor fall below it than the 256-vector block holds: the call
+    must notice and return the Jacobi path's result."""
+    U, G, K, R, ls2 = _kernel_system(20000, 2000)
+    k = _k("float64")
+    Cj, info_j, ej = _run_minnorm(k, G, K, ls2, R, method="lowrank", rcond=1e-9)
+    Cd, info_d, ed = _run_minnorm(k, G, K, ls2, R, method="deflated", rcond=1e-9)
+    assert info_d == 0 and int(ed[6]) - int(ed[1]) > 224, ed
+    assert int(ed[1]) == int(ej[1]) and _relmax(U @ Cd, U @ Cj) < 1e-9
 
 
 def test_solve_minnorm_lr_zero_matrix_and_non_finite_input(st):
