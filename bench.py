@@ -357,7 +357,10 @@ def main():
             },
             "solve": {
                 "lstsq_method": eng.lstsq_method,
-                "path": (("minimum-norm (pivoted-Cholesky factor of rank r + one-sided block Jacobi on its r columns, "
+                "path": (("minimum-norm (pivoted-Cholesky factor of rank r; the invariant subspace below the eps*lambda_max "
+                          "cut-off from block inverse iteration on 256 vectors, deflated solve; jacobi_sweeps = the "
+                          "256 x 256 Rayleigh-Ritz problem's)") if eng.mn_method == "deflated" else
+                         ("minimum-norm (pivoted-Cholesky factor of rank r + one-sided block Jacobi on its r columns, "
                           "eps*lambda_max cut-off)") if eng.mn_method == "lowrank" else
                          "minimum-norm (Cholesky + one-sided block Jacobi eigensolver, eps*lambda_max cut-off)")
                         if eng.rank_deficient else "Cholesky (pivots certify full numerical rank)",
@@ -379,12 +382,18 @@ def main():
             "step_TFLOPs_NM_Mplus1": float(N) * Mc * (Mc + 1) / (ms_per_step * 1e-3) / 1e12,
         }
         # "MFMA utilisation on the solve" (north_star): MFMA-tile flops of the solve over its wall time.  Rank-revealing
-        # path: 2 r M^2 in the trailing updates of the pivoted factor + 8 r^2 M per Jacobi sweep (Gram + update tiles);
+        # Jacobi path: 2 r M^2 in the trailing updates of the pivoted factor + 8 r^2 M per Jacobi sweep (Gram + update tiles);
         # full width: M^3 / 3 (Cholesky) + 8 M^3 per sweep; Cholesky only: M^3 / 3.
         sv = rec["solve"]
         if eng.rank_deficient and sv["jacobi_sweeps"]:
             sw = float(np.mean([int(x) for x in sv["jacobi_sweeps"]]))
-            if eng.mn_method == "lowrank" and sv["factor_rank"]:
+            if eng.mn_method == "deflated" and sv["factor_rank"] and sv["factor_rank"] >= 512:
+                # pivoted factor 2 r M^2; S2 = L^T L 2 r^2 M; Cholesky + inverse rows of S2 4 r^3 / 3; S2^-1 2 r^3; the
+                # block (b = 256): two Gram + two orthonormalising + three b x r x r products, Jacobi sweeps on b x b
+                rr, bb = float(sv["factor_rank"]), 256.0
+                fl = (2.0 * rr * Mc * Mc + 2.0 * rr * rr * Mc + 10.0 / 3.0 * rr**3 + 8.0 * bb * bb * rr + 6.0 * bb * rr * rr +
+                      sw * 8.0 * bb**3)
+            elif eng.mn_method in ("lowrank", "deflated") and sv["factor_rank"]:
                 rr = float(sv["factor_rank"])
                 fl = 2.0 * rr * Mc * Mc + sw * 8.0 * rr * rr * Mc
             else:

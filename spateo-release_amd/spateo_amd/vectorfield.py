@@ -479,7 +479,7 @@ class SparseVFCEngine:
         self._setup_control_points(self.ctrl_full[self.subset])
         self._build_u_cache()
         self.rank_hint, self.basis, self.basis_valid = 0, None, False
-        self.mn_method = "lowrank" if hasattr(k, "solve_minnorm_lr") else self.mn_method
+        self.mn_method = (MINNORM_METHOD or "deflated") if hasattr(k, "solve_minnorm_lr") else self.mn_method
         self.solver_stats.setdefault("pivot_subsets", []).append(int(len(p)))
         self.solver_stats["pivot_subset"] = int(len(p))
         return True

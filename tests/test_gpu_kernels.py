@@ -369,7 +369,7 @@ def test_solve_minnorm_exactly_rank_deficient(st, m, rank, method):
     C, info, e = _run_minnorm(_k("float64"), G, np.zeros((m, m)), 0.0, R, rcond=1e-12, method=method)
     assert info == 0 and int(e[1]) == rank
     if method != "full":
-        assert rank <= int(e[6]) <= rank + 8  # the pivoted factor stops at the rounding level of the matrix
+        assert rank <= int(e[6]) <= rank + max(8, m // 100)  # the pivoted factor stops at the rounding level of the matrix
     Cr = np.linalg.pinv(G, rcond=1e-13, hermitian=True) @ R
     assert _relmax(C, Cr) < 1e-8
     assert _relmax(G @ C, R) < 1e-10
@@ -430,14 +430,14 @@ def test_deflated_solve_is_the_truncated_solve(st, n, m):
     floor = np.abs(U @ _minnorm_ref(A, R)[0] - F).max() / sc
     k = _k("float64")
     Cj, info_j, ej = _run_minnorm(k, G, K, ls2, R, method="lowrank")
-    Cd, info_d, ed, Cd2 = _run_minnorm(k, G, K, ls2, R, method="deflated", reuse_R=R[:, 2:5] * 3.0)
+    Cd, info_d, ed, Cd2 = _run_minnorm(k, G, K, ls2, R, method="deflated", reuse_R=R[:, 2:5] * 4.0)
     assert info_j == 0 and info_d == 0 and int(ed[6]) >= 512
     dev_d, dev_j, between = (np.abs(U @ a - b).max() / sc for a, b in ((Cd, F), (Cj, F), (Cd, U @ Cj)))
     print(f"m={m}: factor rank {int(ed[6])} kept {int(ed[1])} (Jacobi path {int(ej[1])}), block sweeps {ed[0]}; floor {floor:.2e} "
           f"deflated vs lstsq {dev_d:.2e} Jacobi vs lstsq {dev_j:.2e} deflated vs Jacobi {between:.2e}")
     assert ed[0] == np.floor(ed[0]) and abs(int(ed[1]) - int(ej[1])) <= 1
     assert dev_d < 2.0 * floor and between < 0.1 * floor
-    assert _relmax(Cd2, 3.0 * Cd[:, 2:5]) < 1e-11
+    assert _relmax(Cd2, 4.0 * Cd[:, 2:5]) < 1e-11  # (a power of two: the coefficients amplify the rounding of 3 R by 1e10)
     with pytest.raises(_lib.MVFError, match="deflated decomposition"):
         k.pinv_diag(torch.zeros(4, 4, dtype=torch.float64, device="cuda:0"), torch.zeros(m, 4, dtype=torch.float64, device="cuda:0"),
                     1.0, lowrank=True)
