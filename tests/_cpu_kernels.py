@@ -21,7 +21,42 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+def deflated_minnorm(L, R, cut, block, applications=2):
+    """NumPy restatement of mvf_solve_minnorm_lrd's deflated solve (csrc/mvf_minnorm.hip) on the pivoted factor
+    L (m x r, columns in pivot order):  C = sum over the eigenpairs of L L^T with eigenvalue > cut of q (q^T R) / lambda, WITHOUT
+    the eigendecomposition of the whole factor.  Returns (C, number of deflated directions).
+      S2 = L^T L = Rc Rc^T (Cholesky: the factor is graded), Minv = S2^-1;
+      block inverse iteration started on the unit vectors of the `block` smallest pivots, Cholesky-QR after each application;
+      Rayleigh-Ritz on H = Z S2 Z^T; W = Ritz vectors with theta <= cut; Pc = I - W^T W;
+      C = L Pc Minv Pc Minv Pc L^T R  (the projections between the inverse applications keep the amplified rounding error of
+      the dropped directions out of the result)."""
+    r = L.shape[1]
+    S2 = L.T @ L
+    E = np.linalg.inv(np.linalg.cholesky(S2)).T          # Rc^-T
+    Minv = E @ E.T
+
+    def orthonormal_rows(Z):
+        return np.linalg.inv(np.linalg.cholesky(Z @ Z.T)) @ Z
+
+    Z = orthonormal_rows(Minv[r - block:])                # = Minv applied to the trailing unit vectors
+    for _ in range(applications - 1):
+        Z = orthonormal_rows(Z @ Minv)
+    H = Z @ S2 @ Z.T
+    theta, Yh = np.linalg.eigh((H + H.T) / 2)
+    sel = theta <= cut
+    W = Yh[:, sel].T @ Z
+
+    def project(T):
+        return T - W.T @ (W @ T)
+
+    t = project(L.T @ R)
+    t = project(Minv @ t)
+    t = project(Minv @ t)
+    return L @ t, int(sel.sum())
+
+
 class CpuKernels:
+    DEFL_BLOCK = 256  # mvf_minnorm.hip's DEFL_B; tests shrink it to reach the deflated route at CPU sizes
     def __init__(self, device=None, dtype="float64"):
         self.device = torch.device("cpu")
         self.dtype_name = "float64"
@@ -132,9 +167,11 @@ class CpuKernels:
                                   w.min()], dtype=torch.float64)
 
     def solve_minnorm_lr(self, G, K, lambda_sigma2, R, C_out, info, einfo, rcond=None, reuse=False, max_sweeps=60,
-                         rank_hint=0, tolf=0.25, deflate=False):  # deflate: another route to the same truncated solve
+                         rank_hint=0, tolf=0.25, deflate=False):
         """The device algorithm restated: greedy diagonally pivoted Cholesky stopped at tolf * eps * lambda_max, then the
-        SVD of the m x r factor (what the one-sided Jacobi iteration converges to), truncated at rcond * sigma_max^2."""
+        SVD of the m x r factor (what the one-sided Jacobi iteration converges to), truncated at rcond * sigma_max^2.
+        deflate=True: mvf_solve_minnorm_lrd's route to the same solution (deflated_minnorm below) when the factor has at
+        least 2 * DEFL_BLOCK columns, like the device (which uses a block of 256)."""
         rc = np.finfo(float).eps if rcond is None else rcond
         if not reuse:
             A = _np(G) + lambda_sigma2 * _np(K)
@@ -169,6 +206,7 @@ class CpuKernels:
             self._pivot_values, self._pivot_tol = np.array(pvals), float(tol)
             u, s, _ = np.linalg.svd(L[:, :r], full_matrices=False) if r else (np.zeros((m, 0)), np.zeros(0), None)
             self._lr = (u, s * s, r)
+            self._lr_factor = L[:, :r].copy()
         u, lam, r = self._lr
         info.zero_()
         if r == 0:
@@ -176,7 +214,13 @@ class CpuKernels:
             einfo[:7] = 0.0
             return
         keep = lam > rc * lam.max()
-        c = (u[:, keep] / lam[keep]) @ (u[:, keep].T @ _np(R))
+        c = None
+        if deflate and r >= 2 * self.DEFL_BLOCK:
+            c, nsel = deflated_minnorm(self._lr_factor, _np(R), rc * lam.max(), self.DEFL_BLOCK)
+            if nsel > self.DEFL_BLOCK - self.DEFL_BLOCK // 8:
+                c = None  # block too small for what lies below the cut: the SVD route, like the device's Jacobi path
+        if c is None:
+            c = (u[:, keep] / lam[keep]) @ (u[:, keep].T @ _np(R))
         C_out.copy_(torch.from_numpy(c))
         o = 6 if reuse else 0
         einfo[o + 1 : o + 6] = torch.tensor([keep.sum(), lam.max(), lam[keep].min(), 0.0, lam.min()], dtype=torch.float64)

@@ -806,3 +806,45 @@ def test_pivot_mode_continues_on_the_selected_control_points(cpu_kernels, monkey
     assert "ctrl_subset" not in reg
     with pytest.raises(ValueError, match="gram_mode"):
         st.SparseVFC(X, V, None, gram_mode="nonsense", **kw)
+
+
+def test_deflated_route_to_the_truncated_solve_restated_in_numpy():
+    """mvf_solve_minnorm_lrd's algorithm as NumPy (`_cpu_kernels.deflated_minnorm`): on a rank-deficient
+    kernel system the invariant subspace below the eps * lambda_max cut-off, found by block inverse iteration on the r x r matrix
+    L^T L of the pivoted factor, and the deflated solve give the truncated minimum-norm solution of that factor - the same number
+    of truncated eigenvalues, the field within 1e-5 of the SVD route's (the reference's own lstsq-vs-eigh floor on this system:
+    4e-2) - while a block smaller than what lies below the cut is noticed and answered by the SVD route."""
+    import scipy.linalg
+    import torch
+    from spateo_amd._synthetic import make_config
+
+    from _cpu_kernels import CpuKernels, deflated_minnorm
+    from oracle import sparsevfc_oracle as svo
+
+    n, m = 6000, 700
+    X, Y, _ = make_config("C2", N=n)
+    valid, Xv, Yv, idx, ctrl, beta = svo.sparsevfc_setup(X, Y, M=m, seed=0)
+    K = svo.con_K(ctrl, ctrl, beta)
+    U = svo.con_K(Xv, ctrl, beta)
+    P = np.clip(np.random.default_rng(0).random(len(Xv)), 1e-5, 1.0)
+    G, R, ls2 = (U.T * P[None, :]) @ U, (U.T * P[None, :]) @ Yv, 0.02 * 1e-3
+
+    def solve(block, deflate):
+        k = CpuKernels()
+        k.DEFL_BLOCK = block
+        C, info, e = torch.empty(m, 3, dtype=torch.float64), torch.zeros(1, dtype=torch.int32), torch.zeros(12, dtype=torch.float64)
+        k.solve_minnorm_lr(torch.from_numpy(G), torch.from_numpy(K), ls2, torch.from_numpy(R), C, info, e, deflate=deflate)
+        return k, C.numpy().copy(), e.numpy().copy()
+
+    k, C_svd, e = solve(128, False)
+    r, kept = int(e[6]), int(e[1])
+    assert r >= 2 * 128 and 0 < r - kept < 96          # a rank-deficient system with room in the block
+    F = U @ scipy.linalg.lstsq(G + ls2 * K, R)[0]
+    sc = np.abs(F).max()
+    cut = np.finfo(float).eps * k._lr[1].max()
+    C_defl, nsel = deflated_minnorm(k._lr_factor, R, cut, 128)
+    assert nsel == r - kept
+    assert np.abs(U @ (C_defl - C_svd)).max() / sc < 1e-5
+    assert np.abs(U @ C_defl - F).max() / sc < 4e-2      # and with it inside the reference's floor on this system
+    np.testing.assert_array_equal(solve(128, True)[1], C_defl)   # the twin's deflate=True IS this route ...
+    np.testing.assert_array_equal(solve(32, True)[1], C_svd)     # ... and falls back when the block cannot hold the subspace
