@@ -242,9 +242,11 @@ int mvf_solve_minnorm_lr(const double* G, const double* K, double lambda_sigma2,
  *     C = L Pc S2^-1 Pc S2^-1 Pc L^T R
  * (the projections between the inverse applications keep the amplified rounding error of the dropped directions out).
  * lambda_max (einfo[2]) is the Rayleigh quotient of 12 power-iteration steps (relative error ~1e-8), einfo[3] the smallest
- * Ritz value above the cut inside the block.  When the factor has fewer than 512 columns, when more than 224 Ritz values
+ * Ritz value above the cut inside the block, einfo[7] the block size used (256; 128 with three applications when the
+ * previous call on this workspace - rank_hint > 0 - deflated at most 72 directions, repeated with 256 if it then finds more
+ * than 80; 0 when the Jacobi path answered).  When the factor has fewer than 512 columns, when more than 224 Ritz values
  * fall below the cut, or a factorisation meets a non-positive pivot, the call continues on mvf_solve_minnorm_lr's Jacobi
- * path and returns its result.  Measured at m = 3000 in the EM's steady state (r = 869): 9.0 ms against 22.9 ms, the field
+ * path and returns its result.  Measured at m = 3000 in the EM's steady state (r = 869): 6.7 ms against 22.9 ms, the field
  * within 1e-6 of the Jacobi path's on the same factor.  The workspace is larger (the r x r scratch); mvf_pinv_diag does not
  * accept a workspace left by this call (it needs every eigenpair): use mvf_solve_minnorm_lr for that.  No reference
  * interface changes: this is how `lstsq_solver(lhs, rhs, "scipy")` is evaluated. */

@@ -632,7 +632,8 @@ struct PcholState {
     int done, r, panels, hint_broken;  // panels = hint panels accepted so far (the next panel's index)
     double tol, lmax_est, maxdiag, lmax_prev;  // lmax_prev: the Rayleigh quotient one power step earlier
     int panel_nvalid, magic, order_len, pad3;  // magic / order_len: the workspace holds the pivot order of a finished call
-    int defl, defl_block, pad4, pad5;           // defl = 1: the workspace holds the DEFLATED decomposition (mvf_solve_minnorm_lrd)
+    int defl, defl_block, pad4, defl_nsel;      // defl = 1: the workspace holds the DEFLATED decomposition (mvf_solve_minnorm_lrd)
+                                                // of block size defl_block; defl_nsel: directions its last call deflated
 };
 
 // y = A x, one wave per row (the power iteration that estimates lambda_max for the stopping tolerance)
@@ -1142,6 +1143,8 @@ __global__ __launch_bounds__(PC_T) void pchol_panel_rows_kernel(const double* __
 // factorisation meets a non-positive pivot.
 constexpr int DEFL_B = 256;
 constexpr int DEFL_GUARD = 32;
+constexpr int DEFL_SMALL_MAX = 72;     // the previous call truncated at most this many: try a 128-vector block first
+constexpr int DEFL_SMALL_ACCEPT = 80;  // ... and accept its result only if it finds at most this many
 
 struct DeflBuf {
     size_t s2, cw, za, zb, wsel, g, h, yh, cwb, ta, tb, cb, dummy, part, theta, total;
@@ -1593,13 +1596,12 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
     };
 
     // the deflated truncated solve from (Y, Minv in S, the deflation vectors): C = Y^T Pc Minv Pc Minv Pc (Y R)
-    auto defl_apply = [&](int64_t rp) -> int {
+    auto defl_apply = [&](int64_t rp, int b) -> int {
         const DeflBuf d = defl_layout(rp);
         char* dw = ws + p.off_d;
         double *Ta = (double*)(dw + d.ta), *Tb = (double*)(dw + d.tb), *cb = (double*)(dw + d.cb);
         double *dummy = (double*)(dw + d.dummy), *dpart = (double*)(dw + d.part), *Wsel = (double*)(dw + d.wsel);
         const double* Minv = S;
-        const int b = DEFL_B;
         auto project = [&](double* T) {  // T -= Wsel^T (Wsel T)
             hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, Wsel, (int64_t)b, rp, rp, T, 8,
                                dummy, cb);
@@ -1638,7 +1640,8 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         }
         if (hs.defl) {
             MVF_REQUIRE(workspace_bytes >= p.total_d, "mvf_solve_minnorm_lr: reuse of a deflated decomposition needs its workspace");
-            return defl_apply(cdiv(hs.r, 64) * 64);
+            MVF_REQUIRE(hs.defl_block == DEFL_B || hs.defl_block == DEFL_B / 2, "mvf_solve_minnorm_lr: corrupt deflation state");
+            return defl_apply(cdiv(hs.r, 64) * 64, hs.defl_block);
         }
         return backsolve(cdiv(hs.r, 64) * 64, einfo + 6);
     }
@@ -1729,7 +1732,6 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
 
     // 2'. deflated solve: only the invariant subspace below the cut-off is computed (see DEFL_B above)
     if (deflate && r >= 2 * DEFL_B && debug_opt(DBG_LR_NO_DEFLATE) == 0) {
-        const int b = DEFL_B;
         const DeflBuf d = defl_layout(rp);
         char* dw = ws + p.off_d;
         double *S2 = (double*)(dw + d.s2), *Za = (double*)(dw + d.za), *Zb = (double*)(dw + d.zb);
@@ -1763,64 +1765,85 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         if (int rc = chol_factor_mat_inv(st, S2, rp, r, dw + d.cw, &cs, info, 1)) return rc;
         const double* E = cs.W + rp * rp;                      // Rc^-T (upper triangular, identity on the padding)
         gemm<false, true>(st, E, rp, E, rp, Minv, rp, rp, rp, rp);  // Minv = Rc^-T Rc^-1
-        auto orthonormalise = [&](const double* Zin, double* Zout) -> int {  // Cholesky QR on the rows
-            gemm<false, true>(st, Zin, rp, Zin, rp, Gb, b, b, b, rp);
-            if (int rc = chol_factor_mat_inv(st, Gb, b, b, dw + d.cwb, &cq, info, 1)) return rc;
-            gemm<true, false>(st, cq.W + (size_t)b * b, b, Zin, rp, Zout, rp, b, rp, b);  // Lg^-1 Zin
+        // Block size: 256 vectors and two applications of Minv; when the previous call on this workspace (the previous EM
+        // iteration: rank_hint) truncated at most DEFL_SMALL_MAX directions, 128 vectors and three applications (the
+        // 129th eigenvalue is then still > 4 x the cut: tools/lrproto_partial2.py on 60 k x 3000 systems, 65 - 68
+        // truncated: field within 5e-6 of the exactly truncated solve).  A 128-block that finds more than DEFL_SMALL_ACCEPT
+        // is repeated with 256.
+        int hsweeps = 0, b = DEFL_B;
+        unsigned int hrot2 = 1;
+        double he[6] = {0, 0, 0, 0, 0, 0};
+        bool ok = false;
+        auto attempt = [&](int napp) -> int {
+            auto orthonormalise = [&](const double* Zin, double* Zout) -> int {  // Cholesky QR on the rows
+                gemm<false, true>(st, Zin, rp, Zin, rp, Gb, b, b, b, rp);
+                if (int rc = chol_factor_mat_inv(st, Gb, b, b, dw + d.cwb, &cq, info, 1)) return rc;
+                gemm<true, false>(st, cq.W + (size_t)b * b, b, Zin, rp, Zout, rp, b, rp, b);  // Lg^-1 Zin
+                return 0;
+            };
+            // inverse iteration, started on the unit vectors of the b smallest pivots: Minv e_j = rows r-b .. r-1 of Minv
+            // (one Cholesky-QR pass per application leaves the rows orthonormal to ~1e-13: tools/lrproto_partial2.py's
+            // pass-count comparison - the Ritz decision and the projector do not need more)
+            if (int rc = orthonormalise(Minv + (r - b) * rp, Za)) return rc;
+            for (int ap = 1; ap < napp; ++ap) {
+                gemm<false, false>(st, Za, rp, Minv, rp, Zb, rp, b, rp, rp);
+                if (int rc = orthonormalise(Zb, Za)) return rc;  // Za = the block
+            }
+            // Rayleigh-Ritz: H = Za S2 Za^T, its eigenvectors by the Jacobi kernels on the Cholesky factor of H
+            gemm<false, false>(st, Za, rp, S2, rp, Zb, rp, b, rp, rp);
+            gemm<false, true>(st, Zb, rp, Za, rp, H, b, b, b, rp);
+            if (int rc = chol_factor_mat_inv(st, H, b, b, dw + d.cwb, &cq, info, 0)) return rc;
+            hipLaunchKernelGGL(jac_init_kernel, dim3((unsigned)(b / 64), (unsigned)(b / 64)), dim3(256), 0, st, cq.W, (int64_t)b,
+                               (int64_t)b, Yh);
+            MVF_LAUNCH_CHECK();
+            const int hnb = b / JB, hnp = hnb / 2, hnk = b / 64;
+            const double htol = std::sqrt((double)b) * 2.220446049250313e-16;
+            int* hclean = mod + hnb;
+            MVF_CHECK_HIP(hipMemsetAsync(mod, 0, (size_t)(hnb + (size_t)hnb * hnb) * sizeof(int), st));
+            hsweeps = 0;
+            hrot2 = 1;
+            while (hsweeps < max_sweeps) {
+                MVF_CHECK_HIP(hipMemsetAsync(rot, 0, sizeof(unsigned int), st));
+                for (int rd = 0; rd < hnb - 1; ++rd) {
+                    const int stamp = 1 + hsweeps * (hnb - 1) + rd;
+                    hipLaunchKernelGGL(jac_gram_kernel, dim3((unsigned)hnp, (unsigned)hnk), dim3(256), 0, st, Yh, (int64_t)b,
+                                       hnb, rd, hnk, 1, mod, hclean, Spart);
+                    if (rd == 0)
+                        hipLaunchKernelGGL(jac_eig_kernel<true>, dim3((unsigned)hnp), dim3(EIG_THREADS), 0, st, Spart, hnk,
+                                           htol, hnb, rd, stamp, mod, hclean, Jbuf, flags, rot);
+                    else
+                        hipLaunchKernelGGL(jac_eig_kernel<false>, dim3((unsigned)hnp), dim3(EIG_THREADS), 0, st, Spart, hnk,
+                                           htol, hnb, rd, stamp, mod, hclean, Jbuf, flags, rot);
+                    hipLaunchKernelGGL(jac_update_kernel, dim3((unsigned)hnp, (unsigned)(b / 64)), dim3(256), 0, st, Yh,
+                                       (int64_t)b, hnb, rd, Jbuf, flags);
+                }
+                MVF_LAUNCH_CHECK();
+                ++hsweeps;
+                MVF_CHECK_HIP(hipMemcpyAsync(&hrot2, rot, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+                MVF_CHECK_HIP(hipStreamSynchronize(st));
+                if (hrot2 == 0) break;
+            }
+            hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, Yh, (int64_t)b, (int64_t)b,
+                               (int64_t)b, R, 0, theta, dummy);
+            hipLaunchKernelGGL(defl_select_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, theta, b, stt, rcond, r, Yh,
+                               einfo);
+            gemm<false, false>(st, Yh, b, Za, rp, Wsel, rp, b, rp, b);  // rows = the Ritz vectors to deflate (zero rows else)
+            MVF_LAUNCH_CHECK();
             return 0;
         };
-        // inverse iteration, started on the unit vectors of the b smallest pivots: Minv e_j = rows r-b .. r-1 of Minv
-        if (int rc = orthonormalise(Minv + (r - b) * rp, Za)) return rc;
-        gemm<false, false>(st, Za, rp, Minv, rp, Zb, rp, b, rp, rp);
-        // (one Cholesky-QR pass per application leaves the rows orthonormal to ~1e-13: tools/lrproto_partial2.py's
-        // pass-count comparison - the Ritz decision and the projector do not need more)
-        if (int rc = orthonormalise(Zb, Za)) return rc;  // Za = the block
-        // Rayleigh-Ritz: H = Za S2 Za^T, its eigenvectors by the Jacobi kernels on the Cholesky factor of H
-        gemm<false, false>(st, Za, rp, S2, rp, Zb, rp, b, rp, rp);
-        gemm<false, true>(st, Zb, rp, Za, rp, H, b, b, b, rp);
-        if (int rc = chol_factor_mat_inv(st, H, b, b, dw + d.cwb, &cq, info, 0)) return rc;
-        hipLaunchKernelGGL(jac_init_kernel, dim3((unsigned)(b / 64), (unsigned)(b / 64)), dim3(256), 0, st, cq.W, (int64_t)b,
-                           (int64_t)b, Yh);
-        MVF_LAUNCH_CHECK();
-        const int hnb = b / JB, hnp = hnb / 2, hnk = b / 64;
-        const double htol = std::sqrt((double)b) * 2.220446049250313e-16;
-        int* hclean = mod + hnb;
-        MVF_CHECK_HIP(hipMemsetAsync(mod, 0, (size_t)(hnb + (size_t)hnb * hnb) * sizeof(int), st));
-        int hsweeps = 0;
-        unsigned int hrot2 = 1;
-        while (hsweeps < max_sweeps) {
-            MVF_CHECK_HIP(hipMemsetAsync(rot, 0, sizeof(unsigned int), st));
-            for (int rd = 0; rd < hnb - 1; ++rd) {
-                const int stamp = 1 + hsweeps * (hnb - 1) + rd;
-                hipLaunchKernelGGL(jac_gram_kernel, dim3((unsigned)hnp, (unsigned)hnk), dim3(256), 0, st, Yh, (int64_t)b, hnb,
-                                   rd, hnk, 1, mod, hclean, Spart);
-                if (rd == 0)
-                    hipLaunchKernelGGL(jac_eig_kernel<true>, dim3((unsigned)hnp), dim3(EIG_THREADS), 0, st, Spart, hnk, htol,
-                                       hnb, rd, stamp, mod, hclean, Jbuf, flags, rot);
-                else
-                    hipLaunchKernelGGL(jac_eig_kernel<false>, dim3((unsigned)hnp), dim3(EIG_THREADS), 0, st, Spart, hnk, htol,
-                                       hnb, rd, stamp, mod, hclean, Jbuf, flags, rot);
-                hipLaunchKernelGGL(jac_update_kernel, dim3((unsigned)hnp, (unsigned)(b / 64)), dim3(256), 0, st, Yh,
-                                   (int64_t)b, hnb, rd, Jbuf, flags);
-            }
-            MVF_LAUNCH_CHECK();
-            ++hsweeps;
-            MVF_CHECK_HIP(hipMemcpyAsync(&hrot2, rot, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        const bool small_first = use_hint && hs.defl_nsel > 0 && hs.defl_nsel <= DEFL_SMALL_MAX && r >= 2 * DEFL_B;
+        for (int pass = small_first ? 0 : 1; pass < 2 && !ok; ++pass) {
+            b = pass == 0 ? DEFL_B / 2 : DEFL_B;
+            if (int rc = attempt(pass == 0 ? 3 : 2)) return rc;
+            if (timing) MVF_CHECK_HIP(hipEventRecord(ev[2], st));
+            if (int rc = defl_apply(rp, b)) return rc;
+            MVF_CHECK_HIP(hipMemcpyAsync(he, einfo, sizeof(he), hipMemcpyDeviceToHost, st));
+            MVF_CHECK_HIP(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, st));
             MVF_CHECK_HIP(hipStreamSynchronize(st));
-            if (hrot2 == 0) break;
+            ok = hinfo == 0 && hrot2 == 0 && he[4] <= (double)(pass == 0 ? DEFL_SMALL_ACCEPT : b - DEFL_GUARD) &&
+                 std::isfinite(he[5]) && he[5] > 0.0;
+            if (hinfo != 0) break;  // a factorisation met a non-positive pivot: the larger block would meet it too
         }
-        hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, Yh, (int64_t)b, (int64_t)b,
-                           (int64_t)b, R, 0, theta, dummy);
-        hipLaunchKernelGGL(defl_select_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, theta, b, stt, rcond, r, Yh, einfo);
-        gemm<false, false>(st, Yh, b, Za, rp, Wsel, rp, b, rp, b);  // rows = the Ritz vectors to deflate (zero rows else)
-        MVF_LAUNCH_CHECK();
-        if (timing) MVF_CHECK_HIP(hipEventRecord(ev[2], st));
-        if (int rc = defl_apply(rp)) return rc;
-        double he[6];
-        MVF_CHECK_HIP(hipMemcpyAsync(he, einfo, sizeof(he), hipMemcpyDeviceToHost, st));
-        MVF_CHECK_HIP(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, st));
-        MVF_CHECK_HIP(hipStreamSynchronize(st));
-        const bool ok = hinfo == 0 && hrot2 == 0 && he[4] <= (double)(b - DEFL_GUARD) && std::isfinite(he[5]) && he[5] > 0.0;
         if (timing) {
             MVF_CHECK_HIP(hipEventRecord(ev[3], st));
             MVF_CHECK_HIP(hipEventSynchronize(ev[3]));
@@ -1832,10 +1855,12 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
                     (long long)m, (long long)r, t01, t12, hsweeps, b, (int)he[4], hinfo, ok ? "" : " -> Jacobi path", t23);
         }
         if (ok) {
-            const int dtag[2] = {1, b};
+            const int dtag[4] = {1, b, 0, (int)he[4]};  // defl, defl_block, pad4, defl_nsel (the next call's block choice)
             MVF_CHECK_HIP(hipMemcpyAsync(&stt->defl, dtag, sizeof(dtag), hipMemcpyHostToDevice, st));
             const double hsw[5] = {(double)hsweeps, he[1], he[2], he[3], 0.0};  // [4] = delta = 0 as on the Jacobi path
             MVF_CHECK_HIP(hipMemcpyAsync(einfo, hsw, sizeof(hsw), hipMemcpyHostToDevice, st));
+            const double hblk[1] = {(double)b};  // einfo[7] = the block size used (0: the Jacobi path answered)
+            MVF_CHECK_HIP(hipMemcpyAsync(einfo + 7, hblk, sizeof(hblk), hipMemcpyHostToDevice, st));
             MVF_CHECK_HIP(hipStreamSynchronize(st));
             if (timing)
                 for (auto& e : ev) (void)hipEventDestroy(e);

@@ -375,7 +375,7 @@ def test_solve_minnorm_exactly_rank_deficient(st, m, rank, method):
     assert _relmax(G @ C, R) < 1e-10
 
 
-def _kernel_system(n, m, seed=0, lambda_=0.02, s2=1e-3):
+def _kernel_system(n, m, seed=0, lambda_=0.02, s2=1e-3, unit_p=False):
     """A numerically rank-deficient SparseVFC system: Gaussian-kernel Gram of n cells on m control points."""
     from spateo_amd._synthetic import make_config
 
@@ -383,7 +383,7 @@ def _kernel_system(n, m, seed=0, lambda_=0.02, s2=1e-3):
     valid, Xv, Yv, idx, ctrl, beta = svo.sparsevfc_setup(X, Y, M=m, seed=seed)
     K = svo.con_K(ctrl, ctrl, beta)
     U = svo.con_K(Xv, ctrl, beta)
-    P = np.clip(np.random.default_rng(seed).random(len(Xv)), 1e-5, 1.0)
+    P = np.ones(len(Xv)) if unit_p else np.clip(np.random.default_rng(seed).random(len(Xv)), 1e-5, 1.0)
     UP = U.T * P[None, :]
     return U, UP @ U, K, UP @ Yv, lambda_ * s2
 
@@ -443,6 +443,26 @@ def test_deflated_solve_is_the_truncated_solve(st, n, m):
                     1.0, lowrank=True)
 
 
+def test_deflated_solve_shrinks_its_block_when_few_directions_are_truncated(st):
+    """Second call on a workspace (rank_hint, as the EM loop does) after a call that deflated <= 72 directions: a block of 128
+    vectors with three applications instead of 256 with two - the same truncated count and the same field as the Jacobi path
+    run through the same two calls (greedy, then hinted: the hinted factor is another factor of the same matrix)."""
+    U, G, K, R, ls2 = _kernel_system(24000, 1200, s2=1e-5, unit_p=True)
+    kd, kj = _k("float64"), _k("float64")
+    C0, info0, e0 = _run_minnorm(kd, G, K, ls2, R, method="deflated")
+    C1, info1, e1 = _run_minnorm(kd, G, K, ls2, R, method="deflated", rank_hint=int(e0[6]))
+    J0, _, f0 = _run_minnorm(kj, G, K, ls2, R, method="lowrank")
+    J1, _, f1 = _run_minnorm(kj, G, K, ls2, R, method="lowrank", rank_hint=int(f0[6]))
+    sc = np.abs(U @ J0).max()
+    d0, d1 = np.abs(U @ (C0 - J0)).max() / sc, np.abs(U @ (C1 - J1)).max() / sc
+    print(f"factor rank {int(e0[6])} / hinted {int(e1[6])}, truncated {int(e0[6]) - int(e0[1])} / {int(e1[6]) - int(e1[1])}; blocks "
+          f"{int(e0[7])} then {int(e1[7])}; field vs the Jacobi path on the same factor {d0:.2e} / {d1:.2e}")
+    assert info0 == 0 and info1 == 0 and int(e0[7]) == 256 and int(e1[7]) == 128
+    assert 0 < int(e0[6]) - int(e0[1]) <= 72 and int(e0[6]) == int(f0[6]) and int(e1[6]) == int(f1[6])
+    assert int(e0[1]) == int(f0[1]) and int(e1[1]) == int(f1[1])
+    assert d0 < 1e-4 and d1 < 1e-4
+
+
 def test_deflated_solve_falls_back_when_the_block_is_too_small(st):
     """With a cut-off far above eps more eigenvalues of the factor fall below it than the 256-vector block holds: the call
     must notice and return the Jacobi path's result."""
@@ -450,7 +470,7 @@ def test_deflated_solve_falls_back_when_the_block_is_too_small(st):
     k = _k("float64")
     Cj, info_j, ej = _run_minnorm(k, G, K, ls2, R, method="lowrank", rcond=1e-9)
     Cd, info_d, ed = _run_minnorm(k, G, K, ls2, R, method="deflated", rcond=1e-9)
-    assert info_d == 0 and int(ed[6]) - int(ed[1]) > 224, ed
+    assert info_d == 0 and int(ed[6]) - int(ed[1]) > 224 and int(ed[7]) == 0, ed
     assert int(ed[1]) == int(ej[1]) and _relmax(U @ Cd, U @ Cj) < 1e-9
 
 
