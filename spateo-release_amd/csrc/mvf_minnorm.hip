@@ -6,9 +6,13 @@
 // sparsevfc.py:110,194,250); in-tree analogue `_pinv(SigmaInv)` spateo/alignment/methods/morpho_class.py:1287.
 // lhs is symmetric, so its singular values are |eigenvalues| and the SVD-truncated solution is the formula above.
 //
-// Two hand-written solvers for gfx950 (no rocSOLVER) share the Jacobi kernels of this file:
+// Three hand-written solvers for gfx950 (no rocSOLVER) share the kernels of this file:
 //
-// mvf_solve_minnorm_lr (the host uses it from m = 1024): rank-revealing.
+// mvf_solve_minnorm_lrd (the host uses it from m = 1024): step 1 of mvf_solve_minnorm_lr, then ONLY the invariant subspace
+//   below the cut-off (block inverse iteration on the r x r matrix L^T L, Rayleigh-Ritz) and a deflated solve - see "deflated
+//   truncated solve" below; falls back to mvf_solve_minnorm_lr's steps 2 - 3 when its block cannot hold that subspace.
+//
+// mvf_solve_minnorm_lr (the full decomposition of the same factor; what mvf_pinv_diag needs): rank-revealing.
 //   1. A = L L^T + E, L m x r: greedy diagonally pivoted Cholesky (LAPACK pstrf's lazy scheme, one launch per pivot and one
 //      MFMA trailing update per 64), stopped when every remaining diagonal entry is <= 0.25 eps lambda_max; from the second
 //      call on a workspace it follows the previous call's pivot order in 64-column panels (three launches per 64 pivots).
@@ -28,7 +32,7 @@
 //      delta and   C = Y^T ( g .* (Y R) ),   g_i = [|lambda_i| > rcond max|lambda|] / (sigma_i^2 lambda_i).
 // Every transformation applied to Y is orthogonal to rounding, so Y^T Y == L L^T to rounding whatever the rotation
 // choices were: the result is the truncated solve of a matrix within O(eps ||A||) of A, like gelsd's.
-// mvf_pinv_diag evaluates diag(U pinv(A) U^T) from the Y either solver left behind.
+// mvf_pinv_diag evaluates diag(U pinv(A) U^T) from the Y either of the two Jacobi solvers left behind.
 #include "mvf_common.h"
 #include "mvf_solve.h"
 
