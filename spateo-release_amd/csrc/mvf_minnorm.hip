@@ -8,7 +8,7 @@
 //
 // Three hand-written solvers for gfx950 (no rocSOLVER) share the kernels of this file:
 //
-// mvf_solve_minnorm_lrd (the host uses it from m = 1024): step 1 of mvf_solve_minnorm_lr, then ONLY the invariant subspace
+// mvf_solve_minnorm_lrd (the host uses it from m = 640): step 1 of mvf_solve_minnorm_lr, then ONLY the invariant subspace
 //   below the cut-off (block inverse iteration on the r x r matrix L^T L, Rayleigh-Ritz) and a deflated solve - see "deflated
 //   truncated solve" below; falls back to mvf_solve_minnorm_lr's steps 2 - 3 when its block cannot hold that subspace.
 //
@@ -18,7 +18,7 @@
 //      call on a workspace it follows the previous call's pivot order in 64-column panels (three launches per 64 pivots).
 //   2. one-sided block Jacobi on the r columns of L only;  3. as below with delta = 0.
 //
-// mvf_solve_minnorm (m < 1024, where the factor keeps nearly every column and a warm start pays): full width.
+// mvf_solve_minnorm (m < 640, where the factor keeps nearly every column and a warm start pays): full width.
 //   1. A + delta I = L L^T      blocked Cholesky of mvf_solve.hip, delta = shift * mean(diag) > 0 only makes the
 //                               factorisation exist (A is numerically semi-definite); it is subtracted again below.
 //   2. one-sided block Jacobi on the COLUMNS of L (Veselic-Hari: orthogonalising L's columns diagonalises L^T L, one

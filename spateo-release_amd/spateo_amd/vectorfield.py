@@ -45,6 +45,7 @@ _DEFAULT_DTYPE = "float64"
 # developer override of the minimum-norm solver choice ("lowrank" | "full"; None = by M): set by tests and probes, never by
 # the environment
 MINNORM_METHOD = None
+DEFLATED_MIN_M = 640  # control points from which the rank-revealing (deflated) solve is the default
 
 
 def _make_kernels(device, dtype):
@@ -392,7 +393,9 @@ class SparseVFCEngine:
         # measured per solve in the EM's steady state (ms, lowrank / full): M = 500: 8.7 / 3.6, 1000: 17.3 / 18.4,
         # 1500: 20.9 / 33, 2000: 21.6 / 54, 3000: 23.6 / 113 - the full-width warm start wins while the factor keeps
         # nearly every column
-        self.mn_method = MINNORM_METHOD or ("deflated" if self.M >= 1024 else "full")
+        # round 4, deflated / full (ms): M = 640: 4.6 / 6.5, 768: 5.0 / 10.3, 896: 7.5 / 14.5, 1000: 7.5 / 17.5 (the deflated route
+        # needs >= 512 factor columns, which M >= 640 delivers: r = 632 there; below that the call is the Jacobi form)
+        self.mn_method = MINNORM_METHOD or ("deflated" if self.M >= DEFLATED_MIN_M else "full")
         self.rank_hint = 0
         # lstsq_method="cholesky" (extension, not a reference mode): jitter-escalated Cholesky, the round-1 solver
         self.jitter = 0.0

@@ -92,15 +92,19 @@ def test_sparsevfc_end_to_end_well_regularised(st, dtype):
     assert all(abs(ref["P"][i, 0] - 0.75) < 10 * tol for i in diff)
 
 
-def test_sparsevfc_default_lambda_within_reference_noise_floor(st):
+@pytest.mark.parametrize("n,M", [(6000, 300), (10000, 800)])
+def test_sparsevfc_default_lambda_within_reference_noise_floor(st, n, M):
     """lambda_ = 0.02 (Spateo's default): lambda sigma^2 K becomes negligible, the normal equations are numerically
     singular and the reference's own result moves by O(1e-3) under changes that leave its mathematics untouched (LAPACK
     driver swapped, Gram summed in another order: tests/_floors.py).  The GPU field, sigma^2, P and energy must each sit
-    within 1.25x of that measured floor (or inside the north-star tolerance where the floor is below it)."""
+    within 1.25x of that measured floor (or inside the north-star tolerance where the floor is below it).  M = 300: the
+    full-width eigensolve; M = 800: the deflated rank-revealing solve (the default from M = 640)."""
     import _floors as F
 
-    X, V = _c2(6000)
-    kw = dict(M=300, lambda_=0.02, MaxIter=12, seed=0, lstsq_method="scipy")
+    X, V = _c2(n)
+    kw = dict(M=M, lambda_=0.02, MaxIter=12, seed=0, lstsq_method="scipy")
+    if M == 800:
+        kw.update(MaxIter=8, ecr=0.0)  # a fixed number of iterations: the reference's own eigh variant stops elsewhere here
     ref = svo.SparseVFC(X, V, None, **kw)
     table = F.floor_table(X, V, None, ref, kw, f32=False)
     got = st.SparseVFC(X, V, None, dtype="float64", device="cuda:0", **kw)
