@@ -390,7 +390,8 @@ def main():
             if eng.mn_method == "deflated" and sv["factor_rank"] and sv["factor_rank"] >= 512:
                 # pivoted factor 2 r M^2; S2 = L^T L 2 r^2 M; Cholesky + inverse rows of S2 4 r^3 / 3; S2^-1 2 r^3; the
                 # block (b = 256): two Gram + two orthonormalising + three b x r x r products, Jacobi sweeps on b x b
-                rr, bb = float(sv["factor_rank"]), 256.0
+                rr, bb = float(sv["factor_rank"]), float((eng.solver_stats.get("block") or [256])[-1] or 256)
+                sv["block"] = int(bb)
                 fl = (2.0 * rr * Mc * Mc + 2.0 * rr * rr * Mc + 10.0 / 3.0 * rr**3 + 8.0 * bb * bb * rr + 6.0 * bb * rr * rr +
                       sw * 8.0 * bb**3)
             elif eng.mn_method in ("lowrank", "deflated") and sv["factor_rank"]:

@@ -774,6 +774,8 @@ class SparseVFCEngine:
             self.solver_stats["sweeps"].append(float(h[1]))
             self.solver_stats["rank"].append(int(h[2]))
             self.solver_stats.setdefault("factor_rank", []).append(self.rank_hint)
+            if dfl:
+                self.solver_stats.setdefault("block", []).append(int(h[1 + 7]))  # 256 / 128; 0 = the Jacobi form answered
             self._lr_ran = True
             self._solver_signature = (3.0, 0.0, float(h[1]), float(h[2]), float(self.rank_hint), 0.0)
             return h[1 + 12:]
