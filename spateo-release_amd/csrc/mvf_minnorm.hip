@@ -1735,7 +1735,8 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
     if (rp > r) MVF_CHECK_HIP(hipMemsetAsync(Y + r * mp, 0, (size_t)(rp - r) * mp * sizeof(double), st));
 
     // 2'. deflated solve: only the invariant subspace below the cut-off is computed (see DEFL_B above)
-    if (deflate && r >= 2 * DEFL_B && debug_opt(DBG_LR_NO_DEFLATE) == 0) {
+    // (2 rp rows of the factor-with-inverse layout must fit a launch grid: larger factors take the Jacobi path)
+    if (deflate && r >= 2 * DEFL_B && 2 * rp <= 65535 && debug_opt(DBG_LR_NO_DEFLATE) == 0) {
         const DeflBuf d = defl_layout(rp);
         char* dw = ws + p.off_d;
         double *S2 = (double*)(dw + d.s2), *Za = (double*)(dw + d.za), *Zb = (double*)(dw + d.zb);
