@@ -216,6 +216,14 @@ def main():
                          "first rank-revealing solve the fit continues on the r control points that carry the numerical "
                          "rank (N r^2 instead of N M^2 work; field at the reference's noise floor, not its arithmetic)")
     ap.add_argument("--no-pivot", action="store_true", help="skip the extra pivot-mode run of the default line")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1 only: run the HEADLINE itself through the multi-rank protocol on a process group of one rank "
+                         "(every collective of the EM step executes on RCCL; same arithmetic, bit-equal result)")
+    ap.add_argument("--collective", default="torch", choices=["torch", "mvf"],
+                    help="who issues the step's all-reduces: torch.distributed (RCCL under the nccl backend) or "
+                         "mvf_allreduce_stats of the C ABI on the engine's own RCCL communicator")
+    ap.add_argument("--no-rccl-world1", action="store_true",
+                    help="skip the extra N = 1 runs that execute the step's collectives on a one-rank RCCL communicator")
     args = ap.parse_args()
 
     import torch
@@ -283,12 +291,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    def run_mode(dtype, steps, warmup, gram_mode="full"):
+    def ensure_group():
+        """A process group of ONE rank on RCCL (N = 1 runs that force the collectives); idempotent."""
+        if not dist.is_initialized():
+            import socket
+
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                port = s_.getsockname()[1]
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ["MASTER_PORT"] = str(port)
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(device))
+
+    def run_mode(dtype, steps, warmup, gram_mode="full", force=False, collective="torch"):
         """W warm-up + K timed EM iterations of the whole workload in one cell dtype; returns the timing record."""
         kern = HipKernels(device, dtype)
         cache_u = {"auto": "auto", "on": True, "off": False}[args.cache_u]
-        eng = SparseVFCEngine(Xv[lo:hi], Yv[lo:hi], ctrl, beta, dtype=dtype, device=device, distributed=distributed,
-                              n_total=N, kernels=kern, cache_u=cache_u, gram_mode=gram_mode)
+        if force and collective == "torch":
+            ensure_group()
+        eng = SparseVFCEngine(Xv[lo:hi], Yv[lo:hi], ctrl, beta, dtype=dtype, device=device,
+                              distributed=distributed or (force and collective == "torch"),
+                              n_total=N, kernels=kern, cache_u=cache_u, gram_mode=gram_mode, force_collectives=force,
+                              collective=collective)
         eng.lstsq_method = args.lstsq
         eng.init_state(gamma=0.9)
         # the coefficient solve, bracketed by events on the launch stream (it synchronises internally once per Jacobi
@@ -308,7 +332,7 @@ def main():
         for _ in range(warmup):
             eng.em_step(**step_kw)
         kern.gram_events = []
-        eng.comm_events = [] if distributed else None
+        eng.comm_events = [] if eng.multi else None
         solve_events.clear()
         n_sweeps0 = len(eng.solver_stats["sweeps"])
         barrier()
@@ -405,7 +429,7 @@ def main():
         sv["TFLOPs"] = fl / (sv["avg_ms"] * 1e-3) / 1e12
         sv["frac_of_f64_mfma_peak"] = sv["TFLOPs"] / PEAK_F64_MFMA_TFLOPS
         sv["bound"] = "latency (dependent launches / rotation chains), not MFMA"
-        if distributed:
+        if eng.multi:
             # what the first multi-GPU run needs to explain itself: per-rank Gram time and the collectives
             # per step: tri(G) (the big one, issued asynchronously: its interval also covers the rhs / quadform kernels and
             # the [R | stats] all-reduce it overlaps), [R | stats], and the two scalar-sized ones (E-step MIN, step end)
@@ -423,16 +447,24 @@ def main():
             log(f"[bench rank {rank}] " + json.dumps(mine))
             allr = [None] * world
             try:
-                dist.all_gather_object(allr, mine)
+                if distributed:
+                    dist.all_gather_object(allr, mine)
+                else:
+                    allr = [mine]
             except Exception as exc:  # noqa: BLE001
                 log(f"[bench rank {rank}] gathering the per-rank records failed: {exc!r}")
                 allr = [mine]
             rec["per_rank"] = allr
             rec["comm"] = {"collectives_per_step": len(eng.comm_events) / steps, "allreduce_bytes": mine["allreduce_bytes"],
+                           "backend": ("mvf_allreduce_stats (C ABI, RCCL communicator of the engine)" if collective == "mvf"
+                                       else f"torch.distributed {dist.get_backend()}"),
+                           "ranks": world, "forced_on_one_rank": bool(force and world == 1),
                            "allreduce_ms_max": max((r_["allreduce_ms"] or 0.0) for r_ in allr),
                            "note": "event time on the compute stream from issuing a collective to the stream having waited "
                                    "for it: includes waiting for the slowest rank to arrive; the big one is asynchronous, "
                                    "its interval spans the rhs / quadform kernels and the [R | stats] all-reduce"}
+        if eng.comm is not None:
+            eng.comm.close()
         kern.drop_ublk()
         del eng, kern
         torch.cuda.empty_cache()
@@ -440,8 +472,10 @@ def main():
 
     del X, V
     try:
+        if args.force_collectives and world != 1:
+            raise SystemExit("--force-collectives is an N = 1 option (with N > 1 the collectives run anyway)")
         main_rec = run_mode(args.dtype, args.steps, max(args.warmup, 5) if args.gram_mode == "pivot" else args.warmup,
-                            args.gram_mode)
+                            args.gram_mode, force=args.force_collectives, collective=args.collective)
     except Exception as exc:
         # one JSON line per failing rank on stderr (which rank, what, where), then the error itself
         import traceback
@@ -482,6 +516,9 @@ def main():
         "env": {k_: v_ for k_, v_ in sorted(os.environ.items()) if k_.startswith("MVF_")},
         "developer_options": __import__("spateo_amd")._lib.debug_options(),   # mvf_debug_option values != default
     }
+    if "comm" in main_rec and not distributed:
+        out["per_rank"], out["comm"] = main_rec["per_rank"], main_rec["comm"]
+        out["config"]["force_collectives"] = True
     if distributed:
         out["per_rank"], out["comm"] = main_rec["per_rank"], main_rec["comm"]
         out["config"]["parallelism"] = (f"cells block-sharded over {world} GPUs; per EM step the all-reduce of tri(G) "
@@ -511,6 +548,31 @@ def main():
                                        "after the first rank-revealing solve the fit continues on the control points its "
                                        "pivoted factorisation selected (C zero elsewhere, V = U C exact); parity of this "
                                        "mode on the CPU sample's arrays under parity.pivot"}
+
+    # ---------------------------------------------------------------- the step's collectives on RCCL with one rank (N = 1)
+    if world == 1 and not args.no_rccl_world1 and not args.force_collectives and args.gram_mode == "full":
+        # The exchange of the multi-GPU path, executed: force_collectives runs the multi-rank protocol (split Gram stages,
+        # asynchronous all-reduce of tri(G) overlapped with the rhs kernels, [R | stats], the E-step MIN and the closing
+        # 14-double collective) on a communicator of ONE rank - RCCL accepts that on a one-GPU box - through both back ends.
+        # Same arithmetic as the headline (a single rank's sum is the identity); the step-time difference to the headline
+        # is what the protocol costs one rank before any xGMI transfer: the split launches, pack / unpack, and the
+        # collectives' launch latency.
+        kr, wr = max(2, min(args.steps, 3)), 1
+        out["rccl_world1"] = {"note": "force_collectives on a one-rank RCCL communicator: every collective of the EM step "
+                                      "executes on RCCL; NOT a multi-GPU measurement (no xGMI traffic)",
+                              "headline_ms_per_step": ms_per_step, "steps": kr, "warmup": wr}
+        for coll in ("torch", "mvf"):
+            try:
+                rr = run_mode(args.dtype, kr, wr, force=True, collective=coll)
+                out["rccl_world1"][coll] = {"ms_per_step": rr["ms_per_step"], "comm": rr["comm"],
+                                            "per_rank": rr["per_rank"], "sigma2_after": rr["sigma2_after"],
+                                            "protocol_overhead_ms": rr["ms_per_step"] - ms_per_step}
+            except Exception as exc:  # noqa: BLE001 - the headline line must survive a failure of this extra
+                import traceback
+
+                out["rccl_world1"][coll] = {"failed": repr(exc), "traceback": traceback.format_exc().splitlines()[-4:]}
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
     # ---------------------------------------------------------------- con_K HBM bandwidth (N = 1, rank 0)
     if rank == 0 and world == 1 and not args.no_conk:
@@ -603,6 +665,7 @@ def main():
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

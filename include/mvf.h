@@ -24,7 +24,8 @@
  *     the entry point that uses it: the workspace of mvf_solve_minnorm_lr keeps the pivot order of its last finished
  *     factorisation (the next call's hint), the workspaces of the two minimum-norm solves keep their decomposition for
  *     `reuse` calls and mvf_pinv_diag, `basis` keeps the eigenvectors of mvf_solve_minnorm for its warm start.  A fresh
- *     (or overwritten) workspace simply means no hint / no reuse.
+ *     (or overwritten) workspace simply means no hint / no reuse.  The one opaque object is the `mvf_comm` handle of the
+ *     multi-GPU exchange (an RCCL communicator, created and destroyed by the caller; libmvf.so links librccl for it).
  */
 #ifndef MVF_H
 #define MVF_H
@@ -52,7 +53,7 @@ enum {
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
 const char* mvf_last_error(void);
-int mvf_version(void);                 /* ABI version, currently 4 */
+int mvf_version(void);                 /* ABI version, currently 5 */
 /* Developer options, process-wide: which kernel variant / launch plan is taken in A/B measurements and in the tests that
  * compare the variants bit for bit.  The library NEVER reads the environment (rounds 1 - 3 had getenv knobs in launch
  * paths); nothing but this call changes its behaviour.  value 0 = default.  Names: "conk_form" (1 rows, 2 flat, 3 2d),
@@ -140,12 +141,9 @@ int mvf_estep_p(const void* r, int64_t n, double sigma2, double gamma, double a,
  * are regenerated from x4/ctrl4 in registers and accumulated with v_mfma_f64_16x16x4_f64 in both dtypes, so G is the
  * exact Gram matrix of those values; per-slice partial tiles are summed in a fixed order (deterministic).  No
  * process-global state: the library's behaviour depends on its arguments only.
- * Outputs are float64: G (m x m, full symmetric), R (m x 3).  They hold THIS rank's partial sums.  The collective is
- * the CALLER's: the library holds no communicator; the host all-reduces the packed triangle of G (asynchronously, while
- * the rhs kernels run) and then [R | scalars] with torch.distributed (RCCL over xGMI).
- * SURVEY.md 8(b)'s `mvf_allreduce_stats(ctx, buf)` - an opaque context holding an RCCL communicator - is INTENTIONALLY
- * ABSENT: nothing in this build pool can execute RCCL between two devices, so such an entry point could not be tested; a
- * C / C++ host calls ncclAllReduce on the same two device pointers between the stages below. */
+ * Outputs are float64: G (m x m, full symmetric), R (m x 3).  They hold THIS rank's partial sums; the exchange is
+ * mvf_allreduce_stats (below) or the host's own collective on the same device pointers: the packed triangle of G is
+ * all-reduced asynchronously while the rhs kernels run, then [R | scalars]. */
 size_t mvf_gram_workspace_bytes(int64_t n, int64_t m, mvf_dtype dtype);
 int mvf_gram(const void* x4, const void* P, const void* y4, int64_t n, const void* ctrl4, int64_t m, double beta,
              double* G, double* R, void* workspace, size_t workspace_bytes, mvf_dtype dtype, void* stream);
@@ -287,6 +285,34 @@ int mvf_quadform(const double* K, const double* C, int64_t m, int nrhs, double* 
  * multi-GPU host all-reduces the packed triangle of G (36 MB instead of 72 MB at m = 3000). */
 int mvf_sym_pack(const double* G, int64_t m, double* tri, void* stream);
 int mvf_sym_unpack(const double* tri, int64_t m, double* G, void* stream);
+
+/* ---- the EM step's exchange: all-reduce of the sufficient statistics over RCCL (xGMI) -------------------------------
+ * cells are block-sharded over the GPUs of one node, one process per GPU; per EM step every rank
+ * contributes its partial  [tri(G) | R | sum P, sum P r, #(P > theta), ...]  (contiguous float64, caller-owned) and all
+ * ranks continue with the sums.  The reference has no counterpart (single process, NumPy); the statement it distributes
+ * is `lhs = UP.dot(U) ...; rhs = UP.dot(Y)` of SparseVFC (App. A 5c; call site
+ * spateo/tdr/morphometrics/morphofield/sparsevfc.py:189-198) - sums over cells, hence an all-reduce of the partials.
+ *   mvf_comm_unique_id : id_out = MVF_COMM_ID_BYTES host bytes (ncclGetUniqueId).  ONE rank calls it and hands the bytes to
+ *                        the others out of band (the Python host broadcasts them with torch.distributed / its store).
+ *   mvf_comm_create    : collective over all `nranks` ranks (ncclCommInitRank) on the CURRENT HIP device, which becomes the
+ *                        communicator's device; nranks = 1 is valid (a single-rank communicator: how the one-GPU tests
+ *                        execute this path on RCCL).  The handle owns nothing but the RCCL communicator.
+ *   mvf_comm_destroy   : frees it (NULL is a no-op).
+ *   mvf_comm_info      : nranks / rank / device of a handle (any pointer may be NULL).
+ *   mvf_allreduce_stats: buf[0..count) (DEVICE float64, in place) <- elementwise SUM (MVF_RED_SUM) or MIN (MVF_RED_MIN: the
+ *                        E-step's global min-non-zero rule) over the ranks; asynchronous on `stream` (ordered with the
+ *                        kernels the caller launched there: pass a second stream + events to overlap it with compute, as
+ *                        the host does for tri(G)).  The current device must be the communicator's.  Every rank must call
+ *                        with the same count / op in the same order.  RCCL's sums are in a fixed ring order: every rank
+ *                        receives bit-identical results, which the redundant coefficient solve relies on. */
+typedef struct mvf_comm mvf_comm;
+#define MVF_COMM_ID_BYTES 128
+enum { MVF_RED_SUM = 0, MVF_RED_MIN = 1 };
+int mvf_comm_unique_id(void* id_out);
+int mvf_comm_create(mvf_comm** comm_out, int nranks, int rank, const void* id);
+int mvf_comm_destroy(mvf_comm* comm);
+int mvf_comm_info(const mvf_comm* comm, int* nranks, int* rank, int* device);
+int mvf_allreduce_stats(mvf_comm* comm, double* buf, int64_t count, int op, void* stream);
 
 /* ---- differential-geometry evaluators -------------------------------------------------------------------------
  * Replaces: dynamo `Jacobian_rkhs_gaussian` and `compute_{acceleration,curvature,curl,torsion,divergence}` =

@@ -737,6 +737,9 @@ __global__ __launch_bounds__(256) void pchol_init_kernel(const double* __restric
         stt->panels = 0;
         // the hint is usable only if this workspace really holds the order of a finished factorisation of that length
         stt->hint_broken = !(use_hint && stt->magic == PCHOL_MAGIC && stt->order_len == hint_len);
+        // a workspace without a finished factorisation of that length (fresh, foreign, other m) carries no deflation count
+        // either: the deflated solve's block choice must be a function of the inputs, not of uninitialised memory
+        if (stt->hint_broken) stt->defl_nsel = 0;
         stt->magic = 0;
         stt->panel_nvalid = 0;
         stt->maxdiag = bc[1];
@@ -1728,6 +1731,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
     if (r == 0) {  // the zero matrix: minimum-norm solution 0
         MVF_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)m * nrhs * sizeof(double), st));
         MVF_CHECK_HIP(hipMemsetAsync(einfo, 0, 6 * sizeof(double), st));
+        if (deflate) MVF_CHECK_HIP(hipMemsetAsync(einfo + 7, 0, sizeof(double), st));  // no block ran
         MVF_CHECK_HIP(hipStreamSynchronize(st));
         return 0;
     }
@@ -1930,6 +1934,9 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
     }
     const double hsw[1] = {(double)sweeps + (hrot != 0 ? 0.5 : 0.0)};  // x.5 = sweep cap hit before convergence
     MVF_CHECK_HIP(hipMemcpyAsync(einfo, hsw, sizeof(double), hipMemcpyHostToDevice, st));
+    // mvf_solve_minnorm_lrd answered by this path (small factor, launch-grid limit, lr_no_deflate, a failed attempt):
+    // einfo[7] = 0, the block size of a deflated solve that did not run (mvf.h)
+    if (deflate) MVF_CHECK_HIP(hipMemsetAsync(einfo + 7, 0, sizeof(double), st));
     MVF_CHECK_HIP(hipStreamSynchronize(st));
     return 0;
 }

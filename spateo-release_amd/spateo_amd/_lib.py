@@ -27,6 +27,8 @@ _LEGACY_ENV = {  # environment name -> (option, value parser)
 MVF_F32, MVF_F64 = 0, 1
 MVF_ESTEP_MIN_DOUBLES = 4098
 
+MVF_COMM_ID_BYTES = 128
+RED_SUM, RED_MIN = 0, 1
 GRAM_TILES, GRAM_RHS, GRAM_REDUCE, GRAM_REDUCE_RHS = 1, 2, 4, 8
 EVAL_V, EVAL_JAC, EVAL_DIV, EVAL_CURL, EVAL_ACC, EVAL_CURV, EVAL_TORS, EVAL_JDET = 1, 2, 4, 8, 16, 32, 64, 128
 
@@ -71,6 +73,11 @@ SIGNATURES = {
     "mvf_quadform": (_i, [_p, _p, _i64, _i, _p, _p, _p]),
     "mvf_sym_pack": (_i, [_p, _i64, _p, _p]),
     "mvf_sym_unpack": (_i, [_p, _i64, _p, _p]),
+    "mvf_comm_unique_id": (_i, [_p]),
+    "mvf_comm_create": (_i, [C.POINTER(_p), _i, _i, _p]),
+    "mvf_comm_destroy": (_i, [_p]),
+    "mvf_comm_info": (_i, [_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mvf_allreduce_stats": (_i, [_p, _p, _i64, _i, _p]),
     "mvf_eval": (_i, [_p, _i64, _p, _i64, _d, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "mvf_eval_affine": (_i, [_p, _i64, _p, _i64, _d, _p, C.POINTER(C.c_double), _i, _p, _p, _p, _p, _p, _p, _p, _p, _i,
                              _p]),

@@ -101,7 +101,8 @@ def _morphofield_sparsevfc(
     input and learned velocities stays below ``min_vel_corr`` (``sparsevfc.py:103-238``).  Returns the vf dict
     (keys of SURVEY.md Appendix A step 6 + ``method = "sparsevfc"``).  Extra ``**kwargs`` go to ``SparseVFC``
     (dynamo's ``a, beta, ecr, gamma, minP, MaxIter, theta, velocity_based_sampling`` and this package's
-    ``dtype, device, distributed``)."""
+    ``dtype, device, distributed``), except ``reuse_identical_restarts`` (this wrapper's opt-in: see the restart loop)."""
+    reuse_identical = bool(kwargs.pop("reuse_identical_restarts", False))
     if NX is not None:
         predict_X = NX
     else:
@@ -123,18 +124,21 @@ def _morphofield_sparsevfc(
             )
             restart_seed = np.arange(restart_num) * 100
         trials, scores, attempt = [], [], 0
-        # With velocity_based_sampling (dynamo's default) the control-point draw re-seeds itself with its own constant
-        # (SURVEY.md App. A step 2), so `seed` does not reach the fit: every restart is the SAME deterministic
-        # computation.  It is then run once and its result reused (same dict the recomputation would return, bit for
-        # bit: the device reductions are deterministic) instead of redoing preprocessing, uploads, the U cache and the
-        # whole EM loop up to restart_num times.
-        seed_free = bool(kwargs.get("velocity_based_sampling", True))
+        # Default: one fit per restart, exactly the reference's loop (:178-232).  `reuse_identical_restarts=True` (opt-in
+        # extension, documented deviation): with velocity_based_sampling (dynamo's default) the control-point draw is
+        # believed to re-seed itself with its own constant (a [VERIFY] item of the restated
+        # dynamo source), so that `seed` does not reach the fit and every restart is the SAME deterministic computation;
+        # it is then run once and its result reused instead of redoing preprocessing, uploads, the U cache and the EM
+        # loop up to restart_num times.  If real dynamo honours the seed the reference's restarts differ - hence opt-in.
+        seed_free = reuse_identical and bool(kwargs.get("velocity_based_sampling", True))
         memo = {}
         while True:
-            key = None if seed_free else int(restart_seed[attempt])
-            if key not in memo:
-                memo[key] = fit(seed=restart_seed[attempt])
-            cur = memo[key]
+            if seed_free:
+                if None not in memo:
+                    memo[None] = fit(seed=restart_seed[attempt])
+                cur = memo[None]
+            else:
+                cur = fit(seed=restart_seed[attempt])
             score = _cosine_score(cur)
             trials.append(cur)
             scores.append(score)

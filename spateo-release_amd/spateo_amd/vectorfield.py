@@ -42,9 +42,6 @@ __all__ = [
 ]
 
 _DEFAULT_DTYPE = "float64"
-# developer override of the minimum-norm solver choice ("lowrank" | "full"; None = by M): set by tests and probes, never by
-# the environment
-MINNORM_METHOD = None
 DEFLATED_MIN_M = 640  # control points from which the rank-revealing (deflated) solve is the default
 
 
@@ -299,8 +296,13 @@ class SparseVFCEngine:
     identical on every rank.  ``n_total`` = global number of cells (for gamma and the initial sigma^2).
     """
 
+    # which truncated minimum-norm solver answers once the system is rank deficient: None = by M ("deflated" from
+    # DEFLATED_MIN_M control points on, else "full"), or "deflated" | "lowrank" | "full" for every engine built afterwards
+    minnorm_method = None
+
     def __init__(self, X, Y, ctrl, beta, *, dtype=None, device=None, distributed=False, group=None, n_total=None,
-                 kernels=None, cache_u="auto", shard_sizes=None, gram_mode="full"):
+                 kernels=None, cache_u="auto", shard_sizes=None, gram_mode="full", force_collectives=False,
+                 collective="torch"):
         dtype = dtype or _DEFAULT_DTYPE
         X = np.asarray(X, dtype=np.float64)
         Y = np.asarray(Y, dtype=np.float64)
@@ -315,10 +317,27 @@ class SparseVFCEngine:
         # The kernels are 3 columns wide; a wider Y (kernel_interpolation: Dy = #keys) is processed as column groups
         # that share ONE Gram matrix per EM step (G does not depend on Y) and get their own rhs / solve / apply.
         self.ng = (self.Dy + 2) // 3
+        clear_eval_cache()  # evaluator results of an earlier call must not shrink the HBM this fit plans with
         self.k = kernels if kernels is not None else _make_kernels(device, dtype)
         self.distributed = bool(distributed)
         self.group = group
         self.rank, self.world = _dist_info(distributed, group)
+        # `multi`: the step runs the multi-rank protocol (split Gram stages, packed-triangle all-reduce, [R | stats] and the
+        # closing 14-double collective).  force_collectives=True takes it with ONE rank too: every collective then executes
+        # on the real backend (RCCL on a one-GPU box) and, a single rank's sum being the identity, the fit stays bit-equal
+        # to the plain single-process one - how the exchange is tested and timed without a second GPU.
+        # collective: "torch" = torch.distributed all_reduce (RCCL under the "nccl" backend, gloo in the CPU tests);
+        # "mvf" = mvf_allreduce_stats through the C ABI on this engine's own RCCL communicator (_comm.MvfComm)
+        if collective not in ("torch", "mvf"):
+            raise ValueError("collective must be 'torch' or 'mvf'")
+        if force_collectives and collective == "torch" and not self.distributed:
+            raise ValueError("force_collectives with collective='torch' needs distributed=True and an initialised process "
+                             "group (world size 1 is fine); collective='mvf' creates its own single-rank communicator")
+        self.force_collectives = bool(force_collectives)
+        self.multi = self.world > 1 or self.force_collectives
+        self.collective = collective
+        self.comm = None
+        self._comm_stream = None
         self.n_local = len(X)
         self.n_total = int(n_total) if n_total is not None else self.n_local
         # rows per rank (block shards by default; the caller states them when it brings its own uneven shards)
@@ -334,6 +353,11 @@ class SparseVFCEngine:
         self.center = ctrl.mean(0) if self.M else np.zeros(self.D)
 
         k = self.k
+        if self.multi and collective == "mvf":
+            from ._comm import MvfComm
+
+            self.comm = MvfComm(k.device, self.rank, self.world, group)
+            self._comm_stream = torch.cuda.Stream(device=k.device)
         self.x4 = k.to_x4(X, self.center)
         self.y4 = [k.to_x4(Y[:, 3 * g : 3 * g + 3]) for g in range(self.ng)]
         f64 = torch.float64
@@ -356,7 +380,7 @@ class SparseVFCEngine:
         # "pivot" (extension, default off): once the rank-revealing solve has run, the rest of the fit works on the control
         # points its pivoted factorisation selected (`_restrict_to_pivots`)
         self.gram_mode = gram_mode
-        self.ctrl_full, self.subset, self._quad_carry = ctrl, None, None
+        self.ctrl_full, self.subset, self._quad_carry, self._restrict_pending = ctrl, None, None, False
         self.pivot_max_fraction = 0.75   # no switch unless the factor keeps at most this share of the control points
         self.comm_events = None  # bench.py: list of (start, end) events around the collectives
         self._cache_u_wanted = cache_u
@@ -395,7 +419,7 @@ class SparseVFCEngine:
         # nearly every column
         # round 4, deflated / full (ms): M = 640: 4.6 / 6.5, 768: 5.0 / 10.3, 896: 7.5 / 14.5, 1000: 7.5 / 17.5 (the deflated route
         # needs >= 512 factor columns, which M >= 640 delivers: r = 632 there; below that the call is the Jacobi form)
-        self.mn_method = MINNORM_METHOD or ("deflated" if self.M >= DEFLATED_MIN_M else "full")
+        self.mn_method = self.minnorm_method or ("deflated" if self.M >= DEFLATED_MIN_M else "full")
         self.rank_hint = 0
         # lstsq_method="cholesky" (extension, not a reference mode): jitter-escalated Cholesky, the round-1 solver
         self.jitter = 0.0
@@ -420,7 +444,7 @@ class SparseVFCEngine:
         # one contiguous float64 buffer for the all-reduces of an EM step: [packed upper triangle of G (M (M + 1) / 2;
         # only when there is more than one rank) | R_g (M * 3) per column group | stats (5)]
         self.G = k.zeros(M, M, dtype=f64)
-        ntri = M * (M + 1) // 2 if self.world > 1 else 0
+        ntri = M * (M + 1) // 2 if self.multi else 0
         self.red = k.zeros(ntri + 3 * M * ng + 5, dtype=f64)
         self.tri = self.red[:ntri]
         self.R = [self.red[ntri + 3 * M * g : ntri + 3 * M * (g + 1)].view(M, 3) for g in range(ng)]
@@ -482,7 +506,7 @@ class SparseVFCEngine:
         self._setup_control_points(self.ctrl_full[self.subset])
         self._build_u_cache()
         self.rank_hint, self.basis, self.basis_valid = 0, None, False
-        self.mn_method = (MINNORM_METHOD or "deflated") if hasattr(k, "solve_minnorm_lr") else self.mn_method
+        self.mn_method = (self.minnorm_method or "deflated") if hasattr(k, "solve_minnorm_lr") else self.mn_method
         self.solver_stats.setdefault("pivot_subsets", []).append(int(len(p)))
         self.solver_stats["pivot_subset"] = int(len(p))
         return True
@@ -491,17 +515,34 @@ class SparseVFCEngine:
     def _all_reduce(self, t, op="sum", wait=True):
         """All-reduce `t` in place over the ranks.  wait=False: returns a handle for `_wait` - the collective runs on the
         backend's own stream (RCCL) / thread (gloo) while this rank keeps enqueuing kernels that do not touch `t`."""
-        if self.world == 1:
+        if not self.multi:
             return None
-        import torch.distributed as dist
-
         ev = None
         if self.comm_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
+        nbytes = t.numel() * t.element_size()
+        if self.comm is not None:
+            # C-ABI path: ncclAllReduce enqueued by mvf_allreduce_stats.  Synchronous form: on the compute stream itself
+            # (stream order IS the dependency).  Asynchronous form: on the engine's communication stream, fenced by events
+            # on both sides, so the rhs / quadform kernels enqueued next run beside it.
+            cur = torch.cuda.current_stream(self.k.device)
+            if wait:
+                self.comm.all_reduce(t, op, cur)
+                self._wait((None, ev, nbytes))
+                return None
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            self._comm_stream.wait_event(ready)
+            self.comm.all_reduce(t, op, self._comm_stream)
+            done = torch.cuda.Event()
+            done.record(self._comm_stream)
+            return (done, ev, nbytes)
+        import torch.distributed as dist
+
         work = dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MIN, group=self.group,
                                async_op=not wait)
-        handle = (work, ev, t.numel() * t.element_size())
+        handle = (work, ev, nbytes)
         if wait:
             self._wait((None,) + handle[1:])
             return None
@@ -511,7 +552,9 @@ class SparseVFCEngine:
         if handle is None:
             return
         work, ev, nbytes = handle
-        if work is not None:
+        if isinstance(work, torch.cuda.Event):
+            torch.cuda.current_stream(self.k.device).wait_event(work)  # C-ABI path: the compute stream waits for the comm stream
+        elif work is not None:
             work.wait()  # RCCL: the current stream waits for the collective; gloo: the host does
         if ev is not None:
             ev[1].record()
@@ -521,7 +564,16 @@ class SparseVFCEngine:
     def init_state(self, gamma=0.9):
         """V = 0, C = 0, sigma^2 = sum ||Y||^2 / (N Dy)  (Appendix A step 4)."""
         k = self.k
+        self._restrict_pending = False
+        if self.subset is not None:
+            # a previous fit of this engine ended on a pivot subset: back to the full control-point set
+            self.subset, self._quad_carry = None, None
+            self._setup_control_points(self.ctrl_full)
+            self._build_u_cache()
+            self.basis = None
+            self.mn_method = self.minnorm_method or ("deflated" if self.M >= DEFLATED_MIN_M else "full")
         self.spr.zero_()
+        self.P.fill_(1.0)  # sigma^2_0 = sum ||Y||^2 / (N Dy): unit weights (a previous fit of this engine left its posterior)
         empty_ctrl = self.ctrl4[:0]
         for g in range(self.ng):
             self.C[g].zero_()
@@ -558,6 +610,9 @@ class SparseVFCEngine:
         all-reduced or replicated deterministic values, so all ranks decide alike) and one for sigma^2 + the agreement
         check; the minimum-norm solve adds its own (one per Jacobi sweep)."""
         k = self.k
+        if self._restrict_pending:
+            self._restrict_pending = False
+            self._restrict_to_pivots()
         # ---- E-step: dynamo's `t1[t1 == 0] = min(t1[t1 != 0])` needs the GLOBAL min-non-zero t1; phase 1 leaves it in
         # device memory, phase 2 reads it from there
         mins = k.estep_min(self.r, self.sigma2)
@@ -566,7 +621,7 @@ class SparseVFCEngine:
         self.st.zero_()
         k.estep_p(self.r, self.sigma2, self.gamma, a, self.Dy, minP, theta, fill, self.P, self.st)
         # ---- M-step assembly (MFMA Gram + rhs), energy regulariser with the OLD coefficients, the collectives
-        if self.world == 1:
+        if not self.multi:
             k.gram(self.x4, self.P, self.y4[0], self.ctrl4, self.beta, self.G, self.R[0])
         else:
             # G first: THE all-reduce of the step (packed upper triangle, 36 MB at M = 3000) starts the moment this rank's
@@ -579,7 +634,7 @@ class SparseVFCEngine:
             k.gram(self.x4, self.P, self.y4[g], self.ctrl4, self.beta, self.G, self.R[g], rhs_only=True)
         for g in range(self.ng):
             k.quadform(self.K, self.C[g], self.quad[g : g + 1])
-        if self.world > 1:
+        if self.multi:
             self._all_reduce(self.red[self.tri.numel():])
             self._wait(big)
             k.sym_unpack(self.tri, self.G)
@@ -607,8 +662,9 @@ class SparseVFCEngine:
         self.iteration += 1
         if self.gram_mode == "pivot" and self._lr_ran and (self.subset is None or self.pivot_nested):
             self._lr_iterations += 1
-            if self._lr_iterations >= self.pivot_after:
-                self._restrict_to_pivots()
+            # the switch itself happens at the START of the next iteration, if there is one: a fit that ends here (MaxIter,
+            # tecr <= ecr, sigma^2 <= 1e-8) returns the coefficients this iteration solved for, V = U C intact
+            self._restrict_pending = self._lr_iterations >= self.pivot_after
         return self.E, self.tecr
 
     def _rhs_batches(self):
@@ -658,7 +714,7 @@ class SparseVFCEngine:
         step (`_finish_step`): the signature of this rank's solver decisions, or its failure, travels in the step's last
         collective; here a failure is only recorded (returns None) so that this rank still takes part in it."""
         self._step_error, self._solver_signature, self._lr_ran, self._spr_spec = None, (0.0,) * 6, False, None
-        if self.world == 1:
+        if not self.multi:
             return self._solve_all_local(ls2)
         try:
             return self._solve_all_local(ls2)
@@ -672,7 +728,7 @@ class SparseVFCEngine:
         (sig, sig^2): all ranks hold the same signature iff  world * sum(sig^2) == sum(sig)^2  for every entry (the
         entries are small integers or halves: the sums are exact).  A failure on any rank, or a disagreement, raises on
         EVERY rank in this very step instead of leaving the others hanging in the next collective."""
-        if self.world == 1:
+        if not self.multi:
             return float(self.spr.cpu()[0])
         sig = [float(x) for x in self._solver_signature]
         err = self._step_error
@@ -736,7 +792,7 @@ class SparseVFCEngine:
             # in the same device -> host copy as the certificate - one host round trip per EM iteration instead of two in the
             # regime of Spateo's stock call (M = 100: full rank certified in every iteration).  If the certificate fails the
             # truncated solve below recomputes C_new and em_step applies it again.
-            spec = self.world == 1
+            spec = not self.multi
             if spec:
                 self.fin.zero_()
                 self._apply_all(self.ctrl4, self.C_new)
@@ -827,7 +883,7 @@ class SparseVFCEngine:
 
     def _gather_rows(self, t, root_only):
         """Concatenate the per-rank row blocks: on every rank, or (root_only) on rank 0 - the others keep their own."""
-        if self.world == 1:
+        if self.world == 1 and not (self.force_collectives and self.distributed):
             return t
         import torch.distributed as dist
 
@@ -895,7 +951,9 @@ def con_K(x, y, beta: float = 0.1, method: str = "cdist", return_d: bool = False
 _EVAL_ALL = (_lib.EVAL_V | _lib.EVAL_JAC | _lib.EVAL_DIV | _lib.EVAL_CURL | _lib.EVAL_ACC | _lib.EVAL_CURV |
              _lib.EVAL_TORS | _lib.EVAL_JDET)
 _EVAL_BYTES_PER_POINT = 8 * (3 + 9 + 1 + 3 + 3 + 3 + 3 + 1)
-_EVAL_PREFETCH_CAP = 2 << 30   # every quantity is kept on the device for the next call while it fits in this many bytes
+# every quantity is computed by the first call and kept on the device for the next ones while ALL of them fit in this many
+# bytes (256 MB = 1.2 M query points; a 64^3 grid takes 55 MB); beyond that only what a call asks for is computed and kept
+_EVAL_PREFETCH_CAP = 256 << 20
 
 
 class _FusedEval:
@@ -923,7 +981,10 @@ class _FusedEval:
 
 
 def clear_eval_cache():
-    """Drop the evaluator results kept on the device by the last ``SvcVectorField`` / ``GPVectorField`` call."""
+    """Drop the evaluator results kept on the device by the last ``SvcVectorField`` / ``GPVectorField`` /
+    ``vector_field_function`` call of this thread (one entry: the quantities of the last (points, field) pair, at most
+    ``_EVAL_PREFETCH_CAP`` bytes when prefetched).  A new fit (``SparseVFCEngine``) drops it by itself before it sizes its
+    kernel-value cache against the free HBM."""
     _TLS.__dict__.pop("fused", None)
 
 
@@ -1011,7 +1072,8 @@ def SparseVFC(
     sharded_input=False,
     gather="root",
     gram_mode="full",
-    _kernels=None,
+    force_collectives=False,
+    collective="torch",
 ) -> dict:
     """Drop-in for ``dynamo.vectorfield.scVectorField.SparseVFC`` (defaults identical).
 
@@ -1028,7 +1090,11 @@ def SparseVFC(
     the reference's M-step on all M control points) | "pivot" (extension: after the first rank-revealing solve the fit
     three rank-revealing iterations ("pivot:K": after K) the fit continues on the r control points the pivoted factorisation
     selected, ``C`` zero elsewhere; N r^2 instead of N M^2 work per iteration; field at 0.9 - 1.5 x the reference's noise
-    floor, see ``SparseVFCEngine._restrict_to_pivots``).  The coefficients ``C`` are
+    floor, see ``SparseVFCEngine._restrict_to_pivots``).  ``collective``: "torch" (torch.distributed: RCCL under the
+    "nccl" backend) | "mvf" (``mvf_allreduce_stats`` of the C ABI on the engine's own RCCL communicator).
+    ``force_collectives=True`` with ``distributed=True`` runs the whole multi-rank protocol (rank-0 preprocessing +
+    broadcast, the step's collectives, the output gather) on a process group of ONE rank as well - same result bit for
+    bit, every collective executed on the real backend.  The coefficients ``C`` are
     NOT a parity quantity (the reference's own solver only fixes them up to the numerical null space of the Gram
     system) - the field ``V`` / ``grid_V``, ``sigma2`` and ``P`` are.
     Returns the reference's dict with host NumPy float64 arrays.
@@ -1044,7 +1110,8 @@ def SparseVFC(
     X_ori, Y_ori = X.copy(), Y.copy()
     rank, world = _dist_info(distributed, group)
     shard_sizes = None
-    if world == 1:
+    multi = world > 1 or (bool(force_collectives) and bool(distributed))
+    if not multi:
         valid_ind, Xv, Yv, idx, ctrl_pts, beta = sparsevfc_preprocess(
             X, Y, M=M, beta=beta, velocity_based_sampling=velocity_based_sampling, seed=seed, device=device
         )
@@ -1103,7 +1170,8 @@ def SparseVFC(
         # and the energy term C.T.dot(K).dot(C) then fails with a ValueError
         raise ValueError("SparseVFC needs at least 2 control points (shapes (3,) and (1,3) not aligned in the reference)")
     eng = SparseVFCEngine(Xv[lo:hi], Yv[lo:hi], ctrl_pts, beta, dtype=dtype, device=device, distributed=distributed,
-                          group=group, n_total=N, kernels=_kernels, shard_sizes=shard_sizes, gram_mode=gram_mode)
+                          group=group, n_total=N, shard_sizes=shard_sizes, gram_mode=gram_mode,
+                          force_collectives=force_collectives, collective=collective)
     tecr_vec, E_vec = eng.fit(a=a, gamma=gamma, lambda_=lambda_, minP=minP, MaxIter=MaxIter, theta=theta, ecr=ecr,
                               lstsq_method=lstsq_method)
     V, P, C = eng.results(gather=gather)
@@ -1112,7 +1180,7 @@ def SparseVFC(
     extra = {}
     if eng.subset is not None:
         extra["ctrl_subset"] = eng.subset  # pivot mode: rows of X_ctrl / C that carry the field (C is zero elsewhere)
-    if world > 1:
+    if multi:
         # which rows of the finite-row sequence (positions in `valid_ind`) the per-cell outputs V / P / VFCIndex of THIS
         # rank cover: all of them on rank 0 and with gather="all", this rank's block otherwise (VFCIndex is relative to it)
         first = sum(eng.shard_sizes[:rank])

@@ -69,13 +69,13 @@ def _worker(rank, world, port, case, out_dir, mode="all"):
         if case == "minnorm_lr":
             import spateo_amd.vectorfield as _v
 
-            _v.MINNORM_METHOD = "lowrank"  # the rank-revealing solve regardless of M
+            _v.SparseVFCEngine.minnorm_method = "lowrank"  # the rank-revealing solve regardless of M
         Grid = X[::30]
         kw = dict(M=25, lambda_=3.0, lstsq_method="scipy", MaxIter=6, seed=0)
         if case == "pivot":
             import spateo_amd.vectorfield as _v
 
-            _v.MINNORM_METHOD = "lowrank"
+            _v.SparseVFCEngine.minnorm_method = "lowrank"
             kw = _pivot_kw(_v, X, V)
         if case == "wide":
             V = np.column_stack([V, np.sin(X[:, 0] / 70), np.cos(X[:, 1] / 50)])  # Dy = 5: two column groups
@@ -89,13 +89,13 @@ def _worker(rank, world, port, case, out_dir, mode="all"):
             return orig_unique(a, device)
 
         vfm.unique_rows = counting_unique
+        vfm._make_kernels = lambda device, dtype: Recording()  # the product's one kernel-binding seam
         if mode == "sharded":  # every rank brings ITS OWN rows: 401 + 200, not the block split
             lo, hi = (0, 401) if rank == 0 else (401, 601)
-            got = st.SparseVFC(X[lo:hi], V[lo:hi], Grid, distributed=True, sharded_input=True, gather="root",
-                               _kernels=Recording(), **kw)
+            got = st.SparseVFC(X[lo:hi], V[lo:hi], Grid, distributed=True, sharded_input=True, gather="root", **kw)
         elif case in ("disagree", "crash"):
             try:
-                st.SparseVFC(X, V, Grid, distributed=True, gather=mode, _kernels=Recording(), **kw)
+                st.SparseVFC(X, V, Grid, distributed=True, gather=mode, **kw)
                 msg = "no error"
             except Exception as exc:  # noqa: BLE001
                 msg = f"{type(exc).__name__}: {exc}"
@@ -103,7 +103,7 @@ def _worker(rank, world, port, case, out_dir, mode="all"):
                 f.write(msg)
             return
         else:
-            got = st.SparseVFC(X, V, Grid, distributed=True, gather=mode, _kernels=Recording(), **kw)
+            got = st.SparseVFC(X, V, Grid, distributed=True, gather=mode, **kw)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), V=got["V"], P=got["P"], C=got["C"], grid_V=got["grid_V"],
                  sigma2=got["sigma2"], iteration=got["iteration"], E=got["E_traj"], fills=np.array(Recording.fills),
                  unique_calls=calls["unique"], valid_ind=got["valid_ind"], vfc=got["VFCIndex"],
@@ -161,12 +161,13 @@ def test_two_rank_gloo_pivot_mode_matches_single_process(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, "pivot", str(tmp_path)), nprocs=2, join=True)
     X, V, _ = make_config("C2", N=601)
-    old = vfm.MINNORM_METHOD
-    vfm.MINNORM_METHOD = "lowrank"
+    old, old_mk = vfm.SparseVFCEngine.minnorm_method, vfm._make_kernels
+    vfm.SparseVFCEngine.minnorm_method = "lowrank"
+    vfm._make_kernels = lambda device, dtype: CpuKernels()
     try:
-        ref = st.SparseVFC(X, V, X[::30], _kernels=CpuKernels(), **_pivot_kw(vfm, X, V))
+        ref = st.SparseVFC(X, V, X[::30], **_pivot_kw(vfm, X, V))
     finally:
-        vfm.MINNORM_METHOD = old
+        vfm.SparseVFCEngine.minnorm_method, vfm._make_kernels = old, old_mk
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     assert 2 <= len(ref["ctrl_subset"]) <= 90 and 2 <= len(r0["subset"]) <= 90
     # the two ranks hold the same all-reduced system bit for bit, so they select the SAME control points and end identical
@@ -240,4 +241,69 @@ def test_distributed_flag_requires_process_group():
 
     X = np.random.default_rng(0).standard_normal((40, 3))
     with pytest.raises(RuntimeError, match="torch.distributed is not initialised"):
-        st.SparseVFC(X, X, None, M=5, distributed=True, _kernels=CpuKernels())
+        st.SparseVFC(X, X, None, M=5, distributed=True)
+
+
+def _force_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "spateo-release_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import spateo_amd as st
+        import spateo_amd.vectorfield as vfm
+        from _cpu_kernels import CpuKernels
+        from spateo_amd._synthetic import make_config
+
+        count = {"n": 0}
+        orig = dist.all_reduce
+
+        def counting(*a, **kw):
+            count["n"] += 1
+            return orig(*a, **kw)
+
+        dist.all_reduce = counting
+        vfm._make_kernels = lambda device, dtype: CpuKernels()
+        X, V, _ = make_config("C2", N=601)
+        V[7] = np.nan
+        kw = dict(M=25, lambda_=3.0, lstsq_method="scipy", MaxIter=6, seed=0)
+        plain = st.SparseVFC(X, V, X[::30], **kw)
+        n_plain = count["n"]
+        forced = st.SparseVFC(X, V, X[::30], distributed=True, force_collectives=True, gather="all", **kw)
+        np.savez(os.path.join(out_dir, "force.npz"), n_plain=n_plain, n_forced=count["n"] - n_plain,
+                 iters=forced["iteration"] + 1, row_range=np.array(forced["row_range"]),
+                 **{f"p_{k}": plain[k] for k in ("V", "P", "C", "grid_V", "sigma2", "E_traj", "VFCIndex")},
+                 **{f"f_{k}": forced[k] for k in ("V", "P", "C", "grid_V", "sigma2", "E_traj", "VFCIndex")})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_force_collectives_runs_the_multi_rank_protocol_on_one_rank(tmp_path):
+    """`force_collectives=True` on a process group of ONE rank: the rank-0 preprocessing + object broadcast, the four
+    all-reduces of every EM step and the output gather all execute on the backend (gloo here; RCCL in
+    tests/test_gpu_rccl.py), and - a single rank's sum being the identity - the result is that of the plain fit."""
+    port = _free_port()
+    mp.spawn(_force_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    z = np.load(tmp_path / "force.npz")
+    assert int(z["n_plain"]) == 0                       # the plain single-process fit issues no collective at all
+    assert int(z["n_forced"]) == 1 + 4 * int(z["iters"])  # init_state's sum P r + four per EM step
+    # (the CPU test double's BLAS Gram is symmetric only to rounding and the packed triangle mirrors one half: 1e-13 apart;
+    # the HIP Gram kernel's G is exactly symmetric and the RCCL run of this protocol IS bit-equal, tests/test_gpu_rccl.py)
+    np.testing.assert_array_equal(z["p_VFCIndex"], z["f_VFCIndex"])
+    for k in ("V", "P", "C", "grid_V", "sigma2", "E_traj"):
+        np.testing.assert_allclose(z[f"p_{k}"], z[f"f_{k}"], rtol=1e-9, atol=1e-11)
+    assert tuple(z["row_range"]) == (0, 600)
+
+
+def test_force_collectives_needs_a_process_group_for_the_torch_collective():
+    sys.path.insert(0, HERE)
+    import spateo_amd.vectorfield as vfm
+    from _cpu_kernels import CpuKernels
+
+    X = np.random.default_rng(0).standard_normal((40, 3))
+    with pytest.raises(ValueError, match="force_collectives"):
+        vfm.SparseVFCEngine(X, X, X[:5], 0.1, kernels=CpuKernels(), force_collectives=True)
+    with pytest.raises(ValueError, match="collective"):
+        vfm.SparseVFCEngine(X, X, X[:5], 0.1, kernels=CpuKernels(), collective="mpi")

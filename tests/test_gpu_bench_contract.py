@@ -42,3 +42,13 @@ def test_bench_line_contract():
     assert ev["float64"]["jacobian_plus_curl_api_wall_ms"] < 100.0
     pv = d["pivot_subset"]
     assert pv["value"] > 0 and pv["ctrl_used"] <= 1100 and "NOT" in pv["note"].upper()
+    # the step's collectives executed on a one-rank RCCL communicator through both back ends
+    rc = d["rccl_world1"]
+    for coll in ("torch", "mvf"):
+        assert "failed" not in rc[coll], rc[coll]
+        cm = rc[coll]["comm"]
+        assert cm["collectives_per_step"] == 4.0 and cm["ranks"] == 1 and cm["forced_on_one_rank"] is True
+        assert cm["allreduce_bytes"] == 1100 * 1101 // 2 * 8 and rc[coll]["ms_per_step"] > 0
+        pr = rc[coll]["per_rank"][0]
+        assert pr["allreduce_ms"] > 0 and pr["rhs_stats_allreduce_ms"] > 0 and pr["scalar_allreduce_ms"] > 0
+    assert "nccl" in rc["torch"]["comm"]["backend"] and "mvf_allreduce_stats" in rc["mvf"]["comm"]["backend"]

@@ -64,7 +64,7 @@ def test_em_driver_reproduces_oracle_sparsevfc(cpu_kernels):
     Grid = X[::25] + 0.5
     kw = dict(M=40, lambda_=3.0, lstsq_method="scipy", MaxIter=40, seed=0)
     ref = svo.SparseVFC(X, V, Grid, **kw)
-    got = st.SparseVFC(X, V, Grid, _kernels=cpu_kernels, **kw)
+    got = st.SparseVFC(X, V, Grid, **kw)
     assert set(got) == set(ref)
     assert got["iteration"] == ref["iteration"] and len(got["E_traj"]) == got["iteration"] + 1
     np.testing.assert_array_equal(got["ctrl_idx"], ref["ctrl_idx"])
@@ -87,7 +87,7 @@ def test_em_driver_wide_and_narrow_outputs(cpu_kernels, dy):
     Y += 0.02 * rng.standard_normal(Y.shape)
     kw = dict(M=30, lambda_=3.0, lstsq_method="scipy", MaxIter=12, seed=0)
     ref = svo.SparseVFC(X, Y, X[::20], **kw)
-    got = st.SparseVFC(X, Y, X[::20], _kernels=cpu_kernels, **kw)
+    got = st.SparseVFC(X, Y, X[::20], **kw)
     assert got["V"].shape == (500, dy) and got["C"].shape == (30, dy) and got["grid_V"].shape == (25, dy)
     assert got["iteration"] == ref["iteration"]
     assert _rel(got["V"], ref["V"]) < 1e-8 and _rel(got["grid_V"], ref["grid_V"]) < 1e-8
@@ -100,7 +100,7 @@ def test_em_driver_stops_like_the_reference(cpu_kernels):
     for kw in (dict(MaxIter=3), dict(MaxIter=50, ecr=1e-2), dict(MaxIter=1)):
         full = dict(M=20, lambda_=3.0, lstsq_method="scipy", seed=0, **kw)
         ref = svo.SparseVFC(X, V, None, **full)
-        got = st.SparseVFC(X, V, None, _kernels=cpu_kernels, **full)
+        got = st.SparseVFC(X, V, None, **full)
         assert got["iteration"] == ref["iteration"], kw
         assert got["grid_V"] is None and got["grid"] is None
 
@@ -264,7 +264,7 @@ def test_cholesky_mode_jitter_escalates_only_on_failed_pivots(cpu_kernels):
 
 def test_lstsq_method_is_honoured_or_warned(cpu_kernels):
     X, V = _data(300)
-    kw = dict(M=20, MaxIter=3, lambda_=3.0, _kernels=cpu_kernels)
+    kw = dict(M=20, MaxIter=3, lambda_=3.0)
     a = vfm.SparseVFC(X, V, None, lstsq_method="scipy", **kw)
     vfm._LSTSQ_WARNED.clear()
     with pytest.warns(RuntimeWarning, match="normal-equations arithmetic of 'drouin' is not reproduced"):
@@ -299,7 +299,7 @@ def test_restart_loop_matches_reference_wrapper(golden, cpu_kernels):
     g = golden
     res = st.tdr._morphofield_sparsevfc(
         g["w_X"][:300], g["w_V"][:300], NX=None, grid_num=[5, 4, 3], M=30, lambda_=0.02, lstsq_method="scipy",
-        min_vel_corr=0.5, restart_num=3, restart_seed=[0, 100, 200], MaxIter=30, _kernels=cpu_kernels)
+        min_vel_corr=0.5, restart_num=3, restart_seed=[0, 100, 200], MaxIter=30)
     assert res["method"] == "sparsevfc"
     for k in ["valid_ind", "X_ctrl", "ctrl_idx", "grid", "VFCIndex"]:
         np.testing.assert_array_equal(res[k], g[f"w1_{k}"])
@@ -309,12 +309,12 @@ def test_restart_loop_matches_reference_wrapper(golden, cpu_kernels):
     # forced restarts + default seed-length quirk (5 seeds for restart_num=2 -> seeds become arange(2)*100)
     Xf, Vf = g["w_X"][300:], g["w_V"][300:]
     res2 = st.tdr._morphofield_sparsevfc(Xf, Vf, NX=Xf[:10], M=12, min_vel_corr=2.0, restart_num=2,
-                                         restart_seed=(0, 100, 200, 300, 400), MaxIter=8, _kernels=cpu_kernels)
+                                         restart_seed=(0, 100, 200, 300, 400), MaxIter=8)
     np.testing.assert_array_equal(res2["X_ctrl"], g["w2_X_ctrl"])
     assert res2["iteration"] == int(g["w2_iteration"])
     assert _rel(res2["V"], g["w2_V"]) < 1e-8 and _rel(res2["grid_V"], g["w2_grid_V"]) < 1e-8
     # restart_num = 0 -> a single fit, no acceptance test
-    res3 = st.tdr._morphofield_sparsevfc(Xf, Vf, NX=Xf[:10], M=12, restart_num=0, MaxIter=8, _kernels=cpu_kernels)
+    res3 = st.tdr._morphofield_sparsevfc(Xf, Vf, NX=Xf[:10], M=12, restart_num=0, MaxIter=8)
     assert _rel(res3["V"], g["w2_V"]) < 1e-8
 
 
@@ -324,8 +324,7 @@ def test_non_finite_row_reproduces_reference_indexerror(cpu_kernels):
     X, V = _data(120)
     V[7, 1] = np.nan
     with pytest.raises(IndexError):
-        st.tdr._morphofield_sparsevfc(X, V, NX=X[:5], M=10, MaxIter=3, restart_num=1, restart_seed=[0],
-                                      _kernels=cpu_kernels)
+        st.tdr._morphofield_sparsevfc(X, V, NX=X[:5], M=10, MaxIter=3, restart_num=1, restart_seed=[0])
 
 
 def test_anndata_wrappers_match_reference_wrappers(golden, cpu_kernels):
@@ -515,7 +514,7 @@ def test_degenerate_inputs_behave_like_the_reference(cpu_kernels):
     kw = dict(lambda_=3.0, lstsq_method="scipy", MaxIter=3)
     for Xi, Yi, M in ((X, Y, 3), (X[:2], Y[:2], 5)):  # fewer cells than a tile; M clipped to the 2 unique rows
         ref = svo.SparseVFC(Xi, Yi, None, M=M, **kw)
-        got = st.SparseVFC(Xi, Yi, None, M=M, _kernels=cpu_kernels, **kw)
+        got = st.SparseVFC(Xi, Yi, None, M=M, **kw)
         assert got["X_ctrl"].shape == ref["X_ctrl"].shape and got["iteration"] == ref["iteration"]
         np.testing.assert_allclose(got["V"], ref["V"], rtol=1e-7, atol=1e-12)
     cases = [
@@ -529,13 +528,13 @@ def test_degenerate_inputs_behave_like_the_reference(cpu_kernels):
         with pytest.raises(ValueError):
             svo.SparseVFC(Xi, Yi, None, M=M, **kw)
         with pytest.raises(ValueError):
-            st.SparseVFC(Xi, Yi, None, M=M, _kernels=cpu_kernels, **kw)
+            st.SparseVFC(Xi, Yi, None, M=M, **kw)
     # an explicit beta bypasses the bandwidth rule, but a single control point still fails in the reference (its
     # 1 x 1 K is flattened to 1-D and the energy term cannot be formed): ValueError in both
     with pytest.raises(ValueError):
         svo.SparseVFC(X, Y, None, M=1, beta=0.3, **kw)
     with pytest.raises(ValueError):
-        st.SparseVFC(X, Y, None, M=1, beta=0.3, _kernels=cpu_kernels, **kw)
+        st.SparseVFC(X, Y, None, M=1, beta=0.3, **kw)
 
 
 def test_unique_rows_matches_numpy_unique():
@@ -768,11 +767,11 @@ def test_pivot_mode_continues_on_the_selected_control_points(cpu_kernels, monkey
     points the pivoted factorisation selected - M-step matrices r x r, coefficients zero off the subset so that
     ``V == con_K(X, X_ctrl) @ C`` holds for the returned full-size C, energy continuous across the switch, same dict
     contract; the default mode is untouched; a factor that keeps more than 75 % of the control points does not switch."""
-    monkeypatch.setattr(vfm, "MINNORM_METHOD", "lowrank")
+    monkeypatch.setattr(vfm.SparseVFCEngine, "minnorm_method", "lowrank")
     X, V = _data(1500)
     # a kernel 20 x wider than the bandwidth rule's makes 120 control points numerically rank deficient at this small size
     beta = 0.05 * vfm.sparsevfc_preprocess(X, V, M=120, seed=0)[5]
-    kw = dict(M=120, lambda_=0.02, lstsq_method="scipy", MaxIter=8, ecr=0.0, seed=0, beta=beta, _kernels=cpu_kernels)
+    kw = dict(M=120, lambda_=0.02, lstsq_method="scipy", MaxIter=8, ecr=0.0, seed=0, beta=beta)
     full = st.SparseVFC(X, V, X[:40], **kw)
     piv = st.SparseVFC(X, V, X[:40], gram_mode="pivot", **kw)
     assert "ctrl_subset" not in full and "ctrl_subset" in piv
@@ -848,3 +847,80 @@ def test_deflated_route_to_the_truncated_solve_restated_in_numpy():
     assert np.abs(U @ C_defl - F).max() / sc < 4e-2      # and with it inside the reference's floor on this system
     np.testing.assert_array_equal(solve(128, True)[1], C_defl)   # the twin's deflate=True IS this route ...
     np.testing.assert_array_equal(solve(32, True)[1], C_svd)     # ... and falls back when the block cannot hold the subspace
+
+
+def test_pivot_mode_fit_ending_on_the_switching_iteration_keeps_its_coefficients(cpu_kernels, monkeypatch):
+    """the restriction to the pivot subset used to happen at the END of the switching iteration and
+    zeroed C; a fit that ended right there (MaxIter, tecr <= ecr, sigma^2 floor) returned C = 0 with a non-zero V.  The
+    switch is now taken at the start of the NEXT iteration, if there is one."""
+    monkeypatch.setattr(vfm.SparseVFCEngine, "minnorm_method", "lowrank")
+    X, V = _data(1500)
+    beta = 0.05 * vfm.sparsevfc_preprocess(X, V, M=120, seed=0)[5]
+    kw = dict(M=120, lambda_=0.02, lstsq_method="scipy", ecr=0.0, seed=0, beta=beta)
+    Xv = X
+    for max_iter in (2, 3, 4, 5):
+        piv = st.SparseVFC(X, V, X[:40], gram_mode="pivot", MaxIter=max_iter, **kw)
+        assert np.abs(piv["C"]).max() > 0 and np.abs(piv["V"]).max() > 0
+        U = svo.con_K(Xv, piv["X_ctrl"], piv["beta"])
+        np.testing.assert_allclose(U @ piv["C"], piv["V"], rtol=0, atol=1e-9 * np.abs(piv["V"]).max())
+        np.testing.assert_allclose(svo.con_K(X[:40], piv["X_ctrl"], piv["beta"]) @ piv["C"], piv["grid_V"], rtol=0,
+                                   atol=1e-9 * np.abs(piv["V"]).max())
+    # a fit that ends on the switching iteration has not switched (it equals the full-mode fit up to that point) ...
+    full = st.SparseVFC(X, V, X[:40], MaxIter=4, **kw)
+    runs = {mi: st.SparseVFC(X, V, X[:40], gram_mode="pivot", MaxIter=mi, **kw) for mi in (2, 3, 4, 5, 6)}
+    first_switched = min(mi for mi, r in runs.items() if "ctrl_subset" in r)
+    last_unswitched = first_switched - 1
+    assert last_unswitched in runs and "ctrl_subset" not in runs[last_unswitched]
+    if last_unswitched == 4:
+        np.testing.assert_array_equal(runs[4]["V"], full["V"])
+    # ... and the next one has
+    assert np.all(runs[first_switched]["C"][np.setdiff1d(np.arange(120), runs[first_switched]["ctrl_subset"])] == 0.0)
+
+
+def test_engine_refit_after_pivot_mode_starts_from_the_full_control_point_set(cpu_kernels, monkeypatch):
+    """init_state() undoes the pivot-mode restriction, so a second fit() on the same engine (bench warm-up /
+    timed steps) is the same computation as the first."""
+    monkeypatch.setattr(vfm.SparseVFCEngine, "minnorm_method", "lowrank")
+    X, V = _data(1500)
+    _, Xv, Yv, _, ctrl, beta = vfm.sparsevfc_preprocess(X, V, M=120, seed=0)
+    eng = vfm.SparseVFCEngine(Xv, Yv, ctrl, 0.05 * beta, gram_mode="pivot")
+    kw = dict(lambda_=0.02, MaxIter=8, ecr=0.0, lstsq_method="scipy")
+    eng.fit(**kw)
+    assert eng.subset is not None and eng.M < 120
+    V1, P1, C1 = eng.results()
+    sub1 = eng.subset.copy()
+    eng.fit(**kw)
+    assert eng.M < 120
+    V2, P2, C2 = eng.results()
+    np.testing.assert_array_equal(sub1, eng.subset)
+    np.testing.assert_array_equal(V1, V2)
+    np.testing.assert_array_equal(C1, C2)
+    eng.init_state()
+    assert eng.subset is None and eng.M == 120 and eng.G.shape == (120, 120)
+
+
+def test_restart_loop_refits_per_seed_unless_the_memo_is_opted_into(cpu_kernels, monkeypatch):
+    """the default follows the reference's control flow (one fit per restart, sparsevfc.py:178-232);
+    reusing the first fit for every restart (valid only if dynamo's sample_by_velocity ignores `seed`, a [VERIFY] item) is
+    the opt-in `reuse_identical_restarts=True`."""
+    import spateo_amd.tdr.morphometrics.morphofield.sparsevfc as wrap
+
+    calls = []
+    orig = wrap.SparseVFC
+
+    def counting(*a, **kw):
+        calls.append(kw.get("seed"))
+        return orig(*a, **kw)
+
+    monkeypatch.setattr(wrap, "SparseVFC", counting)
+    X, V = _data(300)
+    kw = dict(NX=X[:10], M=12, min_vel_corr=2.0, restart_num=3, restart_seed=[0, 100, 200], MaxIter=4)
+    res = st.tdr._morphofield_sparsevfc(X, V, **kw)
+    assert calls == [0, 100, 200]
+    calls.clear()
+    res2 = st.tdr._morphofield_sparsevfc(X, V, reuse_identical_restarts=True, **kw)
+    assert calls == [0]
+    np.testing.assert_array_equal(res["V"], res2["V"])
+    calls.clear()
+    st.tdr._morphofield_sparsevfc(X, V, reuse_identical_restarts=True, velocity_based_sampling=False, **kw)
+    assert calls == [0, 100, 200]  # seeded permutation sampling: the seed reaches the fit, nothing to reuse
