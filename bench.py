@@ -226,6 +226,13 @@ def main():
                     help="skip the extra N = 1 runs that execute the step's collectives on a one-rank RCCL communicator")
     args = ap.parse_args()
 
+    # ONE JSON line on stdout: RCCL prints a version banner on STDOUT when a communicator is created (seen on the first RCCL
+    # execution of this code, round 5) and other native libraries may do the same, so the process's fd 1 is pointed at stderr
+    # for the whole run and only the final line goes to the real stdout
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -661,12 +668,14 @@ def main():
             out["parity"]["pivot"] = {"f64": pv["f64"], "f32": pv["f32"]}
         del sample
 
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
     if dist.is_initialized():
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":
