@@ -58,8 +58,8 @@ int mvf_version(void);                 /* ABI version, currently 5 */
  * compare the variants bit for bit.  The library NEVER reads the environment (rounds 1 - 3 had getenv knobs in launch
  * paths); nothing but this call changes its behaviour.  value 0 = default.  Names: "conk_form" (1 rows, 2 flat, 3 2d),
  * "conk_rows" (rows per workgroup of the rows form), "slice_len" (cells per Gram slice), "solve_small_off" (1: the blocked
- * multi-launch Cholesky at every m), "jac_gram_wgs" (workgroups per Jacobi Gram launch), "lr_no_deflate" (1: mvf_solve_minnorm_lrd always takes the Jacobi path), "lr_timing" (1: phase times of
- * mvf_solve_minnorm_lr on stderr).  Unknown name: non-zero return.  mvf_debug_option_get returns -1 for an unknown name. */
+ * multi-launch Cholesky at every m), "jac_gram_wgs" (workgroups per Jacobi Gram launch), "lr_no_deflate" (1: mvf_solve_minnorm_lrd always takes the Jacobi path), "defl_block" (64 / 128 / 256: mvf_solve_minnorm_lrd tries that block size alone), "defl_apps" (1 .. 8: applications of S2^-1 in its block
+ * inverse iteration), "lr_timing" (1: phase times of mvf_solve_minnorm_lr on stderr).  Unknown name: non-zero return.  mvf_debug_option_get returns -1 for an unknown name. */
 int mvf_debug_option(const char* name, long long value);
 long long mvf_debug_option_get(const char* name);
 int mvf_device_count(int* count);      /* number of visible HIP devices (0 without a GPU) */
@@ -235,14 +235,15 @@ int mvf_solve_minnorm_lr(const double* G, const double* K, double lambda_sigma2,
  * eigendecomposition of the whole factor: after the pivoted Cholesky has dropped everything below tolf * eps * lambda_max,
  * the eigenvalues gelsd truncates are the few smallest ones of S2 = L^T L (r x r) and lie within 1 / tolf of the cut.
  * S2 = Rc Rc^T (Cholesky; the inverse factor rides along as extra rows), block inverse iteration on 256 vectors started on
- * the smallest pivots (two applications of S2^-1, Cholesky-QR in between), Rayleigh-Ritz on the 256 x 256 projection (the
+ * the smallest pivots (three applications of S2^-1, Cholesky-QR in between), Rayleigh-Ritz on the 256 x 256 projection (the
  * Jacobi kernels; einfo[0] = ITS sweeps), W = Ritz vectors with theta <= rcond * lambda_max, Pc = I - W^T W, and
  *     C = L Pc S2^-1 Pc S2^-1 Pc L^T R
  * (the projections between the inverse applications keep the amplified rounding error of the dropped directions out).
  * lambda_max (einfo[2]) is the Rayleigh quotient of 12 power-iteration steps (relative error ~1e-8), einfo[3] the smallest
- * Ritz value above the cut inside the block, einfo[7] the block size used (256; 128 with three applications when the
+ * Ritz value above the cut inside the block, einfo[7] the block size used (256; 128 when the
  * previous call on this workspace - rank_hint > 0 - deflated at most 72 directions, repeated with 256 if it then finds more
- * than 80; 0 when the Jacobi path answered).  When the factor has fewer than 512 columns, when more than 224 Ritz values
+ * than 80; 64 for factors of 128 .. 511 columns, accepted while at most 40 Ritz values lie below the cut; 0 when the Jacobi
+ * path answered).  When the factor has fewer than 128 columns, when more than 224 (block 256) Ritz values
  * fall below the cut, or a factorisation meets a non-positive pivot, the call continues on mvf_solve_minnorm_lr's Jacobi
  * path and returns its result.  Measured at m = 3000 in the EM's steady state (r = 869): 6.7 ms against 22.9 ms, the field
  * within 1e-6 of the Jacobi path's on the same factor.  The workspace is larger (the r x r scratch); mvf_pinv_diag does not

@@ -76,6 +76,41 @@ def _to_host(k, tensors):
 
 _LSTSQ_WARNED = set()
 
+# Whole-call profile (bench.py's `whole_fit`, tools/): with PROFILE_FITS = True every SparseVFC call synchronises the device
+# at its phase boundaries and leaves {phase: seconds} in this thread's `last_fit_profile()`.  Off (the default) nothing is
+# synchronised or recorded.
+PROFILE_FITS = False
+
+
+def last_fit_profile():
+    """{phase: seconds} of this thread's last SparseVFC call made while ``PROFILE_FITS`` was True (else None)."""
+    return _TLS.__dict__.get("fit_profile")
+
+
+class _Phases:
+    def __init__(self, device):
+        self.on = bool(PROFILE_FITS)
+        self.device, self.t, self.out = device, None, {}
+        if self.on:
+            import time
+
+            self.clock = time.perf_counter
+            self.t = self.clock()
+
+    def mark(self, name):
+        if not self.on:
+            return
+        if torch.cuda.is_available():
+            torch.cuda.synchronize(self.device)
+        now = self.clock()
+        self.out[name] = self.out.get(name, 0.0) + now - self.t
+        self.t = now
+
+    def done(self):
+        if self.on:
+            self.out["total_s"] = sum(self.out.values())
+            _TLS.fit_profile = self.out
+
 
 def _check_lstsq_method(method):
     """"scipy": the reference's call (Spateo always passes it, sparsevfc.py:110,194,250) - minimum-norm solve with
@@ -1107,6 +1142,7 @@ def SparseVFC(
         raise ValueError("X and Y must be 2-D arrays with the same number of rows")
     if gather not in ("root", "all"):
         raise ValueError("gather must be 'root' or 'all'")
+    ph = _Phases(device)
     X_ori, Y_ori = X.copy(), Y.copy()
     rank, world = _dist_info(distributed, group)
     shard_sizes = None
@@ -1169,14 +1205,19 @@ def SparseVFC(
         # reference behaviour: con_K(ctrl, ctrl) of a single control point is flattened to 1-D (gaussian_process.py:23-24)
         # and the energy term C.T.dot(K).dot(C) then fails with a ValueError
         raise ValueError("SparseVFC needs at least 2 control points (shapes (3,) and (1,3) not aligned in the reference)")
+    ph.mark("preprocess_s")
     eng = SparseVFCEngine(Xv[lo:hi], Yv[lo:hi], ctrl_pts, beta, dtype=dtype, device=device, distributed=distributed,
                           group=group, n_total=N, shard_sizes=shard_sizes, gram_mode=gram_mode,
                           force_collectives=force_collectives, collective=collective)
+    ph.mark("upload_and_u_cache_s")
     tecr_vec, E_vec = eng.fit(a=a, gamma=gamma, lambda_=lambda_, minP=minP, MaxIter=MaxIter, theta=theta, ecr=ecr,
                               lstsq_method=lstsq_method)
+    ph.mark("em_s")
     V, P, C = eng.results(gather=gather)
     grid_V = eng.predict(Grid) if Grid is not None else None
     i = eng.iteration
+    if eng.comm is not None:
+        eng.comm.close()
     extra = {}
     if eng.subset is not None:
         extra["ctrl_subset"] = eng.subset  # pivot mode: rows of X_ctrl / C that carry the field (C is zero elsewhere)
@@ -1185,6 +1226,10 @@ def SparseVFC(
         # rank cover: all of them on rank 0 and with gather="all", this rank's block otherwise (VFCIndex is relative to it)
         first = sum(eng.shard_sizes[:rank])
         extra["row_range"] = (0, N) if (gather == "all" or rank == 0) else (first, first + eng.shard_sizes[rank])
+    vfc_index = np.where(P > theta)[0]
+    ph.mark("download_s")
+    ph.out["em_iterations"] = int(i)
+    ph.done()
     return {
         **extra,
         "X": X_ori,
@@ -1196,7 +1241,7 @@ def SparseVFC(
         "V": V,
         "C": C,
         "P": P,
-        "VFCIndex": np.where(P > theta)[0],
+        "VFCIndex": vfc_index,
         "sigma2": eng.sigma2,
         "grid": Grid,
         "grid_V": grid_V,

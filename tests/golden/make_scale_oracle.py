@@ -24,7 +24,7 @@ import test_gpu_scale as T  # noqa: E402
 
 def save():
     out = {f"{k}|{f}": v for k, d in T._ORACLE_STORE.items() for f, v in d.items()}
-    path = os.path.join(HERE, "scale_oracle.npz")
+    path = os.path.join(HERE, os.environ.get("MVF_SCALE_ORACLE_OUT", "scale_oracle.npz"))
     np.savez_compressed(path, **out)
     print("wrote", path, len(out), "arrays", os.path.getsize(path) / 1e6, "MB", flush=True)
 
