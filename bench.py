@@ -665,6 +665,46 @@ def main():
                                "first_call_api_wall_ms": walls[0]}
         clear_eval_cache()
 
+    # ---------------------------------------------------------------- BASELINE configs 2 and 5 (N = 1): ms per EM iteration
+    if rank == 0 and world == 1 and not args.no_whole_fit:
+        def small(cfg_name, n_small, m_small, seed_small):
+            Xs, Vs, _ = make_config(cfg_name, N=n_small, seed=seed_small)
+            _, Xsv, Ysv, _, ctrl_s, beta_s = sparsevfc_preprocess(Xs, Vs, M=m_small, seed=0)
+            eng = SparseVFCEngine(Xsv, Ysv, ctrl_s, beta_s, dtype=args.dtype, device=device)
+            eng.init_state(gamma=0.9)
+            evs, inner = [], eng._solve_all
+
+            def timed(ls2):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                h_ = inner(ls2)
+                e1.record()
+                evs.append((e0, e1))
+                return h_
+
+            eng._solve_all = timed
+            for _ in range(4):
+                eng.em_step(**step_kw)
+            evs.clear()
+            torch.cuda.synchronize()
+            t_s = time.perf_counter()
+            for _ in range(30):
+                eng.em_step(**step_kw)
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t_s) / 30
+            rec = {"cells": int(len(Xsv)), "ctrl": int(m_small), "dtype": args.dtype, "ms_per_em_step": ms,
+                   "cells_per_s": len(Xsv) / (ms * 1e-3), "solve_ms": float(np.mean([a.elapsed_time(b) for a, b in evs])),
+                   "solver": eng.mn_method if eng.rank_deficient else "cholesky",
+                   "kept_rank": (eng.solver_stats["rank"] or [m_small])[-1],
+                   "block": (eng.solver_stats.get("block") or [None])[-1]}
+            eng.k.drop_ublk()
+            return rec
+
+        out["small_configs"] = {"note": "BASELINE configs 2 and 5 at their stated sizes, one EM iteration (steady state, "
+                                        "30 timed after 4 warm-up), lambda_ as the headline",
+                                "c2_50k_x_500": small("C2", 50_000, 500, 2),
+                                "c5_organ_250k_x_500": small("C2", 250_000, 500, 100)}
+
     # ---------------------------------------------------------------- whole calls: host arrays in -> host dict out (N = 1)
     if rank == 0 and world == 1 and not args.no_whole_fit:
         import spateo_amd.vectorfield as vfm

@@ -202,15 +202,23 @@ __device__ __forceinline__ void inner_pair(int r, int l, int& p, int& q) {
 // Blocks partition S, so phase B is in place; two barriers per round.  Within a half-wave the 32 lanes touch 32 distinct
 // columns of one row: conflict-free without padding.
 constexpr int EIG_THREADS = 1024;
+// inner_sweeps > 1 (FULL only; used when the pair IS the whole matrix, the 64 x 64 Rayleigh-Ritz problem of the small
+// deflated solve): the sweep is repeated on the Gram tile in LDS until one applies no rotation (at most inner_sweeps times)
+// and J accumulates all of them - a complete two-sided Jacobi diagonalisation in ONE launch instead of eight rounds of
+// Gram / sweep / update / status read (well-conditioned tile: the one-sided re-orthogonalisation from the factor is not
+// needed for accuracy there).  rot_total then receives the rotation count of the LAST sweep (0 = converged).
 template <bool FULL>
 __global__ __launch_bounds__(EIG_THREADS) void jac_eig_kernel(const double* __restrict__ Spart, int nsplit, double tol,
                                                               int nb, int round, int stamp, int* __restrict__ mod,
                                                               int* __restrict__ clean, double* __restrict__ Jbuf,
                                                               int* __restrict__ flags,
-                                                              unsigned int* __restrict__ rot_total) {
+                                                              unsigned int* __restrict__ rot_total, int inner_sweeps = 1,
+                                                              const int* __restrict__ warm_flag = nullptr,
+                                                              double* __restrict__ Jkeep = nullptr) {
     __shared__ double S[JP][JP];
     __shared__ double Jm[JP][JP];
     __shared__ double cs[2][JB][2];
+    __shared__ int sweep_rot;
     const int pair = blockIdx.x, tid = threadIdx.x;
     int bp, bq;
     rr_pair(nb, round, pair, bp, bq);
@@ -247,6 +255,47 @@ __global__ __launch_bounds__(EIG_THREADS) void jac_eig_kernel(const double* __re
         }
     }
     __syncthreads();
+    // Warm start (inner-sweep form only; warm_flag[0] != 0): Jkeep holds the total rotation of the previous call's tile - the
+    // 64 x 64 Rayleigh-Ritz problem of the previous EM iteration, a nearby matrix in the same basis - so S <- Jk^T S Jk is
+    // already nearly diagonal and two or three sweeps finish what eight start from the identity (0.5 ms -> 0.2 ms).  The
+    // products run in place: every thread forms its four entries in registers, a barrier, then the write.
+    if (FULL && inner_sweeps > 1 && warm_flag != nullptr && Jkeep != nullptr && warm_flag[0] != 0) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int e = tid + w * EIG_THREADS;
+            Jm[e >> 6][e & 63] = Jkeep[e];
+        }
+        __syncthreads();
+        double t4[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {  // T = S Jk
+            const int e = tid + w * EIG_THREADS, i = e >> 6, j = e & 63;
+            double a = 0.0;
+            for (int kk = 0; kk < JP; ++kk) a = fma(S[i][kk], Jm[kk][j], a);
+            t4[w] = a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int e = tid + w * EIG_THREADS;
+            S[e >> 6][e & 63] = t4[w];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {  // S' = Jk^T T
+            const int e = tid + w * EIG_THREADS, i = e >> 6, j = e & 63;
+            double a = 0.0;
+            for (int kk = 0; kk < JP; ++kk) a = fma(Jm[kk][i], S[kk][j], a);
+            t4[w] = a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int e = tid + w * EIG_THREADS;
+            S[e >> 6][e & 63] = t4[w];
+        }
+        __syncthreads();
+    }
     const int l = tid & 31, k = tid >> 5;
     const double tol2 = tol * tol;
     int nrot = 0;
@@ -276,6 +325,10 @@ __global__ __launch_bounds__(EIG_THREADS) void jac_eig_kernel(const double* __re
 #ifdef MVF_EIG_CLOCKS
     const unsigned long long c1 = wall_clock64();
 #endif
+    int nrot_any = 0;
+#pragma unroll 1
+    for (int sw = 0; sw < (FULL ? inner_sweeps : 1); ++sw) {
+    nrot = 0;
     if (k == 0) rotation(0, cs[0]);
     __syncthreads();
     // Per round: (1) every thread rotates its 2 x 2 block of S; barrier; (2) the first half-wave computes the NEXT round's
@@ -323,11 +376,24 @@ __global__ __launch_bounds__(EIG_THREADS) void jac_eig_kernel(const double* __re
         }
         __syncthreads();
     }
+    if (inner_sweeps > 1) {  // uniform: did this sweep rotate anything?  (nrot lives in the first half-wave)
+        if (tid == 0) sweep_rot = nrot;
+        __syncthreads();
+        const int sr = sweep_rot;
+        nrot_any += sr;
+        __syncthreads();  // everybody has read sweep_rot before the next sweep's thread 0 overwrites it
+        if (sr == 0) break;
+    } else {
+        nrot_any = nrot;
+    }
+    }
 #ifdef MVF_EIG_CLOCKS
     const unsigned long long c2 = wall_clock64();
 #endif
     double* jo = Jbuf + (int64_t)pair * (JP * JP);
     for (int e = tid; e < JP * JP; e += EIG_THREADS) jo[e] = Jm[e >> 6][e & 63];
+    if (FULL && inner_sweeps > 1 && Jkeep != nullptr)
+        for (int e = tid; e < JP * JP; e += EIG_THREADS) Jkeep[e] = Jm[e >> 6][e & 63];
 #ifdef MVF_EIG_CLOCKS
     if (tid == 0 && !FULL) {
         rot_total[4] = (unsigned int)(c1 - c0);
@@ -336,9 +402,13 @@ __global__ __launch_bounds__(EIG_THREADS) void jac_eig_kernel(const double* __re
     }
 #endif
     if (tid == 0) {
-        flags[pair] = nrot > 0;
-        if (nrot > 0) {
-            atomicAdd(rot_total, (unsigned int)nrot);
+        // inner_sweeps = 1: nrot_any == nrot (this sweep's count).  inner_sweeps > 1: J carries every sweep (flag / stamps from
+        // nrot_any), the host's convergence counter gets the LAST sweep's count
+        const bool warmed = FULL && inner_sweeps > 1 && warm_flag != nullptr && Jkeep != nullptr && warm_flag[0] != 0;
+        if (warmed) nrot_any += 1;  // J = Jk x (this call's rotations): the update must be applied even if no sweep rotated
+        flags[pair] = nrot_any > 0;
+        if (nrot_any > 0) {
+            if (nrot > 0) atomicAdd(rot_total, (unsigned int)nrot);
             mod[bp] = stamp;  // each block is in exactly one pair per round: single writer
             mod[bq] = stamp;
         } else {
@@ -632,10 +702,12 @@ __global__ __launch_bounds__(256) void basis_extract_kernel(const double* __rest
 // the unpivoted shifted factor needs 26 - and no shift delta, no retry ladder.
 // Y (row j = column j of L, row length mp) is produced row by row: coalesced stores, and exactly the layout the Jacobi
 // kernels want.
+constexpr int PCHOL_MAGIC_V = 0x6d766c72;  // == PCHOL_MAGIC (declared with the factorisation kernels below)
 struct PcholState {
     int done, r, panels, hint_broken;  // panels = hint panels accepted so far (the next panel's index)
     double tol, lmax_est, maxdiag, lmax_prev;  // lmax_prev: the Rayleigh quotient one power step earlier
-    int panel_nvalid, magic, order_len, pad3;  // magic / order_len: the workspace holds the pivot order of a finished call
+    int panel_nvalid, magic, order_len, keep_len;  // magic / order_len: the workspace holds the pivot order of a finished call;
+                                                    // keep_len: length of the kept dominant eigenvector (warm power iteration)
     int defl, defl_block, pad4, defl_nsel;      // defl = 1: the workspace holds the DEFLATED decomposition (mvf_solve_minnorm_lrd)
                                                 // of block size defl_block; defl_nsel: directions its last call deflated
 };
@@ -655,13 +727,20 @@ __global__ __launch_bounds__(256) void lr_symv_kernel(const double* __restrict__
 
 // first = 1: x = 1 / sqrt(m) on the live entries.  Else: est = x^T y (x has unit norm: the Rayleigh quotient, a lower
 // bound of lambda_max that converges from below), x = y / ||y||.
+// first = 2 (warm): x = `keep`, the dominant eigenvector the previous call on this workspace ended its power iteration with -
+// taken only if the workspace really holds a finished call of that factor rank (the same test as the pivot-order hint), else
+// the cold start.  keep_out (may be NULL, first = 0 only): the normalised iterate is also written there.
 __global__ __launch_bounds__(256) void lr_power_kernel(double* __restrict__ x, const double* __restrict__ y, int64_t m,
-                                                       int64_t mp, int first, PcholState* __restrict__ stt) {
+                                                       int64_t mp, int first, PcholState* __restrict__ stt,
+                                                       const double* __restrict__ keep = nullptr, int hint_len = 0,
+                                                       double* __restrict__ keep_out = nullptr) {
     __shared__ double red[4];
     __shared__ double bc[2];
     if (first) {
+        const bool warm = first == 2 && keep != nullptr && stt->magic == PCHOL_MAGIC_V && stt->order_len == hint_len &&
+                          stt->keep_len == (int)m;
         const double v = 1.0 / sqrt((double)m);
-        for (int64_t i = threadIdx.x; i < mp; i += 256) x[i] = i < m ? v : 0.0;
+        for (int64_t i = threadIdx.x; i < mp; i += 256) x[i] = i < m ? (warm ? keep[i] : v) : 0.0;
         if (threadIdx.x == 0) stt->lmax_est = stt->lmax_prev = 0.0;
         return;
     }
@@ -678,15 +757,20 @@ __global__ __launch_bounds__(256) void lr_power_kernel(double* __restrict__ x, c
     }
     __syncthreads();
     const double inv = bc[1] > 0.0 ? 1.0 / sqrt(bc[1]) : 0.0;
-    for (int64_t i = threadIdx.x; i < mp; i += 256) x[i] = y[i] * inv;
+    for (int64_t i = threadIdx.x; i < mp; i += 256) {
+        const double v = y[i] * inv;
+        x[i] = v;
+        if (keep_out) keep_out[i] = v;
+    }
     if (threadIdx.x == 0) {
         stt->lmax_prev = stt->lmax_est;
         stt->lmax_est = bc[0];
+        if (keep_out) stt->keep_len = (int)m;
     }
 }
 
 constexpr int PC_T = 128;  // threads (= columns of A) per workgroup of the pivot step
-constexpr int PCHOL_MAGIC = 0x6d766c72;
+constexpr int PCHOL_MAGIC = PCHOL_MAGIC_V;
 constexpr double PCHOL_THETA = 0.0009765625;  // 2^-10, see pchol_panel_factor_kernel
 
 // dg[i] = A_ii (-inf on the padding: never a pivot), per-workgroup (max, argmax) partials, the tolerance, the state
@@ -1239,11 +1323,126 @@ __global__ __launch_bounds__(256) void defl_sub_kernel(const double* __restrict_
     T[e] -= s;
 }
 
+// ---- the direct form of the small deflated solve (round 5) ---------------------------------------------------------------
+// When the previous call on the workspace factored ALL m columns (factor rank r = m: what M <= 640 control points give, BASELINE
+// configs 2 and 5) the pivoted Cholesky of the next, nearby matrix is, in that pivot order, an ordinary Cholesky of the permuted
+// matrix: A_perm = Rc Rc^T.  The blocked factorisation with the inverse riding along then yields A_perm^-1 = Rc^-T Rc^-1 in
+// ONE factorisation - no pivoted factor, no S2 = L^T L and no second factorisation - and the truncated solve is
+//     C = Pi^T Pc E E^T Pc Pi R,   E = Rc^-T,  Pc = I - W^T W,  W = the eigenvectors of A_perm with lambda <= rcond lambda_max
+// (block inverse iteration on 64 vectors + Rayleigh-Ritz as in the factor form; the projection BEFORE the inverse keeps the
+// dropped directions' 1 / lambda out, the one after it removes what rounding leaked back).  Two things keep the GRADING of the
+// factor, without which the field loses 3 - 4 digits (measured: the product E E^T applied once, and H = Z A_perm Z^T, agree
+// with the factor form to 1e-6 ... 8e-3 only): the inverse is applied as its two triangular factors, never as their product,
+// and the Rayleigh-Ritz matrix is the Gram matrix of B = Z Rc (H = B B^T), not a product with the assembled matrix.  Accepted only if every
+// pivot clears the stopping tolerance tolf eps lambda_max (the factor form would have kept all m columns too) and at most
+// DEFL_TINY_ACCEPT Ritz values lie below the cut; anything else re-runs the call in the factor form.
+__global__ __launch_bounds__(256) void direct_prepare_kernel(const double* __restrict__ S, int64_t m, int64_t mp, double tolf,
+                                                             PcholState* __restrict__ stt, int* __restrict__ info,
+                                                             int* __restrict__ dflag) {
+    __shared__ double red[4];
+    double mx = 0.0;
+    bool finite = true;
+    for (int64_t i = threadIdx.x; i < m; i += 256) {
+        const double d = S[i * mp + i];
+        finite = finite && (fabs(d) <= 1.79e308);
+        mx = fmax(mx, d);
+    }
+    const double bad = block_sum<256>(finite ? 0.0 : 1.0, red);
+    const double t = -block_min<256>(-mx, red);
+    if (threadIdx.x == 0) {
+        const double est = stt->lmax_est;
+        const bool ok = bad == 0.0 && (fabs(est) <= 1.79e308);
+        const double lmax = fmax(ok ? est : 0.0, t);
+        stt->maxdiag = t;
+        stt->lmax_est = lmax;
+        stt->tol = tolf * 2.220446049250313e-16 * lmax;
+        info[0] = ok ? 0 : 1;
+        // the pivot order in the workspace must be that of a finished factorisation of ALL m columns (magic / order_len stay
+        // untouched: the factor form, if it has to answer, reads them for its own hint)
+        const int valid = (ok && stt->magic == PCHOL_MAGIC_V && stt->order_len == (int)m) ? 1 : 0;
+        dflag[0] = valid;
+        // the kept Rayleigh-Ritz rotation is that of the previous call only if that call was answered by the direct form
+        dflag[1] = (valid && stt->defl == 2 && stt->pad4 == 1) ? 1 : 0;
+    }
+}
+
+// A[i][j] = S[order[i]][order[j]] (zero padding to rp); the identity order when the state was not valid (the result is then
+// discarded, but nothing is read out of bounds)
+__global__ __launch_bounds__(256) void perm_gather_kernel(const double* __restrict__ S, int64_t mp, const int* __restrict__ order,
+                                                          int64_t m, int64_t rp, const int* __restrict__ dflag,
+                                                          double* __restrict__ A) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= rp) return;
+    double v = 0.0;
+    if (i < m && j < m) {
+        const bool ok = dflag[0] != 0;
+        int64_t oi = ok ? order[i] : i, oj = ok ? order[j] : j;
+        if (oi < 0 || oi >= m) oi = i;
+        if (oj < 0 || oj >= m) oj = j;
+        v = S[oi * mp + oj];
+    }
+    A[i * rp + j] = v;
+}
+
+// piv[j] = Rc_jj^2 (what the pivoted factorisation records); the direct form is void unless every pivot clears the tolerance
+__global__ __launch_bounds__(256) void direct_check_kernel(const double* __restrict__ rdiag, int64_t m,
+                                                           const PcholState* __restrict__ stt, const int* __restrict__ info,
+                                                           double* __restrict__ piv, int* __restrict__ dflag) {
+    __shared__ double red[4];
+    double lo = INFINITY;
+    for (int64_t i = threadIdx.x; i < m; i += 256) {
+        const double l = 1.0 / rdiag[i];
+        const double v = l * l;
+        piv[i] = v;
+        lo = (v == v) ? fmin(lo, v) : -INFINITY;  // NaN pivots fail the test
+    }
+    const double t = block_min<256>(lo, red);
+    if (threadIdx.x == 0 && (!(t >= stt->tol) || info[0] != 0)) dflag[0] = 0;
+}
+
+// Lo = the lower triangle of the factorisation's work matrix (its blocks above the diagonal still hold matrix entries);
+// Et = E^T (E = Rc^-T, upper triangular): both n x n with leading dimension n
+__global__ __launch_bounds__(256) void tril_and_transpose_kernel(const double* __restrict__ W, const double* __restrict__ E,
+                                                                 int64_t n, double* __restrict__ Lo, double* __restrict__ Et) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= n) return;
+    Lo[i * n + j] = j <= i ? W[i * n + j] : 0.0;
+    Et[i * n + j] = E[j * n + i];
+}
+
+// T[i][0..8) = R[order[i]][0..nrhs) (zero padded), and back: C[order[i]][d] = T[i][d]
+__global__ __launch_bounds__(256) void perm_rows_kernel(const double* __restrict__ R, int nrhs, const int* __restrict__ order,
+                                                        int64_t m, int64_t rp, const int* __restrict__ dflag,
+                                                        double* __restrict__ T) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= rp * 8) return;
+    const int64_t i = e >> 3;
+    const int d = (int)(e & 7);
+    double v = 0.0;
+    if (i < m && d < nrhs) {
+        int64_t oi = dflag[0] ? order[i] : i;
+        if (oi < 0 || oi >= m) oi = i;
+        v = R[oi * nrhs + d];
+    }
+    T[e] = v;
+}
+__global__ __launch_bounds__(256) void unperm_rows_kernel(const double* __restrict__ T, int nrhs, const int* __restrict__ order,
+                                                          int64_t m, const int* __restrict__ dflag, double* __restrict__ C) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * 8) return;
+    const int64_t i = e >> 3;
+    const int d = (int)(e & 7);
+    if (d >= nrhs) return;
+    int64_t oi = dflag[0] ? order[i] : i;
+    if (oi < 0 || oi >= m) oi = i;
+    C[oi * nrhs + d] = T[e];
+}
+
 struct LrPlan {
     int64_t mp;
     int nbmax, npmax, nwg, spart_tiles;
     size_t off_s, off_y, off_dg, off_pm, off_x, off_state, off_order, off_piv, off_spart, off_j, off_flags, off_stamps,
-        off_sig2, off_t, off_part, off_rot, off_scal, off_hint, off_lcc, off_cand, total, off_d, total_d;
+        off_sig2, off_t, off_part, off_rot, off_scal, off_hint, off_lcc, off_cand, off_xkeep, off_dflag, off_jkeep, total, off_d, total_d;
 };
 
 constexpr int LR_GRAM_WGS = 512;  // upper bound of the workgroups per Jacobi Gram launch (pairs x K splits)
@@ -1282,6 +1481,9 @@ static LrPlan lr_plan(int64_t m) {
     p.off_hint = take((size_t)p.mp * sizeof(int));
     p.off_lcc = take((size_t)64 * 64 * sizeof(double));
     p.off_cand = take(256);
+    p.off_xkeep = take((size_t)p.mp * sizeof(double));
+    p.off_dflag = take(256);
+    p.off_jkeep = take((size_t)JP * JP * sizeof(double));
     p.total = o;
     // scratch of the deflated solve (mvf_solve_minnorm_lrd only; sized for a factor of full width)
     p.off_d = take(defl_scratch_bytes(p.mp));
@@ -1549,7 +1751,7 @@ extern "C" size_t mvf_solve_minnorm_lr_workspace_bytes(int64_t m, int nrhs) {
 
 static int lr_solve(const double* G, const double* K, double lambda_sigma2, double tolf, double rcond, const double* R,
                     int64_t m, int nrhs, double* C, int* info, double* einfo, int max_sweeps, int reuse, int rank_hint,
-                    void* workspace, size_t workspace_bytes, void* stream, bool deflate) {
+                    void* workspace, size_t workspace_bytes, void* stream, bool deflate, bool allow_direct = true) {
     MVF_REQUIRE(m >= 0 && nrhs >= 1 && nrhs <= 8,
                 "mvf_solve_minnorm_lr: need m >= 0 and 1 <= nrhs <= 8 (got m=%lld nrhs=%d)", (long long)m, nrhs);
     MVF_REQUIRE(info && einfo, "mvf_solve_minnorm_lr: null info / einfo");
@@ -1641,6 +1843,34 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         return 0;
     };
 
+    // the direct form's solve from (E = Rc^-T and its transpose, the deflation vectors, the pivot order): C = Pi^T Pc E E^T Pc Pi R
+    int* dflag = (int*)(ws + p.off_dflag);
+    auto direct_apply = [&](int64_t rp, int b) -> int {
+        const DeflBuf d = defl_layout(rp);
+        char* dw = ws + p.off_d;
+        double *Ta = (double*)(dw + d.ta), *Tb = (double*)(dw + d.tb), *cb = (double*)(dw + d.cb);
+        double *dummy = (double*)(dw + d.dummy), *dpart = (double*)(dw + d.part), *Wsel = (double*)(dw + d.wsel);
+        auto project = [&](double* T) {  // T -= Wsel^T (Wsel T)
+            hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, Wsel, (int64_t)b, rp, rp, T, 8,
+                               dummy, cb);
+            hipLaunchKernelGGL(jac_back_kernel, dim3((unsigned)(rp / 64), 4u), dim3(256), 0, st, Wsel, (int64_t)b, rp, rp, cb,
+                               b / 4, dpart);
+            hipLaunchKernelGGL(defl_sub_kernel, dim3((unsigned)cdiv(rp * 8, 256)), dim3(256), 0, st, dpart, 4, rp, T);
+        };
+        hipLaunchKernelGGL(perm_rows_kernel, dim3((unsigned)cdiv(rp * 8, 256)), dim3(256), 0, st, R, nrhs, order, m, rp, dflag, Ta);
+        project(Ta);
+        // E^T (Pc b), then E (...): rows of Et / E dot the 8-column block (E = Rc^-T sits behind the factor in the
+        // factorisation's workspace, Et in the slot of the permuted matrix)
+        const double* E = (const double*)(dw + d.cw) + rp * rp;
+        const double* Et = (const double*)(dw + d.s2);
+        hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(rp, 4)), dim3(256), 0, st, Et, rp, rp, rp, Ta, 8, dummy, Tb);
+        hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(rp, 4)), dim3(256), 0, st, E, rp, rp, rp, Tb, 8, dummy, Ta);
+        project(Ta);
+        hipLaunchKernelGGL(unperm_rows_kernel, dim3((unsigned)cdiv(m * 8, 256)), dim3(256), 0, st, Ta, nrhs, order, m, dflag, C);
+        MVF_LAUNCH_CHECK();
+        return 0;
+    };
+
     if (reuse) {
         // the workspace still holds the decomposition of the previous call for this matrix
         MVF_CHECK_HIP(hipMemcpyAsync(&hs, stt, sizeof(hs), hipMemcpyDeviceToHost, st));
@@ -1654,6 +1884,10 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             MVF_REQUIRE(workspace_bytes >= p.total_d, "mvf_solve_minnorm_lr: reuse of a deflated decomposition needs its workspace");
             MVF_REQUIRE(hs.defl_block == DEFL_B || hs.defl_block == DEFL_B / 2 || hs.defl_block == DEFL_TINY,
                         "mvf_solve_minnorm_lr: corrupt deflation state");
+            if (hs.defl == 2) {  // the direct form answered the previous call (dflag is still 1 from it)
+                MVF_REQUIRE(hs.r == m, "mvf_solve_minnorm_lr: corrupt direct-form state");
+                return direct_apply(cdiv(hs.r, 64) * 64, hs.defl_block);
+            }
             return defl_apply(cdiv(hs.r, 64) * 64, hs.defl_block);
         }
         return backsolve(cdiv(hs.r, 64) * 64, einfo + 6);
@@ -1663,11 +1897,133 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
     hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)cdiv(mp, 256), (unsigned)mp), dim3(256), 0, st, G, K, lambda_sigma2,
                        m, mp, S);
     MVF_CHECK_HIP(hipMemsetAsync(scal, 0, 256, st));
-    hipLaunchKernelGGL(lr_power_kernel, dim3(1), dim3(256), 0, st, xv, xv + mp, m, mp, 1, stt);
-    for (int it = 0; it < (deflate ? 12 : 8); ++it) {  // the deflated solve takes its cut-off from this estimate
+    // lambda_max: power iteration.  With a rank hint it starts from the dominant eigenvector the previous call on this
+    // workspace (the previous EM iteration: a nearby matrix) ended with - the Rayleigh quotient is then converged to ~1e-12
+    // after 5 steps where the cold start needs 12 for 1e-8 (and, at M = 500, a second run on S2: 0.45 ms of a 3 ms solve).
+    // A workspace that does not hold a finished call falls back to the cold start vector on the device; the convergence
+    // test before the deflated solve then refines as before.
+    double* xkeep = (double*)(ws + p.off_xkeep);
+    const int use_hint0 = rank_hint > 0 && rank_hint <= m;
+    const int npow = use_hint0 ? 5 : (deflate ? 12 : 8);  // the deflated solve takes its cut-off from this estimate
+    hipLaunchKernelGGL(lr_power_kernel, dim3(1), dim3(256), 0, st, xv, xv + mp, m, mp, use_hint0 ? 2 : 1, stt,
+                       (const double*)xkeep, rank_hint, (double*)nullptr);
+    for (int it = 0; it < npow; ++it) {
         hipLaunchKernelGGL(lr_symv_kernel, dim3((unsigned)cdiv(mp, 4)), dim3(256), 0, st, S, mp, xv, xv + mp);
-        hipLaunchKernelGGL(lr_power_kernel, dim3(1), dim3(256), 0, st, xv, xv + mp, m, mp, 0, stt);
+        hipLaunchKernelGGL(lr_power_kernel, dim3(1), dim3(256), 0, st, xv, xv + mp, m, mp, 0, stt, (const double*)nullptr, 0,
+                           it == npow - 1 ? xkeep : (double*)nullptr);
     }
+    // 1'. the direct form (see direct_prepare_kernel): the previous call on this workspace kept all m columns
+    const int64_t rpm = cdiv(m, 64) * 64;
+    if (deflate && allow_direct && use_hint0 && rank_hint == m && m >= 2 * DEFL_TINY && m <= 640 && 2 * rpm <= 65535 &&
+        debug_opt(DBG_LR_NO_DEFLATE) == 0 && debug_opt(DBG_LR_NO_DIRECT) == 0) {
+        const int64_t rp = rpm;
+        const int b = DEFL_TINY;
+        const DeflBuf d = defl_layout(rp);
+        char* dw = ws + p.off_d;
+        double *Ap = (double*)(dw + d.s2), *Za = (double*)(dw + d.za), *Zb = (double*)(dw + d.zb);
+        double *Wsel = (double*)(dw + d.wsel), *Gb = (double*)(dw + d.g), *H = (double*)(dw + d.h), *Yh = (double*)(dw + d.yh);
+        double *theta = (double*)(dw + d.theta), *dummy = (double*)(dw + d.dummy);
+        double* Minv = S;
+        hipLaunchKernelGGL(direct_prepare_kernel, dim3(1), dim3(256), 0, st, S, m, mp, tolf, stt, info, dflag);
+        hipLaunchKernelGGL(perm_gather_kernel, dim3((unsigned)cdiv(rp, 256), (unsigned)rp), dim3(256), 0, st, S, mp, order, m, rp,
+                           dflag, Ap);
+        MVF_LAUNCH_CHECK();
+        CholPlan cs, cq;
+        if (int rc = chol_factor_mat_inv(st, Ap, rp, m, dw + d.cw, &cs, info, 1)) return rc;
+        hipLaunchKernelGGL(direct_check_kernel, dim3(1), dim3(256), 0, st, cs.rdiag, m, stt, info, piv, dflag);
+        const double* E = cs.W + rp * rp;                           // Rc^-T (upper triangular, identity on the padding)
+        (void)Minv;
+        auto orthonormalise = [&](const double* Zin, double* Zout) -> int {  // Cholesky QR on the rows
+            gemm<false, true>(st, Zin, rp, Zin, rp, Gb, b, b, b, rp);
+            if (int rc = chol_factor_mat_inv(st, Gb, b, b, dw + d.cwb, &cq, info, 1)) return rc;
+            gemm<true, false>(st, cq.W + (size_t)b * b, b, Zin, rp, Zout, rp, b, rp, b);
+            return 0;
+        };
+        // block inverse iteration from the unit vectors of the b smallest pivots, three applications of A_perm^-1 = E E^T -
+        // applied factor by factor (Z E, then (Z E) E^T): the product E E^T is never formed
+        gemm<false, true>(st, E + (m - b) * rp, rp, E, rp, Zb, rp, b, rp, rp);  // rows m-b .. m-1 of E E^T
+        if (int rc = orthonormalise(Zb, Za)) return rc;
+        for (int ap = 1; ap < 3; ++ap) {
+            gemm<false, false>(st, Za, rp, E, rp, Wsel, rp, b, rp, rp);
+            gemm<false, true>(st, Wsel, rp, E, rp, Zb, rp, b, rp, rp);
+            if (int rc = orthonormalise(Zb, Za)) return rc;
+        }
+        // Rayleigh-Ritz: H = Za A_perm Za^T as the Gram matrix of B = Za Rc (the graded factor, not the assembled matrix), one
+        // 64 x 64 Jacobi tile diagonalised in a single launch.  Lo = tril(Rc) goes to the slot of the factor rows (unused in
+        // this form), E^T to the slot of the permuted matrix (used up by the factorisation).
+        double* Lo = Y;
+        hipLaunchKernelGGL(tril_and_transpose_kernel, dim3((unsigned)cdiv(rp, 256), (unsigned)rp), dim3(256), 0, st, cs.W, E, rp, Lo,
+                           Ap);
+        gemm<false, false>(st, Za, rp, Lo, rp, Zb, rp, b, rp, rp);
+        gemm<false, true>(st, Zb, rp, Zb, rp, H, b, b, b, rp);
+        if (int rc = chol_factor_mat_inv(st, H, b, b, dw + d.cwb, &cq, info, 0)) return rc;
+        hipLaunchKernelGGL(jac_init_kernel, dim3(1u, 1u), dim3(256), 0, st, cq.W, (int64_t)b, (int64_t)b, Yh);
+        const int hnb = b / JB;  // 2: one pair
+        const double htol = std::sqrt((double)b) * 2.220446049250313e-16;
+        int* hclean = mod + hnb;
+        MVF_CHECK_HIP(hipMemsetAsync(mod, 0, (size_t)(hnb + (size_t)hnb * hnb) * sizeof(int), st));
+        int hsweeps = 0;
+        unsigned int hrot2 = 1;
+        while (hsweeps < std::max(2, max_sweeps / 12)) {  // each launch runs up to 12 sweeps
+            MVF_CHECK_HIP(hipMemsetAsync(rot, 0, sizeof(unsigned int), st));
+            hipLaunchKernelGGL(jac_gram_kernel, dim3(1u, 1u), dim3(256), 0, st, Yh, (int64_t)b, hnb, 0, 1, 1, mod, hclean, Spart);
+            // (the first launch starts from the previous call's total rotation when that call was a direct one; a second
+            // launch - never seen - would continue from the rotated factor and must start cold)
+            hipLaunchKernelGGL(jac_eig_kernel<true>, dim3(1u), dim3(EIG_THREADS), 0, st, Spart, 1, htol, hnb, 0, 1 + hsweeps, mod,
+                               hclean, Jbuf, flags, rot, 12, hsweeps == 0 ? (const int*)(dflag + 1) : (const int*)nullptr,
+                               hsweeps == 0 ? (double*)(ws + p.off_jkeep) : (double*)nullptr);
+            hipLaunchKernelGGL(jac_update_kernel, dim3(1u, 1u), dim3(256), 0, st, Yh, (int64_t)b, hnb, 0, Jbuf, flags);
+            MVF_LAUNCH_CHECK();
+            ++hsweeps;
+            MVF_CHECK_HIP(hipMemcpyAsync(&hrot2, rot, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+            MVF_CHECK_HIP(hipStreamSynchronize(st));
+            if (hrot2 == 0) break;
+        }
+        hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, Yh, (int64_t)b, (int64_t)b, (int64_t)b,
+                           R, 0, theta, dummy);
+        hipLaunchKernelGGL(defl_select_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, theta, b, stt, rcond, m, Yh, einfo);
+        gemm<false, false>(st, Yh, b, Za, rp, Wsel, rp, b, rp, b);  // rows = the Ritz vectors to deflate (zero rows else)
+        MVF_LAUNCH_CHECK();
+        if (int rc = direct_apply(rp, b)) return rc;
+        double he[6] = {0, 0, 0, 0, 0, 0};
+        int hinfo2 = 0, hflag = 0;
+        PcholState hq;
+        MVF_CHECK_HIP(hipMemcpyAsync(he, einfo, sizeof(he), hipMemcpyDeviceToHost, st));
+        MVF_CHECK_HIP(hipMemcpyAsync(&hinfo2, info, sizeof(int), hipMemcpyDeviceToHost, st));
+        MVF_CHECK_HIP(hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
+        MVF_CHECK_HIP(hipMemcpyAsync(&hq, stt, sizeof(hq), hipMemcpyDeviceToHost, st));
+        MVF_CHECK_HIP(hipStreamSynchronize(st));
+        // the cut-off needs a converged lambda_max: the warm power iteration's last two Rayleigh quotients must agree
+        const bool lmax_ok = std::fabs(hq.lmax_est - hq.lmax_prev) <= 1e-7 * hq.lmax_est || hq.lmax_est == hq.maxdiag;
+        const bool ok = hinfo2 == 0 && hflag == 1 && hrot2 == 0 && lmax_ok && he[4] <= (double)DEFL_TINY_ACCEPT &&
+                        std::isfinite(he[5]) && he[5] > 0.0;
+        if (timing) {
+            MVF_CHECK_HIP(hipEventRecord(ev[3], st));
+            MVF_CHECK_HIP(hipEventSynchronize(ev[3]));
+            float t03 = 0;
+            (void)hipEventElapsedTime(&t03, ev[0], ev[3]);
+            fprintf(stderr, "[mvf_solve_minnorm_lrd] m %lld direct form: %.2f ms (%d launch(es) of the 64 x 64 Rayleigh-Ritz, %d below the cut, info %d, state %d, lambda_max %s)%s\n",
+                    (long long)m, t03, hsweeps, (int)he[4], hinfo2, hflag, lmax_ok ? "converged" : "NOT converged",
+                    ok ? "" : " -> factor form");
+            for (auto& e : ev) (void)hipEventDestroy(e);
+        }
+        if (ok) {
+            // the workspace now holds: the same pivot order (all m columns), their pivots, A_perm^-1 and the deflation vectors
+            const int head[2] = {1, (int)m};  // done, r
+            MVF_CHECK_HIP(hipMemcpyAsync(stt, head, sizeof(head), hipMemcpyHostToDevice, st));
+            // magic, order_len, keep_len, defl = 2, block, pad4 = the kept Rayleigh-Ritz rotation is this call's complete one, nsel
+            const int tag[7] = {PCHOL_MAGIC, (int)m, (int)m, 2, b, hsweeps == 1 ? 1 : 0, (int)he[4]};
+            MVF_CHECK_HIP(hipMemcpyAsync(&stt->magic, tag, sizeof(tag), hipMemcpyHostToDevice, st));
+            const double hsw[8] = {(double)hsweeps, he[1], he[2], he[3], 0.0, he[5], (double)m, (double)b};
+            MVF_CHECK_HIP(hipMemcpyAsync(einfo, hsw, sizeof(hsw), hipMemcpyHostToDevice, st));
+            MVF_CHECK_HIP(hipStreamSynchronize(st));
+            return 0;
+        }
+        // anything else: the factor form answers (re-assembles S, which now holds the inverse)
+        return lr_solve(G, K, lambda_sigma2, tolf, rcond, R, m, nrhs, C, info, einfo, max_sweeps, reuse, rank_hint, workspace,
+                        workspace_bytes, stream, deflate, false);
+    }
+
     int* hint = (int*)(ws + p.off_hint);
     double* Lcc = (double*)(ws + p.off_lcc);
     int* candb = (int*)(ws + p.off_cand);
@@ -1727,7 +2083,8 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         if (hs.done || j >= msteps) break;
         upto = std::min(msteps, upto + (tail_only ? 32 : 128));
     }
-    const int tag[6] = {PCHOL_MAGIC, (int)hs.r, 0, 0, 0, 0};  // this workspace now holds a finished order of hs.r rows
+    // this workspace now holds a finished order of hs.r rows (and the dominant eigenvector of this call: keep_len = m)
+    const int tag[6] = {PCHOL_MAGIC, (int)hs.r, (int)m, 0, 0, 0};
     MVF_CHECK_HIP(hipMemcpyAsync(&stt->magic, tag, sizeof(tag), hipMemcpyHostToDevice, st));  // (tag lives until the
                                                                                                 // final synchronise)
     const int64_t r = hs.r;
@@ -1823,9 +2180,9 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
                     const int stamp = 1 + hsweeps * (hnb - 1) + rd;
                     hipLaunchKernelGGL(jac_gram_kernel, dim3((unsigned)hnp, (unsigned)hnk), dim3(256), 0, st, Yh, (int64_t)b,
                                        hnb, rd, hnk, 1, mod, hclean, Spart);
-                    if (rd == 0)
+                    if (rd == 0)  // (a 64-vector block is ONE pair: all its sweeps run inside this launch)
                         hipLaunchKernelGGL(jac_eig_kernel<true>, dim3((unsigned)hnp), dim3(EIG_THREADS), 0, st, Spart, hnk,
-                                           htol, hnb, rd, stamp, mod, hclean, Jbuf, flags, rot);
+                                           htol, hnb, rd, stamp, mod, hclean, Jbuf, flags, rot, hnb == 2 ? 12 : 1);
                     else
                         hipLaunchKernelGGL(jac_eig_kernel<false>, dim3((unsigned)hnp), dim3(EIG_THREADS), 0, st, Spart, hnk,
                                            htol, hnb, rd, stamp, mod, hclean, Jbuf, flags, rot);

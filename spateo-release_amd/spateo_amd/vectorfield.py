@@ -42,7 +42,7 @@ __all__ = [
 ]
 
 _DEFAULT_DTYPE = "float64"
-DEFLATED_MIN_M = 640  # control points from which the rank-revealing (deflated) solve is the default
+DEFLATED_MIN_M = 256  # control points from which the rank-revealing (deflated) solve is the default (640 until round 4)
 
 
 def _make_kernels(device, dtype):
@@ -452,8 +452,11 @@ class SparseVFCEngine:
         # measured per solve in the EM's steady state (ms, lowrank / full): M = 500: 8.7 / 3.6, 1000: 17.3 / 18.4,
         # 1500: 20.9 / 33, 2000: 21.6 / 54, 3000: 23.6 / 113 - the full-width warm start wins while the factor keeps
         # nearly every column
-        # round 4, deflated / full (ms): M = 640: 4.6 / 6.5, 768: 5.0 / 10.3, 896: 7.5 / 14.5, 1000: 7.5 / 17.5 (the deflated route
-        # needs >= 512 factor columns, which M >= 640 delivers: r = 632 there; below that the call is the Jacobi form)
+        # round 4, deflated / full (ms): M = 640: 4.6 / 6.5, 768: 5.0 / 10.3, 896: 7.5 / 14.5, 1000: 7.5 / 17.5
+        # round 5: factors of 128 .. 511 columns take a 64-vector block, and when the previous iteration's factor kept ALL M
+        # columns (M <= 640: BASELINE configs 2 and 5) the call takes its direct form - one Cholesky of the permuted matrix with
+        # the inverse factor riding along, block inverse iteration, a one-launch warm-started 64 x 64 Rayleigh-Ritz:
+        # M = 500: 1.83 / 3.6 ms (profiles/r05_small_m_probe.json); below 256 control points the full-width solve stays
         self.mn_method = self.minnorm_method or ("deflated" if self.M >= DEFLATED_MIN_M else "full")
         self.rank_hint = 0
         # lstsq_method="cholesky" (extension, not a reference mode): jitter-escalated Cholesky, the round-1 solver

@@ -345,7 +345,7 @@ def test_solve_minnorm_full_rank_equals_the_inverse(st, m, nrhs, method):
     assert int(e[1]) == m
     if method != "full":
         assert int(e[6]) == m  # the factor keeps every column of a well-conditioned matrix
-    if method == "deflated" and m >= 512:
+    if method == "deflated" and m >= 128:
         # the deflated solve knows lambda_max from its power iteration (stopped when two successive Rayleigh quotients agree
         # to 1e-7: a few 1e-6 on this clustered Wishart spectrum, 1e-8 on kernel Gram matrices) and the smallest Ritz value
         # of its block only
@@ -461,6 +461,61 @@ def test_deflated_solve_shrinks_its_block_when_few_directions_are_truncated(st):
     assert 0 < int(e0[6]) - int(e0[1]) <= 72 and int(e0[6]) == int(f0[6]) and int(e1[6]) == int(f1[6])
     assert int(e0[1]) == int(f0[1]) and int(e1[1]) == int(f1[1])
     assert d0 < 1e-4 and d1 < 1e-4
+
+
+@pytest.mark.parametrize("n,m", [(50000, 500), (20000, 300), (16000, 400)])
+def test_deflated_solve_small_factor_uses_a_64_vector_block(st, n, m):
+    """Factors of 128 .. 511 columns (M = 128 .. 640 control points: BASELINE configs 2 and 5) take a 64-vector block whose
+    Rayleigh-Ritz problem is ONE 64 x 64 Jacobi tile, diagonalised inside a single launch (round 5).  Two calls on one
+    workspace, as the EM loop makes them (greedy factor, then the hinted factor with the power iteration warm-started from the
+    kept dominant eigenvector): the field against scipy.linalg.lstsq within twice the reference's own lstsq-vs-eigh floor,
+    against the Jacobi path run through the same two calls far below it, the same kept rank, lambda_max to 1e-6."""
+    import scipy.linalg
+
+    U, G, K, R, ls2 = _kernel_system(n, m, s2=2.4e-3)
+    A = G + ls2 * K
+    F = U @ scipy.linalg.lstsq(A, R)[0]
+    sc = np.abs(F).max()
+    C_eh, w, keep = _minnorm_ref(A, R)
+    floor = np.abs(U @ C_eh - F).max() / sc
+    kd, kj = _k("float64"), _k("float64")
+    C0, info0, e0 = _run_minnorm(kd, G, K, ls2, R, method="deflated")
+    C1, info1, e1 = _run_minnorm(kd, G, K, ls2, R, method="deflated", rank_hint=int(e0[6]))
+    J0, _, f0 = _run_minnorm(kj, G, K, ls2, R, method="lowrank")
+    J1, _, f1 = _run_minnorm(kj, G, K, ls2, R, method="lowrank", rank_hint=int(f0[6]))
+    d0, d1 = np.abs(U @ (C0 - J0)).max() / sc, np.abs(U @ (C1 - J1)).max() / sc
+    print(f"m={m}: factor rank {int(e0[6])} / hinted {int(e1[6])}, kept {int(e0[1])} / {int(e1[1])} (eigh {int(keep.sum())}), blocks "
+          f"{int(e0[7])} / {int(e1[7])}, block sweeps {e0[0]} / {e1[0]}; floor {floor:.2e}, deflated vs lstsq "
+          f"{np.abs(U @ C1 - F).max() / sc:.2e}, vs the Jacobi path {d0:.2e} / {d1:.2e}; lambda_max rel err cold "
+          f"{abs(e0[2] / w.max() - 1):.1e} warm {abs(e1[2] / w.max() - 1):.1e}")
+    assert info0 == 0 and info1 == 0
+    assert 128 <= int(e0[6]) < 512 and int(e0[7]) == 64 and int(e1[7]) == 64
+    assert e0[0] == 1.0 and e1[0] == 1.0                      # the whole Rayleigh-Ritz diagonalisation in one launch
+    # the hinted call took the DIRECT form when the first factor kept all m columns (one Cholesky of the permuted matrix with
+    # its inverse riding along instead of pivoted factor + L^T L + its Cholesky): same answer as the factor form of the same
+    # two calls (developer option lr_no_direct), reuse on another right-hand side included
+    from spateo_amd import _lib
+
+    kf = _k("float64")
+    old = _lib.debug_option("lr_no_direct", 1)
+    try:
+        F0, _, g0 = _run_minnorm(kf, G, K, ls2, R, method="deflated")
+        F1, _, g1, F1b = _run_minnorm(kf, G, K, ls2, R, method="deflated", rank_hint=int(g0[6]), reuse_R=R[:, :2] * 2.0)
+    finally:
+        _lib.debug_option("lr_no_direct", old)
+    C1r, _, e1r, C1b = _run_minnorm(kd, G, K, ls2, R, method="deflated", rank_hint=int(e1[6]), reuse_R=R[:, :2] * 2.0)
+    dd = np.abs(U @ (C1r - F1)).max() / sc
+    print(f"    direct form ({'taken' if int(e0[6]) == m else 'not applicable: factor rank < m'}) vs factor form on the hinted "
+          f"call: {dd:.2e}; kept {int(e1r[1])} vs {int(g1[1])}")
+    assert int(e1r[1]) == int(g1[1]) and int(e1r[6]) == int(g1[6]) and dd < max(0.1 * floor, 1e-7)
+    assert _relmax(C1b, 2.0 * C1r[:, :2]) < 1e-11 and _relmax(F1b, 2.0 * F1[:, :2]) < 1e-11
+    assert np.abs(U @ (C1r - C1)).max() / sc < max(0.1 * floor, 1e-7)   # third call (same order, warm state) = second call
+    assert int(e0[1]) == int(f0[1]) and int(e1[1]) == int(f1[1]) and abs(int(e1[1]) - int(keep.sum())) <= max(2, m // 50)
+    assert np.abs(U @ C1 - F).max() / sc < max(2.0 * floor, 1e-9) and np.abs(U @ C0 - F).max() / sc < max(2.0 * floor, 1e-9)
+    assert d0 < max(0.1 * floor, 1e-7) and d1 < max(0.1 * floor, 1e-7)
+    np.testing.assert_allclose(e0[2], w.max(), rtol=1e-6)
+    np.testing.assert_allclose(e1[2], w.max(), rtol=1e-6)
+    np.testing.assert_allclose(f1[2], w.max(), rtol=1e-6)     # the Jacobi path's hinted call is warm-started too
 
 
 def test_deflated_solve_falls_back_when_the_block_is_too_small(st):
