@@ -58,6 +58,64 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def measured_traffic(cells, ctrl, dtype, lambda_, timeout_s=300):
+    """HBM bytes per tile stage (= per EM iteration) of the dominant kernel, MEASURED IN THIS RUN: two child processes of
+    this script (`--traffic-child`: the same workload, two EM iterations, jitter-Cholesky solve so that the eigensolver's
+    launches do not slow the counter collection) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (one counter group
+    per pass, --kernel-trace only), summed over the launches of gram_cached_kernel and divided by the iterations.
+    Corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: the counters are in KB; FETCH_SIZE reports
+    half the bytes of wide coalesced streaming reads (x 2); WRITE_SIZE as reported.  None if rocprofv3 is unavailable or a
+    pass fails (the caller then falls back to the committed profile and says so)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    iters = 2
+    got = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k_, None)
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="mvf_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", tmp, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--traffic-child", str(iters), "--cells", str(cells), "--ctrl", str(ctrl),
+                   "--dtype", dtype, "--lambda_", str(lambda_)]
+            t0 = time.perf_counter()
+            pr = subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL,
+                                stderr=subprocess.PIPE, text=True)
+            dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
+            if pr.returncode != 0 or not dbs:
+                log(f"[bench] PMC pass {ctr} failed (rc {pr.returncode}): {pr.stderr[-400:]}")
+                return None
+            con = sqlite3.connect(dbs[0])
+            row = con.execute("select count(distinct dispatch_id), sum(value) from counters_collection where kernel_name "
+                              "like '%gram_cached_kernel%' and counter_name = ?", (ctr,)).fetchone()
+            con.close()
+            if not row or not row[0]:
+                log(f"[bench] PMC pass {ctr}: no gram_cached_kernel rows")
+                return None
+            got[ctr] = {"launches": int(row[0]), "raw_kb": float(row[1]), "pass_s": time.perf_counter() - t0}
+        except Exception as exc:  # noqa: BLE001 - never let the counter pass take the bench line down
+            log(f"[bench] PMC pass {ctr} failed: {exc!r}")
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    fetch = got["FETCH_SIZE"]["raw_kb"] * 1024.0 * 2.0 / iters
+    write = got["WRITE_SIZE"]["raw_kb"] * 1024.0 / iters
+    return {"bytes": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
+            "launches_per_iteration": got["FETCH_SIZE"]["launches"] / iters,
+            "pass_seconds": [got["FETCH_SIZE"]["pass_s"], got["WRITE_SIZE"]["pass_s"]],
+            "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace "
+                      "only) over child processes running the same workload; counters in KB, FETCH_SIZE x 2 (gfx950: half "
+                      "the bytes of wide streaming reads are tallied), summed over the tile-stage launches of one EM iteration"}
+
+
 def _eigh_solver(lhs, rhs, method=None):
     """The reference's solve with its LAPACK driver swapped for a mathematically identical one (truncated symmetric
     eigendecomposition, same eps * max|lambda| cut-off as gelsd): oracle-vs-oracle deviation = the reference noise floor."""
@@ -232,6 +290,9 @@ def main():
     ap.add_argument("--collective", default="torch", choices=["torch", "mvf"],
                     help="who issues the step's all-reduces: torch.distributed (RCCL under the nccl backend) or "
                          "mvf_allreduce_stats of the C ABI on the engine's own RCCL communicator")
+    ap.add_argument("--no-measure-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child passes (roofline.traffic then comes from the committed profile)")
+    ap.add_argument("--traffic-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-whole-fit", action="store_true", help="skip the whole-call (host arrays in, host dict out) timings")
     ap.add_argument("--no-rccl-world1", action="store_true",
                     help="skip the extra N = 1 runs that execute the step's collectives on a one-rank RCCL communicator")
@@ -276,6 +337,20 @@ def main():
     from spateo_amd._kernels import HipKernels
     from spateo_amd._synthetic import make_config
     from spateo_amd.vectorfield import SparseVFCEngine, shard_bounds, sparsevfc_preprocess
+
+    # ---------------------------------------------------------------- counter-pass child (see measured_traffic)
+    if args.traffic_child > 0:
+        Xc, Vc, _ = make_config("C4", N=args.cells)
+        _, Xcv, Ycv, _, ctrl_c, beta_c = sparsevfc_preprocess(Xc, Vc, M=args.ctrl, seed=0)
+        eng_c = SparseVFCEngine(Xcv, Ycv, ctrl_c, beta_c, dtype=args.dtype, device=device,
+                                cache_u={"auto": "auto", "on": True, "off": False}[args.cache_u])
+        eng_c.lstsq_method = "cholesky"
+        eng_c.init_state(gamma=0.9)
+        for _ in range(args.traffic_child):
+            eng_c.em_step(a=5.0, lambda_=args.lambda_, minP=1e-5, theta=0.75)
+        torch.cuda.synchronize()
+        os.close(real_stdout)
+        return
 
     # ---------------------------------------------------------------- synthetic workload (same on every rank)
     t0 = time.perf_counter()
@@ -683,8 +758,14 @@ def main():
                 return h_
 
             eng._solve_all = timed
-            for _ in range(4):
+            # warm-up: at least 4 iterations AND 0.4 s of them.  The solve at M = 500 is a chain of ~100 single-workgroup
+            # launches: too little load to pull the GPU's clocks up by itself, so right after a host-bound stretch of this
+            # script it ran 2 x slower for its first ~100 ms (measured: 4.5 ms / iteration behind the evaluator section,
+            # 2.3 ms behind a Gram-heavy one) - the steady state is what this object reports
+            t_w, n_w = time.perf_counter(), 0
+            while n_w < 4 or time.perf_counter() - t_w < 0.4:
                 eng.em_step(**step_kw)
+                n_w += 1
             evs.clear()
             torch.cuda.synchronize()
             t_s = time.perf_counter()
@@ -700,8 +781,8 @@ def main():
             eng.k.drop_ublk()
             return rec
 
-        out["small_configs"] = {"note": "BASELINE configs 2 and 5 at their stated sizes, one EM iteration (steady state, "
-                                        "30 timed after 4 warm-up), lambda_ as the headline",
+        out["small_configs"] = {"note": "BASELINE configs 2 and 5 at their stated sizes, one EM iteration (steady state: "
+                                        "30 timed after >= 0.4 s of warm-up iterations), lambda_ as the headline",
                                 "c2_50k_x_500": small("C2", 50_000, 500, 2),
                                 "c5_organ_250k_x_500": small("C2", 250_000, 500, 100)}
 
@@ -737,6 +818,19 @@ def main():
                             "c4": whole(X, V, M, 4)}
         del X2, V2
     del X, V
+
+    # ---------------------------------------------------------------- HBM traffic of the dominant kernel, measured (N = 1)
+    if rank == 0 and world == 1 and not args.no_measure_traffic and args.gram_mode == "full" and not args.force_collectives:
+        torch.cuda.empty_cache()
+        mt = measured_traffic(N, Mc, args.dtype, args.lambda_)
+        if mt is not None:
+            rl = out["roofline"]
+            rl["traffic_committed_profile"] = rl.get("traffic")
+            rl["traffic"] = mt["bytes"]
+            rl["traffic_source"] = mt["source"]
+            rl["traffic_from_committed_profile"] = False
+            rl["traffic_detail"] = {k_: mt[k_] for k_ in ("fetch_bytes", "write_bytes", "launches_per_iteration", "pass_seconds")}
+            rl["traffic_over_algorithmic_bytes"] = mt["bytes"] / (2.0 * (4 if args.dtype == "float32" else 8) * N * Mc)
 
     # ---------------------------------------------------------------- CPU baseline (N = 1, rank 0, bounded sample)
     if rank == 0 and world == 1 and args.cpu_cells > 0:

@@ -1250,6 +1250,9 @@ def SparseVFC(
         "grid_V": grid_V,
         "iteration": i - 1,
         "tecr_traj": tecr_vec[:i],
+        # the same vector under the name Spateo's docstring gives it (sparsevfc.py:155, :301 "tecr_vec"); dynamo's dict key is
+        # believed to be "tecr_traj" (SURVEY.md App. A [VERIFY]): a consumer of either name finds it
+        "tecr_vec": tecr_vec[:i],
         "E_traj": E_vec[:i],
     }
 

@@ -29,6 +29,10 @@ def test_bench_line_contract():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert 0.0 < r["frac"] < 1.0 and "traffic" in r and r["avg_kernel_ms"] * 0.999 <= d["ms_per_step"]
+    # HBM traffic of the dominant kernel measured in the run itself (two rocprofv3 --pmc child passes), not read from a file
+    assert r["traffic_from_committed_profile"] is False and r["traffic"] > 0 and "measured in this run" in r["traffic_source"]
+    alg = 2.0 * 4 * d["config"]["cells"] * d["config"]["ctrl_points"]
+    assert 0.3 * alg < r["traffic"] < 60.0 * alg and r["traffic_detail"]["launches_per_iteration"] >= 1
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "cells/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     par = d["parity"]
@@ -40,6 +44,12 @@ def test_bench_line_contract():
     ev = d["eval"]
     assert ev["grid_points"] == 64**3 and ev["float32"]["kernel_ms_all_quantities"] < 5.0
     assert ev["float64"]["jacobian_plus_curl_api_wall_ms"] < 100.0
+    sc = d["small_configs"]
+    assert sc["c2_50k_x_500"]["ms_per_em_step"] < 4.0 and sc["c5_organ_250k_x_500"]["ms_per_em_step"] < 6.0
+    wf = d["whole_fit"]
+    for cfg in ("c2", "c4"):
+        split = wf[cfg]["split_of_a_second_call_with_phase_syncs"]
+        assert set(split) >= {"preprocess_s", "upload_and_u_cache_s", "em_s", "download_s", "total_s"} and wf[cfg]["wall_s"] > 0
     pv = d["pivot_subset"]
     assert pv["value"] > 0 and pv["ctrl_used"] <= 1100 and "NOT" in pv["note"].upper()
     # the step's collectives executed on a one-rank RCCL communicator through both back ends

@@ -75,7 +75,8 @@ def test_sparsevfc_end_to_end_well_regularised(st, dtype):
     got = st.SparseVFC(X, V, Grid, dtype=dtype, device="cuda:0", **kw)
     tol = TOL[dtype]
     assert got["iteration"] == ref["iteration"]
-    assert set(got.keys()) == set(ref.keys())
+    assert set(got.keys()) == set(ref.keys()) | {"tecr_vec"}  # + the docstring's name of tecr_traj (sparsevfc.py:155)
+    np.testing.assert_array_equal(got["tecr_vec"], got["tecr_traj"])
     for key in ("X", "Y", "valid_ind", "X_ctrl", "ctrl_idx", "grid"):
         np.testing.assert_array_equal(got[key], ref[key])
     assert got["beta"] == pytest.approx(ref["beta"], rel=1e-12)
