@@ -1231,8 +1231,8 @@ def SparseVFC(
         extra["row_range"] = (0, N) if (gather == "all" or rank == 0) else (first, first + eng.shard_sizes[rank])
     vfc_index = np.where(P > theta)[0]
     ph.mark("download_s")
-    ph.out["em_iterations"] = int(i)
     ph.done()
+    ph.out["em_iterations"] = int(i)
     return {
         **extra,
         "X": X_ori,

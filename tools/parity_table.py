@@ -17,7 +17,8 @@ for line in open(sys.argv[1], errors="replace"):
     cells = {}
     for q, gpu, floor, ratio in re.findall(r"(\w+) gpu ([\d.e+-]+) / floor ([\d.e+-]+) \(x([\d.]+)", rest):
         cells[q] = (gpu, floor, ratio)
-    rows.append((case, dtype, cells))
+    if cells:
+        rows.append((case, dtype, cells))
 cols = ["V", "hull", "grid12", "grid", "sigma2", "P999", "P", "E"]
 print("Asserted at 1.25 x floor: V, hull, grid12 (grid within 1.2 hull radii), sigma2, P999 (99.9th percentile of |dP|), E. "
       "Reported only: grid (whole bounding box), P (max |dP|) where P999 is present.\n")
