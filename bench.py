@@ -58,7 +58,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def measured_traffic(cells, ctrl, dtype, lambda_, timeout_s=300):
+def measured_traffic(cells, ctrl, dtype, lambda_, timeout_s=150):
     """HBM bytes per tile stage (= per EM iteration) of the dominant kernel, MEASURED IN THIS RUN: two child processes of
     this script (`--traffic-child`: the same workload, two EM iterations, jitter-Cholesky solve so that the eigensolver's
     launches do not slow the counter collection) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (one counter group
@@ -74,6 +74,10 @@ def measured_traffic(cells, ctrl, dtype, lambda_, timeout_s=300):
 
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
+        return None
+    # this process is itself running under a profiler / tool library: a nested counter pass would inherit it - skip
+    if os.environ.get("HSA_TOOLS_LIB") or any(k_.startswith(("ROCPROF", "ROCPROFILER", "ROCP_")) for k_ in os.environ):
+        log("[bench] running under a profiler: no nested PMC passes (roofline.traffic from the committed profile)")
         return None
     iters = 2
     got = {}
