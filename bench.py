@@ -479,8 +479,8 @@ def main():
             "solve": {
                 "lstsq_method": eng.lstsq_method,
                 "path": (("minimum-norm (pivoted-Cholesky factor of rank r; the invariant subspace below the eps*lambda_max "
-                          "cut-off from block inverse iteration on 256 vectors, deflated solve; jacobi_sweeps = the "
-                          "256 x 256 Rayleigh-Ritz problem's)") if eng.mn_method == "deflated" else
+                          "cut-off from block inverse iteration on 128 / 256 vectors (solve.block), three applications, deflated "
+                          "solve; jacobi_sweeps = the block's Rayleigh-Ritz problem's)") if eng.mn_method == "deflated" else
                          ("minimum-norm (pivoted-Cholesky factor of rank r + one-sided block Jacobi on its r columns, "
                           "eps*lambda_max cut-off)") if eng.mn_method == "lowrank" else
                          "minimum-norm (Cholesky + one-sided block Jacobi eigensolver, eps*lambda_max cut-off)")
@@ -852,12 +852,12 @@ def main():
 
     if distributed:
         dist.barrier()
-    if dist.is_initialized():
-        dist.destroy_process_group()
     sys.stdout.flush()
-    if rank == 0:
+    if rank == 0:  # the line goes out BEFORE the process group is torn down: a hang in the teardown cannot lose it
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     os.close(real_stdout)
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -20,7 +20,11 @@ PARITY STATUS
 * ``con_K`` (both code paths) is pinned against the real in-tree twin
   ``spateo/tdr/morphometrics/morphofield/gaussian_process.py:16-36`` executed in the build container
   (``tests/golden/make_golden.py`` -> ``tests/golden/ref_twins.npz``).
-* The EM loop itself (``SparseVFC``, ``get_P``, ``lstsq_solver``, ``bandwidth_selector``, ``sample_by_velocity``) is
+* ``sample_by_velocity`` (the control-point draw) is pinned against the real in-tree copy of dynamo's sampling module,
+  ``spateo/alignment/methods/sampling.py:225-241`` (``tests/golden/make_golden_sampling.py`` -> ``ref_sampling.npz``; found in
+  round 5 - SURVEY.md lists the function as out of tree): indices bit for bit, its self-re-seeding with 19491001, and the
+  state it leaves NumPy's global generator in.
+* The EM loop itself (``SparseVFC``, ``get_P``, ``lstsq_solver``, ``bandwidth_selector``) is
   **parity unpinned**: the reference holds no test, golden vector or source for it.  It is
   pinned only by analytic known-answer tests and cross-formulation checks in ``tests/test_oracle.py``.
 """
@@ -119,8 +123,12 @@ def bandwidth_selector(X):
 def sample_by_velocity(V, n, seed=19491001):
     """dynamo ``tools.sampling.sample_by_velocity``: velocity-magnitude weighted sampling without replacement.
 
-    [VERIFY, SURVEY.md Appendix A step 2] dynamo's function carries its own ``seed=19491001`` default and re-seeds the
-    global RNG, which makes the result independent of ``SparseVFC(seed=...)``; restated as recalled."""
+    Follows the in-tree copy ``spateo/alignment/methods/sampling.py:225-241`` (Spateo vendors dynamo's ``tools/sampling.py``
+    for its alignment module) statement by statement and is pinned against outputs of that real function
+    (``tests/test_oracle.py::test_sample_by_velocity_matches_the_in_tree_copy_of_dynamos_sampling_module``): the function
+    carries its own ``seed=19491001`` default and re-seeds the global RNG - SURVEY.md Appendix A step 2's [VERIFY] item,
+    confirmed.  What stays unverified is dynamo's CALL (``sample_by_velocity(Y[uid], M)`` without ``seed=``), on which the
+    independence of ``SparseVFC(seed=...)`` rests."""
     np.random.seed(seed)
     tmp_V = np.linalg.norm(V, axis=1)
     p = tmp_V / np.sum(tmp_V)

@@ -170,7 +170,8 @@ _RNG_LOCK = __import__("threading").Lock()
 
 
 def sample_by_velocity(V: np.ndarray, n: int, seed: int = 19491001) -> np.ndarray:
-    """dynamo ``sample_by_velocity``: |V|-weighted sampling without replacement.  dynamo re-seeds NumPy's GLOBAL RNG
+    """dynamo ``sample_by_velocity`` (in-tree copy: ``spateo/alignment/methods/sampling.py:225-241``; pinned against outputs of
+    that real function, tests/golden/ref_sampling.npz): |V|-weighted sampling without replacement.  dynamo re-seeds NumPy's GLOBAL RNG
     (``np.random.seed(seed)``) and draws from it; here the draw comes from a private ``RandomState(seed)`` - the same
     MT19937 stream, so the same indices - and the global RNG is then left in the state dynamo would leave it in, so
     concurrent fits (``SparseVFC_many``) cannot interleave their draws."""

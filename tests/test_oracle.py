@@ -344,3 +344,58 @@ def test_the_reference_noise_floor_is_not_a_builder_artifact():
         floor = max(dev["eigh"][q], dev["sumorder"][q])
         assert dev["gelss"][q] > 1e-7                      # LAPACK's own driver swap moves the reference visibly
         assert 0.2 < floor / dev["gelss"][q] < 5.0, (q, floor, dev["gelss"][q])   # the asserted floor measures the same thing
+
+
+# ------------------------------------------------------------------------------------------------ control-point draw: PINNED
+def _sampling_golden():
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_sampling.npz")
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_sample_by_velocity_matches_the_in_tree_copy_of_dynamos_sampling_module():
+    """``spateo/alignment/methods/sampling.py:225-241`` is Spateo's in-tree copy of dynamo's ``tools/sampling.py``; the
+    goldens (tests/golden/make_golden_sampling.py) are outputs of that REAL function.  The oracle's restatement and the
+    product's (private RandomState, global generator left as dynamo leaves it) reproduce the drawn indices bit for bit -
+    default seed (whatever the caller seeded just before), explicit seeds, zero-velocity rows, a draw of every row - and the
+    global generator's next numbers.  This pins the control-point draw of SparseVFC to reference
+    code, including the [VERIFY] item that the function re-seeds itself with 19491001."""
+    import spateo_amd.vectorfield as vfm
+
+    g = _sampling_golden()
+    tags = sorted({k.split("_")[0] for k in g})
+    assert tags == list("abcdefg")
+    for tag in tags:
+        V, n, seed = g[f"{tag}_V"], int(g[f"{tag}_n"]), int(g[f"{tag}_seed"])
+        for impl in (svo.sample_by_velocity, vfm.sample_by_velocity):
+            np.random.seed(999)  # must not matter
+            idx = impl(V, n) if seed < 0 else impl(V, n, seed=seed)
+            np.testing.assert_array_equal(idx, g[f"{tag}_idx"], err_msg=f"{impl.__module__} case {tag}")
+            np.testing.assert_array_equal(np.random.random(3), g[f"{tag}_next"])
+        assert len(set(g[f"{tag}_idx"].tolist())) == n  # without replacement
+    assert not np.any(np.linalg.norm(g["c_V"][g["c_idx"]], axis=1) == 0.0)
+    np.testing.assert_array_equal(np.sort(g["d_idx"]), np.arange(64))
+    assert not np.array_equal(g["a_idx"], g["e_idx"]) and not np.array_equal(g["e_idx"], g["f_idx"])
+
+
+def test_control_points_of_the_preprocessing_are_the_reference_draw():
+    """The product's preprocessing takes the row norms BEFORE the gather into sorted-unique order (one double per row instead
+    of a row): the same values in the same order as ``sample_by_velocity(Y[uid], M)`` - checked against the golden draw of the
+    real function on exactly that array."""
+    import spateo_amd.vectorfield as vfm
+
+    g = _sampling_golden()
+    Y = g["a_V"]
+    X = np.random.default_rng(5).standard_normal((len(Y), 3))      # distinct rows: uid is a permutation
+    tmp_X, uid = np.unique(X, axis=0, return_index=True)
+    inv = np.empty_like(uid)
+    inv[uid] = np.arange(len(uid))
+    Yp = Y[inv]                                                   # so that Yp[uid] == Y: the golden's array
+    np.testing.assert_array_equal(Yp[uid], Y)
+    for mod in (vfm, svo):
+        fn = getattr(mod, "sparsevfc_preprocess", None) or mod.sparsevfc_setup
+        valid, Xv, Yv, idx, ctrl, beta = fn(X, Yp, M=100, seed=7)
+        np.testing.assert_array_equal(idx, g["a_idx"])
+        np.testing.assert_array_equal(ctrl, tmp_X[g["a_idx"]])
