@@ -1924,6 +1924,20 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         double *Wsel = (double*)(dw + d.wsel), *Gb = (double*)(dw + d.g), *H = (double*)(dw + d.h), *Yh = (double*)(dw + d.yh);
         double *theta = (double*)(dw + d.theta), *dummy = (double*)(dw + d.dummy);
         double* Minv = S;
+        // what the previous call left (64 bytes; the stream is idle behind the power iteration's few launches by now): a
+        // workspace without a finished factorisation of all m columns skips this form at once, and a previous DIRECT call
+        // lets the block iteration continue from its converged block
+        PcholState hprev;
+        MVF_CHECK_HIP(hipMemcpyAsync(&hprev, stt, sizeof(hprev), hipMemcpyDeviceToHost, st));
+        MVF_CHECK_HIP(hipStreamSynchronize(st));
+        if (!(hprev.magic == PCHOL_MAGIC && hprev.order_len == (int)m)) {
+            if (timing)
+                for (auto& e : ev) (void)hipEventDestroy(e);
+            return lr_solve(G, K, lambda_sigma2, tolf, rcond, R, m, nrhs, C, info, einfo, max_sweeps, reuse, rank_hint, workspace,
+                            workspace_bytes, stream, deflate, false);
+        }
+        const bool prev_direct = hprev.defl == 2 && hprev.pad4 == 1 && hprev.defl_block == b &&
+                                 debug_opt(DBG_DEFL_APPS) == 0;  // (defl_apps set: the cold three-application plan, for A/B)
         hipLaunchKernelGGL(direct_prepare_kernel, dim3(1), dim3(256), 0, st, S, m, mp, tolf, stt, info, dflag);
         hipLaunchKernelGGL(perm_gather_kernel, dim3((unsigned)cdiv(rp, 256), (unsigned)rp), dim3(256), 0, st, S, mp, order, m, rp,
                            dflag, Ap);
@@ -1941,9 +1955,13 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         };
         // block inverse iteration from the unit vectors of the b smallest pivots, three applications of A_perm^-1 = E E^T -
         // applied factor by factor (Z E, then (Z E) E^T): the product E E^T is never formed
-        gemm<false, true>(st, E + (m - b) * rp, rp, E, rp, Zb, rp, b, rp, rp);  // rows m-b .. m-1 of E E^T
-        if (int rc = orthonormalise(Zb, Za)) return rc;
-        for (int ap = 1; ap < 3; ++ap) {
+        // When the previous call on this workspace was answered by this very form, its converged block is still in Za (same
+        // pivot order, a nearby matrix): ONE application from there replaces the three from the unit vectors.
+        if (!prev_direct) {
+            gemm<false, true>(st, E + (m - b) * rp, rp, E, rp, Zb, rp, b, rp, rp);  // rows m-b .. m-1 of E E^T
+            if (int rc = orthonormalise(Zb, Za)) return rc;
+        }
+        for (int ap = prev_direct ? 2 : 1; ap < 3; ++ap) {
             gemm<false, false>(st, Za, rp, E, rp, Wsel, rp, b, rp, rp);
             gemm<false, true>(st, Wsel, rp, E, rp, Zb, rp, b, rp, rp);
             if (int rc = orthonormalise(Zb, Za)) return rc;
