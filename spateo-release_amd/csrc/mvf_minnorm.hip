@@ -1410,6 +1410,39 @@ __global__ __launch_bounds__(256) void tril_and_transpose_kernel(const double* _
     Et[i * n + j] = E[j * n + i];
 }
 
+// rep[0..5] = einfo[0..5], rep[6] = info, rep[7] = the state flag, rep[8..10] = lambda_max estimate, the one before, max diagonal
+__global__ void direct_report_kernel(const double* __restrict__ einfo, const int* __restrict__ info,
+                                     const int* __restrict__ dflag, const PcholState* __restrict__ stt,
+                                     double* __restrict__ rep) {
+    const int t = threadIdx.x;
+    if (t < 6) rep[t] = einfo[t];
+    if (t == 6) rep[6] = (double)info[0];
+    if (t == 7) rep[7] = (double)dflag[0];
+    if (t == 8) rep[8] = stt->lmax_est;
+    if (t == 9) rep[9] = stt->lmax_prev;
+    if (t == 10) rep[10] = stt->maxdiag;
+}
+
+// the closing state of a direct-form call: a finished factorisation of all m columns in the unchanged pivot order, defl = 2
+// (this form), the block size, pad4 = 1 (block and Rayleigh-Ritz rotation are this call's complete ones) and the count of
+// deflated directions; einfo[0] = Rayleigh-Ritz launches, [4] = 0 (no shift), [6] = r = m, [7] = block
+__global__ void direct_finish_kernel(PcholState* __restrict__ stt, double* __restrict__ einfo, int m, int b, int hsweeps) {
+    const int nsel = (int)einfo[4];
+    stt->done = 1;
+    stt->r = m;
+    stt->magic = PCHOL_MAGIC_V;
+    stt->order_len = m;
+    stt->keep_len = m;
+    stt->defl = 2;
+    stt->defl_block = b;
+    stt->pad4 = hsweeps == 1 ? 1 : 0;
+    stt->defl_nsel = nsel;
+    einfo[0] = (double)hsweeps;
+    einfo[4] = 0.0;
+    einfo[6] = (double)m;
+    einfo[7] = (double)b;
+}
+
 // T[i][0..8) = R[order[i]][0..nrhs) (zero padded), and back: C[order[i]][d] = T[i][d]
 __global__ __launch_bounds__(256) void perm_rows_kernel(const double* __restrict__ R, int nrhs, const int* __restrict__ order,
                                                         int64_t m, int64_t rp, const int* __restrict__ dflag,
@@ -2003,16 +2036,18 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         gemm<false, false>(st, Yh, b, Za, rp, Wsel, rp, b, rp, b);  // rows = the Ritz vectors to deflate (zero rows else)
         MVF_LAUNCH_CHECK();
         if (int rc = direct_apply(rp, b)) return rc;
-        double he[6] = {0, 0, 0, 0, 0, 0};
-        int hinfo2 = 0, hflag = 0;
-        PcholState hq;
-        MVF_CHECK_HIP(hipMemcpyAsync(he, einfo, sizeof(he), hipMemcpyDeviceToHost, st));
-        MVF_CHECK_HIP(hipMemcpyAsync(&hinfo2, info, sizeof(int), hipMemcpyDeviceToHost, st));
-        MVF_CHECK_HIP(hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
-        MVF_CHECK_HIP(hipMemcpyAsync(&hq, stt, sizeof(hq), hipMemcpyDeviceToHost, st));
+        // ONE device -> host copy decides (einfo[0..5], info, the state flag, the power iteration's last two quotients), and
+        // ONE launch writes the closing state + einfo: seven separate small copies used to cost 0.13 ms of this 1.5 ms call
+        double* rep = (double*)(ws + p.off_scal) + 16;  // 11 doubles of the 256-byte scalar slot (its first two are the shift's)
+        hipLaunchKernelGGL(direct_report_kernel, dim3(1), dim3(64), 0, st, einfo, info, dflag, stt, rep);
+        double hrep[11];
+        MVF_CHECK_HIP(hipMemcpyAsync(hrep, rep, sizeof(hrep), hipMemcpyDeviceToHost, st));
         MVF_CHECK_HIP(hipStreamSynchronize(st));
+        const double* he = hrep;
+        const int hinfo2 = (int)hrep[6], hflag = (int)hrep[7];
+        const double q_est = hrep[8], q_prev = hrep[9], q_maxdiag = hrep[10];
         // the cut-off needs a converged lambda_max: the warm power iteration's last two Rayleigh quotients must agree
-        const bool lmax_ok = std::fabs(hq.lmax_est - hq.lmax_prev) <= 1e-7 * hq.lmax_est || hq.lmax_est == hq.maxdiag;
+        const bool lmax_ok = std::fabs(q_est - q_prev) <= 1e-7 * q_est || q_est == q_maxdiag;
         const bool ok = hinfo2 == 0 && hflag == 1 && hrot2 == 0 && lmax_ok && he[4] <= (double)DEFL_TINY_ACCEPT &&
                         std::isfinite(he[5]) && he[5] > 0.0;
         if (timing) {
@@ -2020,21 +2055,16 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             MVF_CHECK_HIP(hipEventSynchronize(ev[3]));
             float t03 = 0;
             (void)hipEventElapsedTime(&t03, ev[0], ev[3]);
-            fprintf(stderr, "[mvf_solve_minnorm_lrd] m %lld direct form: %.2f ms (%d launch(es) of the 64 x 64 Rayleigh-Ritz, %d below the cut, info %d, state %d, lambda_max %s)%s\n",
-                    (long long)m, t03, hsweeps, (int)he[4], hinfo2, hflag, lmax_ok ? "converged" : "NOT converged",
-                    ok ? "" : " -> factor form");
+            fprintf(stderr, "[mvf_solve_minnorm_lrd] m %lld direct form: %.2f ms (%s block, %d launch(es) of the 64 x 64 Rayleigh-Ritz, %d below the cut, info %d, state %d, lambda_max %s)%s\n",
+                    (long long)m, t03, prev_direct ? "continued" : "fresh", hsweeps, (int)he[4], hinfo2, hflag,
+                    lmax_ok ? "converged" : "NOT converged", ok ? "" : " -> factor form");
             for (auto& e : ev) (void)hipEventDestroy(e);
         }
         if (ok) {
-            // the workspace now holds: the same pivot order (all m columns), their pivots, A_perm^-1 and the deflation vectors
-            const int head[2] = {1, (int)m};  // done, r
-            MVF_CHECK_HIP(hipMemcpyAsync(stt, head, sizeof(head), hipMemcpyHostToDevice, st));
-            // magic, order_len, keep_len, defl = 2, block, pad4 = the kept Rayleigh-Ritz rotation is this call's complete one, nsel
-            const int tag[7] = {PCHOL_MAGIC, (int)m, (int)m, 2, b, hsweeps == 1 ? 1 : 0, (int)he[4]};
-            MVF_CHECK_HIP(hipMemcpyAsync(&stt->magic, tag, sizeof(tag), hipMemcpyHostToDevice, st));
-            const double hsw[8] = {(double)hsweeps, he[1], he[2], he[3], 0.0, he[5], (double)m, (double)b};
-            MVF_CHECK_HIP(hipMemcpyAsync(einfo, hsw, sizeof(hsw), hipMemcpyHostToDevice, st));
-            MVF_CHECK_HIP(hipStreamSynchronize(st));
+            // the workspace now holds: the same pivot order (all m columns), their pivots, E = Rc^-T and its transpose, the block
+            // and the deflation vectors; stream-ordered, no further synchronisation (the caller's next copy sees it)
+            hipLaunchKernelGGL(direct_finish_kernel, dim3(1), dim3(1), 0, st, stt, einfo, (int)m, b, hsweeps);
+            MVF_LAUNCH_CHECK();
             return 0;
         }
         // anything else: the factor form answers (re-assembles S, which now holds the inverse)
