@@ -789,6 +789,24 @@ def main():
                                         "30 timed after >= 0.4 s of warm-up iterations), lambda_ as the headline",
                                 "c2_50k_x_500": small("C2", 50_000, 500, 2),
                                 "c5_organ_250k_x_500": small("C2", 250_000, 500, 100)}
+        # config 5 as it runs on one GPU of eight: 4 of the 32 organs, whole fits (host arrays in -> host dicts out, MaxIter 30,
+        # run to convergence), one organ per HIP stream (replicas only: no collective) against the same four one after the other
+        from spateo_amd.vectorfield import SparseVFC, SparseVFC_many
+
+        organs = [make_config("C2", N=250_000, seed=100 + s_)[:2] + (None,) for s_ in range(4)]
+        kw5 = dict(M=500, lambda_=args.lambda_, MaxIter=30, dtype=args.dtype, lstsq_method="scipy", device=device)
+        SparseVFC_many(organs, n_streams=4, **kw5)  # every thread's first-use costs (kernel objects, workspaces, streams)
+        t_5 = time.perf_counter()
+        res5 = SparseVFC_many(organs, n_streams=4, **kw5)
+        t_par = time.perf_counter() - t_5
+        t_5 = time.perf_counter()
+        seq5 = [SparseVFC(*o_, **kw5) for o_ in organs]
+        t_seq = time.perf_counter() - t_5
+        out["small_configs"]["c5_four_organs"] = {
+            "organs": 4, "cells_each": 250_000, "ctrl": 500, "iterations": [int(r_["iteration"]) + 1 for r_ in res5],
+            "four_streams_wall_s": t_par, "sequential_wall_s": t_seq,
+            "identical_to_sequential": bool(all(np.array_equal(a_["V"], b_["V"]) for a_, b_ in zip(res5, seq5)))}
+        del organs, res5, seq5
 
     # ---------------------------------------------------------------- whole calls: host arrays in -> host dict out (N = 1)
     if rank == 0 and world == 1 and not args.no_whole_fit:

@@ -140,3 +140,32 @@ def test_developer_options_are_an_explicit_call_not_the_environment(monkeypatch)
     assert lib.mvf_debug_option(b"no_such_option", 1) != 0 and b"unknown option" in lib.mvf_last_error()
     assert lib.mvf_debug_option_get(b"no_such_option") == -1
     assert not _lib.DEV_KNOBS and _lib.LIB_PATH.endswith(os.path.join("spateo_amd", "lib", "libmvf.so"))
+
+
+def test_communicator_entry_points_report_misuse_without_a_gpu():
+    """SURVEY 8(b)'s communicator entry points (ABI 5): libmvf.so links librccl, loads without a GPU, hands out a unique id,
+    and reports misuse through the int status + mvf_last_error channel (nothing is launched, no communicator is created)."""
+    from spateo_amd import _lib
+
+    lib = _lib.load()
+    text = open(HEADER).read()
+    assert int(re.search(r"#define MVF_COMM_ID_BYTES (\d+)", text).group(1)) == _lib.MVF_COMM_ID_BYTES == 128
+    assert re.search(r"MVF_RED_SUM = 0, MVF_RED_MIN = 1", text) and (_lib.RED_SUM, _lib.RED_MIN) == (0, 1)
+    buf = ctypes.create_string_buffer(_lib.MVF_COMM_ID_BYTES)
+    assert lib.mvf_comm_unique_id(buf) == 0 and any(buf.raw)
+    assert lib.mvf_comm_unique_id(None) != 0 and b"null pointer" in lib.mvf_last_error()
+    h = ctypes.c_void_p(None)
+    assert lib.mvf_comm_create(ctypes.byref(h), 0, 0, buf) != 0 and b"rank" in lib.mvf_last_error()
+    assert lib.mvf_comm_create(ctypes.byref(h), 2, 5, buf) != 0 and h.value is None
+    assert lib.mvf_comm_create(None, 1, 0, buf) != 0 and lib.mvf_comm_create(ctypes.byref(h), 1, 0, None) != 0
+    assert lib.mvf_allreduce_stats(None, None, 4, _lib.RED_SUM, None) != 0 and b"null communicator" in lib.mvf_last_error()
+    assert lib.mvf_comm_info(None, None, None, None) != 0
+    assert lib.mvf_comm_destroy(None) == 0
+    if not torch.cuda.is_available():  # no device: creation fails in hipGetDevice, loudly, before RCCL is touched
+        assert lib.mvf_comm_create(ctypes.byref(h), 1, 0, buf) != 0 and h.value is None
+        assert b"hipGetDevice" in lib.mvf_last_error()
+    # the shared object really links RCCL (the collective is the library's, not a re-implementation)
+    import subprocess
+
+    out = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" in out and "libamdhip64" in out

@@ -46,6 +46,7 @@ def test_bench_line_contract():
     assert ev["float64"]["jacobian_plus_curl_api_wall_ms"] < 100.0
     sc = d["small_configs"]
     assert sc["c2_50k_x_500"]["ms_per_em_step"] < 4.0 and sc["c5_organ_250k_x_500"]["ms_per_em_step"] < 6.0
+    assert sc["c5_four_organs"]["identical_to_sequential"] is True and sc["c5_four_organs"]["four_streams_wall_s"] > 0
     wf = d["whole_fit"]
     for cfg in ("c2", "c4"):
         split = wf[cfg]["split_of_a_second_call_with_phase_syncs"]
