@@ -249,7 +249,18 @@ int mvf_solve_minnorm_lr(const double* G, const double* K, double lambda_sigma2,
  * path and returns its result.  Measured at m = 3000 in the EM's steady state (r = 869): 6.7 ms against 22.9 ms, the field
  * within 1e-6 of the Jacobi path's on the same factor.  The workspace is larger (the r x r scratch); mvf_pinv_diag does not
  * accept a workspace left by this call (it needs every eigenpair): use mvf_solve_minnorm_lr for that.  No reference
- * interface changes: this is how `lstsq_solver(lhs, rhs, "scipy")` is evaluated. */
+ * interface changes: this is how `lstsq_solver(lhs, rhs, "scipy")` is evaluated.
+ * Direct form (ABI 5; m <= 640, rank_hint == m, i.e. the previous call on this workspace kept ALL m columns - what m = 500
+ * control points give): the pivoted factorisation of the next matrix in that order is an ordinary Cholesky of the permuted
+ * matrix, A_perm = Rc Rc^T, and the blocked factorisation with the identity riding along yields E = Rc^-T in the same pass;
+ * block inverse iteration on 64 vectors (continued from the previous call's block when that call had this form), Rayleigh-Ritz
+ * through the factor (H = (Z Rc)(Z Rc)^T, one 64 x 64 Jacobi tile diagonalised in one launch), and
+ *     C = Pi^T Pc E E^T Pc Pi R
+ * with the inverse applied as its two triangular factors (the product E E^T would lose the factor's grading: 3 - 4 digits of
+ * the field).  Accepted only if every pivot clears tolf * eps * lambda_max, lambda_max has converged and at most 40 Ritz values
+ * lie below the cut; anything else re-runs the call in the factor form above.  The workspace then holds the unchanged pivot
+ * order (mvf_lr_pivot_order works), einfo[0] = Rayleigh-Ritz launches (1), einfo[6] = m, einfo[7] = 64; reuse works.  Measured
+ * at m = 500: 1.5 ms against 2.5 ms for the factor form and 3.6 ms for mvf_solve_minnorm. */
 size_t mvf_solve_minnorm_lrd_workspace_bytes(int64_t m, int nrhs);
 int mvf_solve_minnorm_lrd(const double* G, const double* K, double lambda_sigma2, double tolf, double rcond,
                           const double* R, int64_t m, int nrhs, double* C, int* info, double* einfo, int max_sweeps,
