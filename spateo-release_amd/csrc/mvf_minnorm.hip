@@ -1971,6 +1971,16 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         }
         const bool prev_direct = hprev.defl == 2 && hprev.pad4 == 1 && hprev.defl_block == b &&
                                  debug_opt(DBG_DEFL_APPS) == 0;  // (defl_apps set: the cold three-application plan, for A/B)
+        // (the same copy carries THIS call's power iteration: early in a fit the matrix still moves a lot between two calls -
+        // sigma^2 falls by an order of magnitude - and five warm steps may not have settled the Rayleigh quotient; eight more,
+        // 13 in all as on the cold path, cost 50 us where a failed attempt of this form costs 1.9 ms)
+        if (!(std::fabs(hprev.lmax_est - hprev.lmax_prev) <= 1e-7 * hprev.lmax_est)) {
+            for (int it = 0; it < 8; ++it) {
+                hipLaunchKernelGGL(lr_symv_kernel, dim3((unsigned)cdiv(mp, 4)), dim3(256), 0, st, S, mp, xv, xv + mp);
+                hipLaunchKernelGGL(lr_power_kernel, dim3(1), dim3(256), 0, st, xv, xv + mp, m, mp, 0, stt, (const double*)nullptr, 0,
+                                   it == 7 ? xkeep : (double*)nullptr);
+            }
+        }
         hipLaunchKernelGGL(direct_prepare_kernel, dim3(1), dim3(256), 0, st, S, m, mp, tolf, stt, info, dflag);
         hipLaunchKernelGGL(perm_gather_kernel, dim3((unsigned)cdiv(rp, 256), (unsigned)rp), dim3(256), 0, st, S, mp, order, m, rp,
                            dflag, Ap);
