@@ -457,7 +457,7 @@ class SparseVFCEngine:
         # round 5: factors of 128 .. 511 columns take a 64-vector block, and when the previous iteration's factor kept ALL M
         # columns (M <= 640: BASELINE configs 2 and 5) the call takes its direct form - one Cholesky of the permuted matrix with
         # the inverse factor riding along, block inverse iteration, a one-launch warm-started 64 x 64 Rayleigh-Ritz:
-        # M = 500: 1.83 / 3.6 ms (profiles/r05_small_m_probe.json); below 256 control points the full-width solve stays
+        # M = 500: 1.5 / 3.6 ms (profiles/r05_small_m_probe.json); below 256 control points the full-width solve stays
         self.mn_method = self.minnorm_method or ("deflated" if self.M >= DEFLATED_MIN_M else "full")
         self.rank_hint = 0
         # lstsq_method="cholesky" (extension, not a reference mode): jitter-escalated Cholesky, the round-1 solver
