@@ -336,7 +336,11 @@ def main():
         if one_dev:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+            try:  # eager communicator bound to this rank's GPU (what the one-rank runs of this code exercise)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+            except (TypeError, ValueError) as exc:  # a torch that does not take device_id: the lazy form
+                log(f"[bench rank {rank}] init_process_group(device_id=...) refused ({exc!r}); retrying without it")
+                dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from spateo_amd._kernels import HipKernels
     from spateo_amd._synthetic import make_config
