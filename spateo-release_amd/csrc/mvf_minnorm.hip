@@ -710,6 +710,7 @@ struct PcholState {
                                                     // keep_len: length of the kept dominant eigenvector (warm power iteration)
     int defl, defl_block, pad4, defl_nsel;      // defl = 1: the workspace holds the DEFLATED decomposition (mvf_solve_minnorm_lrd)
                                                 // of block size defl_block; defl_nsel: directions its last call deflated
+    int direct_skip, pad5, pad6, pad7;          // > 0: so many further calls skip the direct form (its last attempt failed)
 };
 
 // y = A x, one wave per row (the power iteration that estimates lambda_max for the stopping tolerance)
@@ -823,7 +824,10 @@ __global__ __launch_bounds__(256) void pchol_init_kernel(const double* __restric
         stt->hint_broken = !(use_hint && stt->magic == PCHOL_MAGIC && stt->order_len == hint_len);
         // a workspace without a finished factorisation of that length (fresh, foreign, other m) carries no deflation count
         // either: the deflated solve's block choice must be a function of the inputs, not of uninitialised memory
-        if (stt->hint_broken) stt->defl_nsel = 0;
+        if (stt->hint_broken) {
+            stt->defl_nsel = 0;
+            stt->direct_skip = 0;
+        }
         stt->magic = 0;
         stt->panel_nvalid = 0;
         stt->maxdiag = bc[1];
@@ -1437,6 +1441,7 @@ __global__ void direct_finish_kernel(PcholState* __restrict__ stt, double* __res
     stt->defl_block = b;
     stt->pad4 = hsweeps == 1 ? 1 : 0;
     stt->defl_nsel = nsel;
+    stt->direct_skip = 0;
     einfo[0] = (double)hsweeps;
     einfo[4] = 0.0;
     einfo[6] = (double)m;
@@ -1969,6 +1974,15 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             return lr_solve(G, K, lambda_sigma2, tolf, rcond, R, m, nrhs, C, info, einfo, max_sweeps, reuse, rank_hint, workspace,
                             workspace_bytes, stream, deflate, false);
         }
+        if (hprev.direct_skip > 0 && hprev.direct_skip <= 4) {  // a recent attempt of this form failed: not again just yet
+            const int left[1] = {hprev.direct_skip - 1};
+            MVF_CHECK_HIP(hipMemcpyAsync(&stt->direct_skip, left, sizeof(left), hipMemcpyHostToDevice, st));
+            MVF_CHECK_HIP(hipStreamSynchronize(st));
+            if (timing)
+                for (auto& e : ev) (void)hipEventDestroy(e);
+            return lr_solve(G, K, lambda_sigma2, tolf, rcond, R, m, nrhs, C, info, einfo, max_sweeps, reuse, rank_hint, workspace,
+                            workspace_bytes, stream, deflate, false);
+        }
         const bool prev_direct = hprev.defl == 2 && hprev.pad4 == 1 && hprev.defl_block == b &&
                                  debug_opt(DBG_DEFL_APPS) == 0;  // (defl_apps set: the cold three-application plan, for A/B)
         // (the same copy carries THIS call's power iteration: early in a fit the matrix still moves a lot between two calls -
@@ -2077,7 +2091,13 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             MVF_LAUNCH_CHECK();
             return 0;
         }
-        // anything else: the factor form answers (re-assembles S, which now holds the inverse)
+        // anything else: the factor form answers (re-assembles S, which now holds the inverse), and the next four calls on this
+        // workspace go to it directly - a system on which this form keeps failing must not pay for the attempt every time
+        {
+            const int skip[1] = {4};
+            MVF_CHECK_HIP(hipMemcpyAsync(&stt->direct_skip, skip, sizeof(skip), hipMemcpyHostToDevice, st));
+            MVF_CHECK_HIP(hipStreamSynchronize(st));
+        }
         return lr_solve(G, K, lambda_sigma2, tolf, rcond, R, m, nrhs, C, info, einfo, max_sweeps, reuse, rank_hint, workspace,
                         workspace_bytes, stream, deflate, false);
     }
