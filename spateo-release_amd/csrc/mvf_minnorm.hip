@@ -2072,8 +2072,11 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         const double q_est = hrep[8], q_prev = hrep[9], q_maxdiag = hrep[10];
         // the cut-off needs a converged lambda_max: the warm power iteration's last two Rayleigh quotients must agree
         const bool lmax_ok = std::fabs(q_est - q_prev) <= 1e-7 * q_est || q_est == q_maxdiag;
-        const bool ok = hinfo2 == 0 && hflag == 1 && hrot2 == 0 && lmax_ok && he[4] <= (double)DEFL_TINY_ACCEPT &&
-                        std::isfinite(he[5]) && he[5] > 0.0;
+        // (developer option direct_accept = v > 0: accept at most v - 1 deflated directions - forces the fall-back in tests)
+        const long long dacc = debug_opt(DBG_DIRECT_ACCEPT);
+        const double accept_n = dacc > 0 ? (double)(dacc - 1) : (double)DEFL_TINY_ACCEPT;
+        const bool ok = hinfo2 == 0 && hflag == 1 && hrot2 == 0 && lmax_ok && he[4] <= accept_n && std::isfinite(he[5]) &&
+                        he[5] > 0.0;
         if (timing) {
             MVF_CHECK_HIP(hipEventRecord(ev[3], st));
             MVF_CHECK_HIP(hipEventSynchronize(ev[3]));

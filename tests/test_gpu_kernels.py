@@ -530,6 +530,44 @@ def test_deflated_solve_small_factor_uses_a_64_vector_block(st, n, m):
     np.testing.assert_allclose(f1[2], w.max(), rtol=1e-6)     # the Jacobi path's hinted call is warm-started too
 
 
+def test_direct_form_falls_back_to_the_factor_form_and_cools_down(st):
+    """A direct-form attempt that is not accepted (forced here: developer option direct_accept = 1 accepts no deflated
+    direction, and this system truncates one) must re-run the call in the factor form - the answer is then the factor form's,
+    bit for bit - and leave the next four calls on the workspace to the factor form without another attempt; the fifth tries
+    again (and, with the option cleared, succeeds)."""
+    import time
+
+    from spateo_amd import _lib
+
+    U, G, K, R, ls2 = _kernel_system(50000, 500, s2=2.4e-3)
+    sc = np.abs(U @ np.linalg.lstsq(G + ls2 * K, R, rcond=None)[0]).max()
+    kf, kd = _k("float64"), _k("float64")
+    old = _lib.debug_option("lr_no_direct", 1)
+    try:
+        F, _, f0 = _run_minnorm(kf, G, K, ls2, R, method="deflated")
+        ref = []
+        for _ in range(7):
+            F, _, f0 = _run_minnorm(kf, G, K, ls2, R, method="deflated", rank_hint=int(f0[6]))
+            ref.append(F)
+    finally:
+        _lib.debug_option("lr_no_direct", old)
+    assert int(f0[6]) == 500 and int(f0[6]) - int(f0[1]) >= 1     # all columns kept, at least one direction truncated
+    C, _, e = _run_minnorm(kd, G, K, ls2, R, method="deflated")
+    old = _lib.debug_option("direct_accept", 1)
+    try:
+        got = []
+        for i in range(5):                                        # call 1: attempt + fall-back; calls 2 - 5: cool-down
+            C, _, e = _run_minnorm(kd, G, K, ls2, R, method="deflated", rank_hint=int(e[6]))
+            got.append(C)
+    finally:
+        _lib.debug_option("direct_accept", old)
+    for i in range(5):
+        np.testing.assert_array_equal(got[i], ref[i], err_msg=f"call {i + 1} after the failed attempt")
+    C6, _, e6 = _run_minnorm(kd, G, K, ls2, R, method="deflated", rank_hint=int(e[6]))     # the sixth tries the direct form again
+    assert not np.array_equal(C6, ref[5]) and np.abs(U @ (C6 - ref[5])).max() / sc < 1e-3
+    assert int(e6[1]) == int(f0[1]) and int(e6[6]) == 500 and int(e6[7]) == 64 and e6[0] == 1.0
+
+
 def test_deflated_solve_falls_back_when_the_block_is_too_small(st):
     """With a cut-off far above eps more eigenvalues of the factor fall below it than the 256-vector block holds: the call
     must notice and return the Jacobi path's result."""
