@@ -60,7 +60,9 @@ static GramPlan make_plan(int64_t n, int64_t m, mvf_dtype dtype) {
     // 20 GB; at least 3 GB) and is reused by several launches when the capped slices need more.
     const int64_t max_chunks = cdiv(n, GCHUNK);
     const double cache_bytes = (double)n * (double)m * (dtype == MVF_F64 ? 8.0 : 4.0);
-    const double budget_bytes = std::min(20e9, std::max(3e9, 0.1 * cache_bytes));
+    double budget_bytes = std::min(20e9, std::max(3e9, 0.1 * cache_bytes));
+    const long long budget_knob = debug_opt(DBG_GRAM_BUDGET_GB);  // developer option: partial-tile budget in GB (A/B of the phase count)
+    if (budget_knob > 0) budget_bytes = 1e9 * (double)budget_knob;
     const int64_t budget_jobs = std::max<int64_t>(p.npairs, (int64_t)(budget_bytes / (GT * GT * sizeof(double))));
     const int64_t fit = std::max<int64_t>(1, budget_jobs / p.npairs);  // slices whose partial tiles fit the buffer
     constexpr int64_t SL_CAP = 8192;

@@ -16,7 +16,7 @@ DEV_KNOBS = os.environ.get("MVF_DEV_KNOBS") == "1"
 LIB_PATH = (DEV_KNOBS and os.environ.get("MVF_LIB_PATH")) or os.path.join(_HERE, "lib", "libmvf.so")
 DEBUG_OPTIONS = ("conk_form", "conk_rows", "slice_len", "solve_small_off", "jac_gram_wgs", "lr_timing", "lr_no_deflate", "defl_block",
                  "defl_apps", "lr_no_direct", "gram_f64_lds",
-                 "direct_accept")
+                 "direct_accept", "gram_budget_gb")
 _LEGACY_ENV = {  # environment name -> (option, value parser)
     "MVF_CONK": ("conk_form", lambda v: {"rows": 1, "flat": 2, "2d": 3}[v]),
     "MVF_CONK_ROWS": ("conk_rows", int),
