@@ -47,6 +47,8 @@ class MvfComm:
             raise TypeError("MvfComm.all_reduce needs a contiguous float64 device tensor")
         if self._h is None:
             raise RuntimeError("MvfComm.all_reduce after close()")
+        if op not in ("sum", "min"):
+            raise ValueError(f"MvfComm.all_reduce: op must be 'sum' or 'min', not {op!r}")
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.mvf_allreduce_stats(self._h, t.data_ptr(), t.numel(),
