@@ -1353,10 +1353,9 @@ class SvcVectorField:
     def compute_curl(self, X=None, method="analytical", dim1=0, dim2=1, dim3=2, **kwargs):
         self._check_method(method)
         X = self.data["X"] if X is None else np.asarray(X)
-        if dim3 is None or X.shape[1] == 2:
-            X = X[:, [dim1, dim2]]
-        else:
-            X = X[:, [dim1, dim2, dim3]]
+        cols = [dim1, dim2] if dim3 is None or X.shape[1] == 2 else [dim1, dim2, dim3]
+        if cols != list(range(X.shape[1])):  # the default selection of a 2-D / 3-D X is X itself: no gather of n rows
+            X = X[:, cols]
         if X.shape[1] == 2:
             return self._eval(X, _lib.EVAL_CURL)[_lib.EVAL_CURL][:, 2].copy()  # J10 - J01
         elif X.shape[1] == 3:

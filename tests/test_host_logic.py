@@ -751,6 +751,26 @@ def test_one_evaluator_launch_serves_the_calls_on_the_same_points(monkeypatch):
     vfm.clear_eval_cache()
 
 
+def test_curl_column_selection(cpu_kernels):
+    """``compute_curl(X, dim1, dim2, dim3)`` evaluates at ``X[:, [dim1, dim2, dim3]]`` (``GPVectorField.py:55-63``): the
+    default selection of a 3-D X is X itself (no copy of the points is made for it), a permuted one is gathered."""
+    rng = np.random.default_rng(8)
+    vfd = {"X_ctrl": rng.normal(size=(30, 3)), "C": rng.normal(size=(30, 3)), "beta": 0.4}
+    vf = st.SvcVectorField()
+    vf.vf_dict = vfd
+    X = rng.normal(size=(50, 3))
+    J = vf.get_Jacobian()(X)
+    want = np.stack([J[2, 1] - J[1, 2], J[0, 2] - J[2, 0], J[1, 0] - J[0, 1]], 1)
+    c = vf.compute_curl(X=X)
+    assert c.shape == (50, 3, 3)
+    for r in range(3):
+        np.testing.assert_allclose(c[:, r, :], want, rtol=1e-12, atol=1e-14)
+    Xp = X[:, [1, 0, 2]]
+    np.testing.assert_array_equal(vf.compute_curl(X=X, dim1=1, dim2=0, dim3=2), vf.compute_curl(X=Xp.copy()))
+    with pytest.raises(ValueError):
+        vf.compute_curl(X=X, dim3=None)  # two selected columns against a 3-D field
+
+
 def test_jacobian_with_det_in_two_dimensions(cpu_kernels):
     rng = np.random.default_rng(6)
     vfd = {"X_ctrl": rng.normal(size=(30, 2)), "C": rng.normal(size=(30, 2)), "beta": 0.4}
