@@ -675,11 +675,67 @@ __global__ __launch_bounds__(256) void gemm_kernel(const double* __restrict__ A,
             }
 }
 
+// The same product for SKINNY shapes (the 64 / 128 / 256-vector block of the deflated solve against an rp x rp operand:
+// 8 - 56 output tiles of 64 x 64 on a 256-CU part, each with the whole K loop behind it - 32 us per launch at rp = 512, five
+// of them in every small solve).  One 16 x 16 output tile per workgroup, the four waves split K and their partial tiles are
+// summed through LDS in wave order (deterministic); MFMA operand fragments come straight from global memory (the operands
+// are L2-resident and every tile is read once per workgroup), 16 k-steps of loads in flight per wave ahead of the MFMAs.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const double* __restrict__ A, int64_t lda,
+                                                          const double* __restrict__ B, int64_t ldb, double* __restrict__ C,
+                                                          int64_t ldc, int64_t K) {
+    __shared__ double part[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int64_t i0 = (int64_t)blockIdx.y * 16, j0 = (int64_t)blockIdx.x * 16;
+    const int64_t kq = K / 4, kb = wave * kq;  // this wave's K range (K is a multiple of 64)
+    const double* ap = TA ? A + (kb + lk) * lda + i0 + li : A + (i0 + li) * lda + kb + lk;
+    const double* bp = TB ? B + (j0 + li) * ldb + kb + lk : B + (kb + lk) * ldb + j0 + li;
+    const int64_t sa = TA ? 4 * lda : 4, sb = TB ? 4 : 4 * ldb;  // pointer step per k-step (4 values of k)
+    f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+    const int nst = (int)(kq / 4);  // k-steps of this wave (a multiple of 4)
+    double fa[16], fb[16];
+    const int first = min(16, nst);
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        if (s < first) {
+            fa[s] = ap[s * sa];
+            fb[s] = bp[s * sb];
+        }
+    for (int s0 = 0; s0 < nst; s0 += 16) {
+        double na[16], nb[16];
+        const int cnt = min(16, nst - s0), ncnt = min(16, nst - s0 - 16);
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            if (s < ncnt) {
+                na[s] = ap[(s0 + 16 + s) * sa];
+                nb[s] = bp[(s0 + 16 + s) * sb];
+            }
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            if (s < cnt) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[s], fb[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            fa[s] = na[s];
+            fb[s] = nb[s];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][(lk + 4 * r) * 16 + li] = acc[r];
+    __syncthreads();
+    const double v = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+    C[(i0 + (tid >> 4)) * ldc + j0 + (tid & 15)] = v;
+}
+
 template <bool TA, bool TB>
 static void gemm(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                  int64_t rows, int64_t cols, int64_t K) {
-    hipLaunchKernelGGL((gemm_kernel<TA, TB>), dim3((unsigned)(cols / 64), (unsigned)(rows / 64)), dim3(256), 0, st, A, lda, B,
-                       ldb, C, ldc, K);
+    if ((rows / 64) * (cols / 64) < 96)  // fewer 64 x 64 tiles than would keep the part busy: the skinny form
+        hipLaunchKernelGGL((gemm_skinny_kernel<TA, TB>), dim3((unsigned)(cols / 16), (unsigned)(rows / 16)), dim3(256), 0, st, A,
+                           lda, B, ldb, C, ldc, K);
+    else
+        hipLaunchKernelGGL((gemm_kernel<TA, TB>), dim3((unsigned)(cols / 64), (unsigned)(rows / 64)), dim3(256), 0, st, A, lda,
+                           B, ldb, C, ldc, K);
 }
 
 // Wt[i][:] = Y[i][:] / sigma_i  (row i = eigenvector i);  the zero rows of the padding become unit vectors

@@ -7,9 +7,10 @@
 // parity quantity and shows the measured noise floor of the reference itself.
 //
 // Structure per block column k (all kernels on one stream, no host sync):
-//   potrf_diag : one workgroup factors the 64x64 diagonal block (register tiled, one barrier per column)
-//   trsm_panel : one DPP quad (4 lanes x 16 columns) per row below solves  x L_kk^T = a
-//   syrk_update: one workgroup per 64x64 trailing tile, v_mfma_f64_16x16x4_f64 on LDS-staged panels
+//   potrf64    : one workgroup factors the 64x64 diagonal block (register tiled, one barrier per column) - inside the
+//                syrk launch of the previous block column, by the workgroup that updated that block
+//   trsm_panel : one DPP quad (4 lanes x 16 interleaved columns) per row below solves  x L_kk^T = a
+//   syrk_potrf : one workgroup per 64x64 trailing tile, v_mfma_f64_16x16x4_f64 on LDS-staged panels
 // The right-hand sides ride along as extra ROWS of the trapezoidal matrix, so the forward substitution L Y = R falls
 // out of trsm/syrk for free; the back substitution L^T C = Y is one small kernel per block column.
 #include "mvf_common.h"
@@ -58,52 +59,109 @@ __global__ __launch_bounds__(256) void chol_prepare_kernel(const double* __restr
     W[i * mp + j] = v;
 }
 
-// Right-looking Cholesky of one 64x64 diagonal block, register tiled: thread (ty, tx) of a 16 x 16 grid keeps the 16
-// elements a[ty + 16 p][tx + 16 q] in registers.  Step j: the owners of column j publish it (still UNSCALED) to LDS,
-// ONE barrier, then every thread applies the rank-1 update a[i][c] -= (a[i][j] / a[j][j]) a[c][j] to its registers
-// (8 LDS reads + 16 multiply-subtracts per step instead of a latency-bound LDS read-modify-write per element).
-// Columns are scaled by 1 / sqrt(a[j][j]) once at the end; rdiag gets 1 / L[j][j] for the triangular solves (no
-// divisions in their dependent chains).  The column loop is ROLLED inside each 16-column group (the group index must
-// be static for the register tile): these one-workgroup kernels run once per launch, so straight-line unrolled code
-// is paid for in instruction-cache misses (measured: the fully unrolled version was no faster than the LDS one).
+// ---- the three kernels of a block column (round 6: each of them was a chain of exposed latencies - 25 + 32 + 15 us per 64
+// columns, profiles/r05_small_m_timeline.md - on a part whose dependent-launch boundary costs 1.5 us) ----------------------
+//
+// potrf64: right-looking Cholesky of one 64 x 64 block by ONE workgroup, register tiled: thread (ty, tx) of a 16 x 16 grid
+// keeps a[ty + 16 p][tx + 16 q] (p >= q: the lower triangle of tiles).  Step j: the owners of column j have published it
+// (still UNSCALED) in its own LDS row Lu[j][.], ONE barrier, every thread applies the rank-1 update
+// a[i][c] -= (a[i][j] / a[j][j]) a[c][j] to its registers.  What makes a step short:
+//   * the reciprocal of the pivot is v_rcp_f64 + two Newton steps (the IEEE divide the compiler emits is ~20 dependent
+//     instructions in every step's critical chain);
+//   * no predicate on the update: an entry with i <= j or c <= j is dead once its column has been published (the columns
+//     are kept in LDS, the result is written from there), so whatever the update does to it is never read;
+//   * the NEXT column is updated and published first, the other tiles after it: their multiply-subtracts overlap the LDS
+//     round trip of the publication instead of preceding it.
+// Columns are scaled by 1 / sqrt(d_j) at the end; rdiag gets 1 / L_jj for the triangular solves.  The column loop is rolled
+// inside each 16-column group (the group index must be static for the register tile; straight-line code of a
+// one-workgroup kernel is paid for in instruction-cache misses).
+constexpr int LDU = NB + 1;  // LDS stride of the published columns
+
+__device__ __forceinline__ double rcp_nr2(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return fma(fma(-x, y, 1.0), y, y);
+}
+
 template <int JQ>
-__device__ __forceinline__ void potrf_group(double (&r)[4][4], double (*col)[NB], double* dg, int tx, int ty, int k,
+__device__ __forceinline__ void potrf_group(double (&r)[4][4], double (*Lu)[LDU], double* dg, int tx, int ty, int k,
                                             int* __restrict__ info) {
+    if (tx == 0) {  // the group's first column (the earlier groups' updates are complete in the registers)
+#pragma unroll
+        for (int p = JQ; p < 4; ++p) Lu[16 * JQ][ty + 16 * p] = r[p][JQ];
+    }
+    __syncthreads();
 #pragma unroll 1
     for (int jx = 0; jx < 16; ++jx) {
         const int j = 16 * JQ + jx;
-        if (tx == jx) {
-#pragma unroll
-            for (int p = JQ; p < 4; ++p) col[j & 1][ty + 16 * p] = r[p][JQ];
-        }
-        __syncthreads();
-        const double* cb = col[j & 1];
+        const double* cb = Lu[j];
         double d = cb[j];
+        double ci[4], cc[4];
+#pragma unroll
+        for (int p = JQ; p < 4; ++p) {  // (every LDS read of the step is in flight before the pivot is looked at)
+            ci[p] = cb[ty + 16 * p];
+            cc[p] = cb[tx + 16 * p];
+        }
         if (!(d > 0.0)) {  // also catches NaN; keep going with a harmless pivot so the kernel chain completes
             if (threadIdx.x == 0) atomicCAS(info, 0, 1 + k * NB + j);
             d = 1.0;
         }
         if (threadIdx.x == 0) dg[j] = d;
-        const double inv = 1.0 / d;
-        double ci[4], cc[4];
+        const double inv = rcp_nr2(d);
 #pragma unroll
-        for (int p = JQ; p < 4; ++p) {
-            ci[p] = cb[ty + 16 * p] * inv;
-            cc[p] = cb[tx + 16 * p];
+        for (int p = JQ; p < 4; ++p) ci[p] *= inv;
+        // tile column JQ first: it holds column j + 1, which its owners publish before anybody touches the other tiles
+#pragma unroll
+        for (int p = JQ; p < 4; ++p) r[p][JQ] = fma(-ci[p], cc[JQ], r[p][JQ]);
+        if (tx == jx + 1) {  // (never in the group's last step: the next group publishes its own first column)
+#pragma unroll
+            for (int p = JQ; p < 4; ++p) Lu[j + 1][ty + 16 * p] = r[p][JQ];
         }
 #pragma unroll
-        for (int p = JQ; p < 4; ++p)
+        for (int q = JQ + 1; q < 4; ++q)
 #pragma unroll
-            for (int q = JQ; q < 4; ++q) {
-                const double u = r[p][q] - ci[p] * cc[q];
-                r[p][q] = (ty + 16 * p > j && tx + 16 * q > j) ? u : r[p][q];
-            }
+            for (int p = q; p < 4; ++p) r[p][q] = fma(-ci[p], cc[q], r[p][q]);
+        __syncthreads();
     }
 }
 
+// r = the block (thread (ty, tx) holds a[ty + 16 p][tx + 16 q]);  on return Lu[c][i] = unscaled column c (rows i >= c) and
+// dg[c] = the pivots; the caller scales and stores with potrf64_store.  256 threads.
+__device__ __forceinline__ void potrf64(double (&r)[4][4], double (*Lu)[LDU], double* dg, int k, int* __restrict__ info) {
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    potrf_group<0>(r, Lu, dg, tx, ty, k, info);
+    potrf_group<1>(r, Lu, dg, tx, ty, k, info);
+    potrf_group<2>(r, Lu, dg, tx, ty, k, info);
+    potrf_group<3>(r, Lu, dg, tx, ty, k, info);
+}
+
+// the factor of block column k's diagonal block to W (explicitly ZERO upper triangle: the triangular solves rely on it)
+__device__ __forceinline__ void potrf64_store(const double (*Lu)[LDU], const double* dg, double* __restrict__ blk, int64_t mp,
+                                              double* __restrict__ rdiag_k) {
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = tx + 16 * q;
+        const double l = sqrt(dg[c]);
+        const double rl = 1.0 / l;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int i = ty + 16 * p;
+            // a / l as a * (1 / l) with one correction step: the quotient to within an ulp of the correctly rounded one
+            // (16 IEEE divisions per thread would sit on the factorisation's serial path)
+            const double a = Lu[c][i];
+            const double q0 = a * rl;
+            const double q = fma(fma(-q0, l, a), rl, q0);
+            blk[(int64_t)i * mp + c] = (c < i) ? q : (c == i ? l : 0.0);
+            if (c == i) rdiag_k[c] = rl;
+        }
+    }
+}
+
+// block column 0's diagonal block (the later ones are factored by the workgroup of syrk_potrf_kernel that updated them)
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ W, int64_t mp, int k,
                                                          double* __restrict__ rdiag, int* __restrict__ info) {
-    __shared__ double col[2][NB];
+    __shared__ double Lu[NB][LDU];
     __shared__ double dg[NB];
     double* blk = W + ((int64_t)k * NB) * mp + (int64_t)k * NB;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -112,28 +170,19 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ W,
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) r[p][q] = blk[(int64_t)(ty + 16 * p) * mp + tx + 16 * q];
-    potrf_group<0>(r, col, dg, tx, ty, k, info);
-    potrf_group<1>(r, col, dg, tx, ty, k, info);
-    potrf_group<2>(r, col, dg, tx, ty, k, info);
-    potrf_group<3>(r, col, dg, tx, ty, k, info);
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = ty + 16 * p, c = tx + 16 * q;
-            const double l = sqrt(dg[c]);
-            blk[(int64_t)i * mp + c] = (c < i) ? r[p][q] / l : (c == i ? l : 0.0);
-            if (c == i) rdiag[(int64_t)k * NB + c] = 1.0 / l;
-        }
+    potrf64(r, Lu, dg, k, info);
+    potrf64_store(Lu, dg, blk, mp, rdiag + (int64_t)k * NB);
 }
 
 // rows below the diagonal block:  x L^T = a  ->  for c: x_c = a_c / L_cc ; a_j -= x_c L_jc (j > c).
-// FOUR lanes (one DPP quad) per row, each holding 16 of the row's 64 columns in registers: per column c the owning
-// lane scales by the precomputed 1 / L_cc, a quad_perm DPP move broadcasts x_c to the quad, and every lane updates its
-// 16 columns.  The diagonal block is stored with an explicitly ZERO upper triangle, so the update needs no predicate:
-// for j < c it subtracts x_c * 0.  (4x the lanes and a 4x shorter dependent chain than one lane per row; the column
-// loop is rolled - wave-uniform dynamic register index - to stay inside the instruction cache.)
+// FOUR lanes (one DPP quad) per row; lane rho of the quad holds the row's columns 4 jl + rho (jl = 0 .. 15) - interleaved, so
+// that at every step c all four lanes still have live columns and the uniform instruction stream carries 16 - c / 4
+// multiply-subtracts instead of 16.  Per column c the owning lane scales by the precomputed 1 / L_cc, a quad_perm DPP move
+// broadcasts x_c to the quad, every lane updates its columns of index >= c / 4.  The factor sits in LDS as
+// Ls[c][rho][jl] = L[4 jl + rho][c] with the diagonal and the upper triangle ZERO: a lane's operands of one step are
+// consecutive (ds_read_b128), entries that must not change are multiplied by zero - no predicates - and the owner's x_c
+// register keeps a_c - sum (scaled once more, bit-identically, at the end).  Fully unrolled: every register index is
+// static (the round-5 kernel indexed its register tile dynamically inside a rolled loop: 32 us per launch).
 template <int O>
 __device__ __forceinline__ double quad_bcast(double v) {
     constexpr int ctrl = O | (O << 2) | (O << 4) | (O << 6);  // quad_perm: every lane of the quad reads lane O
@@ -143,57 +192,75 @@ __device__ __forceinline__ double quad_bcast(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-typedef double f64x16 __attribute__((ext_vector_type(16)));
+constexpr int TLQ = 18;           // doubles per (column, lane-of-quad) slot: 16 used, the pad de-phases the four lanes' banks
+constexpr int TLC = 4 * TLQ + 2;  // doubles per column c (the odd multiple of 2 keeps the transposing store conflict-free)
 
-template <int O>
-__device__ __forceinline__ void trsm_quarter(f64x16& x, const double (*L)[NB + 1], const double* rd, int role) {
-#pragma unroll 1
-    for (int cl = 0; cl < 16; ++cl) {
-        const int c = 16 * O + cl;
-        const double xc = quad_bcast<O>(x[cl] * rd[c]);  // meaningful on the owning lane (role == O), read from it
-        const double* Lc = &L[16 * role][c];
+// step C with the operands of step C + 1 (their LDS reads) issued before its arithmetic: the chain of a step is
+// multiply - two DPP moves - multiply-subtract, and an LDS round trip per step would triple it
+template <int C>
+__device__ __forceinline__ void trsm_steps(double (&x)[16], const double* __restrict__ ls_rho, const double* __restrict__ rd,
+                                           const double2 (&cur)[8], double rdc) {
+    constexpr int G = C / 4, O = C % 4;
+    double2 nxt[8];
+    double rdn = 0.0;
+    if constexpr (C + 1 < NB) {
+        const double2* ln = reinterpret_cast<const double2*>(ls_rho + (C + 1) * TLC);
 #pragma unroll
-        for (int jl = 0; jl < 16; ++jl) x[jl] = fma(-xc, Lc[jl * (NB + 1)], x[jl]);
-        const double keep = x[cl];
-        x[cl] = (role == O) ? xc : keep;
+        for (int h = (C + 1) / 8; h < 8; ++h) nxt[h] = ln[h];
+        rdn = rd[C + 1];
     }
+    const double xc = quad_bcast<O>(x[G] * rdc);  // meaningful on the owning lane (rho == O), read from it
+#pragma unroll
+    for (int h = G / 2; h < 8; ++h) {
+        x[2 * h] = fma(-xc, cur[h].x, x[2 * h]);
+        x[2 * h + 1] = fma(-xc, cur[h].y, x[2 * h + 1]);
+    }
+    if constexpr (C + 1 < NB) trsm_steps<C + 1>(x, ls_rho, rd, nxt, rdn);
 }
 
 __global__ __launch_bounds__(256) void trsm_panel_kernel(double* __restrict__ W, int64_t mp, int64_t mr, int k,
                                                          const double* __restrict__ rdiag) {
-    __shared__ double L[NB][NB + 1];
+    __shared__ __align__(16) double Ls[NB * TLC];
     __shared__ double rd[NB];
     const double* blk = W + ((int64_t)k * NB) * mp + (int64_t)k * NB;
+    const int rho = threadIdx.x & 3;
+    const int64_t row = (int64_t)(k + 1) * NB + (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool live = row < mr;  // whole quads are live or not (same row)
+    double* rp = W + (live ? row : (int64_t)(k + 1) * NB) * mp + (int64_t)k * NB + rho;
+    double x[16];
+#pragma unroll
+    for (int jl = 0; jl < 16; ++jl) x[jl] = rp[4 * jl];
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         double v[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = blk[(int64_t)(wave * 16 + q) * mp + lane];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) L[wave * 16 + q][lane] = v[q];
+        for (int q = 0; q < 16; ++q) {
+            const int i = wave * 16 + q;  // L[i][c = lane]
+            Ls[lane * TLC + (i & 3) * TLQ + (i >> 2)] = (lane < i) ? v[q] : 0.0;
+        }
         if (threadIdx.x < NB) rd[threadIdx.x] = rdiag[(int64_t)k * NB + threadIdx.x];
     }
-    const int role = threadIdx.x & 3;
-    const int64_t row = (int64_t)(k + 1) * NB + (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
-    const bool live = row < mr;  // whole quads are live or not (same row)
-    double* rp = W + (live ? row : (int64_t)(k + 1) * NB) * mp + (int64_t)k * NB + 16 * role;
-    f64x16 x;
-#pragma unroll
-    for (int jl = 0; jl < 16; ++jl) x[jl] = rp[jl];
     __syncthreads();
-    trsm_quarter<0>(x, L, rd, role);
-    trsm_quarter<1>(x, L, rd, role);
-    trsm_quarter<2>(x, L, rd, role);
-    trsm_quarter<3>(x, L, rd, role);
+    const double* ls_rho = Ls + rho * TLQ;
+    double2 first[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) first[h] = reinterpret_cast<const double2*>(ls_rho)[h];
+    trsm_steps<0>(x, ls_rho, rd, first, rd[0]);
     if (live) {
 #pragma unroll
-        for (int jl = 0; jl < 16; ++jl) rp[jl] = x[jl];
+        for (int jl = 0; jl < 16; ++jl) rp[4 * jl] = x[jl] * rd[4 * jl + rho];
     }
 }
 
-// W[i, j] -= W[i, k] W[j, k]^T  for block rows i > k (incl. the rhs block row) and block cols k < j <= min(i, nb-1)
+// W[i, j] -= W[i, k] W[j, k]^T  for block rows i > k (incl. the rhs block row) and block cols k < j <= min(i, nb-1); every
+// load of a workgroup (both panels and its tile of W, in the accumulator layout) is issued before the first is used.  The
+// workgroup of the NEXT diagonal tile (k + 1, k + 1) - tile 0 of the launch - factors it on the spot (potrf64) instead of
+// storing it: a block column costs two launches, trsm_panel_kernel and this one.
 constexpr int LDP = NB + 2;  // padded LDS row stride (doubles): conflict-free ds_read_b64 of MFMA operands
-__global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ W, int64_t mp, int k, int nb, int nbr) {
+__global__ __launch_bounds__(256) void syrk_potrf_kernel(double* __restrict__ W, int64_t mp, int k, int nb, int nbr,
+                                                         double* __restrict__ rdiag, int* __restrict__ info) {
     // decode (i, j) from the linear tile index: i in (k, nbr), j in (k, min(i, nb-1)]
     int t = blockIdx.x, i = k + 1;
     while (true) {
@@ -205,29 +272,49 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ W
     const int j = k + 1 + t;
     __shared__ double sa[NB * LDP];
     __shared__ double sb[NB * LDP];
+    __shared__ double dg[NB];
     const double* pa = W + ((int64_t)i * NB) * mp + (int64_t)k * NB;
     const double* pb = W + ((int64_t)j * NB) * mp + (int64_t)k * NB;
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {
-        const int r = e / NB, c = e % NB;
-        sa[r * LDP + c] = pa[(int64_t)r * mp + c];
-        sb[r * LDP + c] = pb[(int64_t)r * mp + c];
-    }
-    __syncthreads();
+    double* pc = W + ((int64_t)i * NB) * mp + (int64_t)j * NB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    const int li = lane & 15, lk = lane >> 4;
+    const bool diag = i == j;
+    double va[16], vb[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) va[q] = pa[(int64_t)(wave * 16 + q) * mp + lane];
+    if (!diag) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) vb[q] = pb[(int64_t)(wave * 16 + q) * mp + lane];
+    }
+    f64x4 cin[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                cin[a][b][r] = pc[(int64_t)(wr + a * 16 + lk + 4 * r) * mp + wc + b * 16 + li];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sa[(wave * 16 + q) * LDP + lane] = va[q];
+    if (!diag) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sb[(wave * 16 + q) * LDP + lane] = vb[q];
+    }
+    __syncthreads();
+    const double* sbb = diag ? sa : sb;
     f64x4 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
-    const int li = lane & 15, lk = lane >> 4;
 #pragma unroll 4
     for (int kk = 0; kk < NB; kk += 4) {
         double fa[2], fb[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            fa[a] = sa[(wr + a * 16 + li) * LDP + kk + lk];  // A[i][k]
-            fb[a] = sb[(wc + a * 16 + li) * LDP + kk + lk];  // B[k][j] = Wj[j][k]
+            fa[a] = sa[(wr + a * 16 + li) * LDP + kk + lk];   // A[i][k]
+            fb[a] = sbb[(wc + a * 16 + li) * LDP + kk + lk];  // B[k][j] = Wj[j][k]
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -235,17 +322,35 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ W
             for (int b = 0; b < 2; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
     }
-    double* pc = W + ((int64_t)i * NB) * mp + (int64_t)j * NB;
+    if (blockIdx.x != 0) {  // (tile 0 is (k + 1, k + 1): the launch has tiles only while k + 1 < nb)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pc[(int64_t)(wr + a * 16 + lk + 4 * r) * mp + wc + b * 16 + li] = cin[a][b][r] - acc[a][b][r];
+        return;
+    }
+    // the updated diagonal tile goes through LDS into potrf64's register layout and is factored here
+    __syncthreads();  // every wave is done with the panels
+    double(*T)[LDU] = reinterpret_cast<double(*)[LDU]>(sa);
+    double(*Lu)[LDU] = reinterpret_cast<double(*)[LDU]>(sb);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wr + a * 16 + lk + 4 * r;
-                const int col = wc + b * 16 + li;
-                pc[(int64_t)row * mp + col] -= acc[a][b][r];
-            }
+            for (int r = 0; r < 4; ++r) T[wr + a * 16 + lk + 4 * r][wc + b * 16 + li] = cin[a][b][r] - acc[a][b][r];
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    double r[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[p][q] = T[ty + 16 * p][tx + 16 * q];
+    potrf64(r, Lu, dg, k + 1, info);
+    potrf64_store(Lu, dg, pc, mp, rdiag + (int64_t)(k + 1) * NB);
 }
 
 // back substitution L^T C = Y, one launch per block column k (descending), k + 1 workgroups:
@@ -520,16 +625,17 @@ static int chol_run(hipStream_t st, CholPlan* pl, int* info) {
     const int64_t mp = pl->mp, mr = pl->mr;
     const int nb = pl->nb, nbr = pl->nbr;
     double* W = pl->W;
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, W, mp, 0, pl->rdiag, info);
     for (int k = 0; k < nb; ++k) {
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, W, mp, k, pl->rdiag, info);
         const int64_t rows_below = mr - (int64_t)(k + 1) * NB;
         hipLaunchKernelGGL(trsm_panel_kernel, dim3((unsigned)cdiv(rows_below, 64)), dim3(256), 0, st, W, mp, mr, k,
                            pl->rdiag);
-        // tiles: sum over i in (k, nbr) of (min(i, nb-1) - k)
+        // tiles: sum over i in (k, nbr) of (min(i, nb-1) - k); tile 0 = the next diagonal block, factored in the same launch
         int64_t ntiles = 0;
         for (int i = k + 1; i < nbr; ++i) ntiles += std::min(i, nb - 1) - k;
         if (ntiles > 0)
-            hipLaunchKernelGGL(syrk_update_kernel, dim3((unsigned)ntiles), dim3(256), 0, st, W, mp, k, nb, nbr);
+            hipLaunchKernelGGL(syrk_potrf_kernel, dim3((unsigned)ntiles), dim3(256), 0, st, W, mp, k, nb, nbr, pl->rdiag,
+                               info);
     }
     MVF_LAUNCH_CHECK();
     return 0;
