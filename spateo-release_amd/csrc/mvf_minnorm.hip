@@ -35,6 +35,7 @@
 // mvf_pinv_diag evaluates diag(U pinv(A) U^T) from the Y either of the two Jacobi solvers left behind.
 #include "mvf_common.h"
 #include "mvf_solve.h"
+#include "mvf_chol_dev.h"
 
 namespace mvf {
 
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(EIG_THREADS) void jac_eig_kernel(const double* __re
     __shared__ double Jm[JP][JP];
     __shared__ double cs[2][JB][2];
     __shared__ int sweep_rot;
+    __shared__ int round_act[64], round_list[64], n_act;
     const int pair = blockIdx.x, tid = threadIdx.x;
     int bp, bq;
     rr_pair(nb, round, pair, bp, bq);
@@ -326,19 +328,49 @@ __global__ __launch_bounds__(EIG_THREADS) void jac_eig_kernel(const double* __re
     const unsigned long long c1 = wall_clock64();
 #endif
     int nrot_any = 0;
+    // Which inner rounds have anything to do?  Every pair of the sweep is tested ONCE, in parallel, on the tile as the sweep
+    // finds it (1024 threads: one or two pairs each); rounds without an active pair are not run at all (they used to cost
+    // two barriers and a full update pass of S and J each: the later sweeps of an iteration - and most of a warm-started
+    // one - are almost empty), and a sweep that finds no active pair anywhere ends the iteration without running: the
+    // verification sweep costs one pass of tests instead of 63 rounds.  (A pair that only becomes active through the
+    // rotations of this sweep is met by the next sweep's tests - threshold Jacobi; the stopping criterion is the same
+    // test on every pair, now on one and the same tile.)
+    auto pair_active = [&](int r, int ll) -> bool {
+        int p, q;
+        inner_pair<FULL>(r, ll, p, q);
+        const double app = S[p][p], aqq = S[q][q], apq = S[p][q];
+        return apq != 0.0 && apq * apq > tol2 * fabs(app * aqq);
+    };
 #pragma unroll 1
     for (int sw = 0; sw < (FULL ? inner_sweeps : 1); ++sw) {
     nrot = 0;
-    if (k == 0) rotation(0, cs[0]);
+    if (tid < 64) round_act[tid] = 0;
+    __syncthreads();
+    {
+        if (k < NR && pair_active(k, l)) round_act[k] = 1;  // (benign race: every writer stores 1)
+        if (FULL && k + 32 < NR && pair_active(k + 32, l)) round_act[k + 32] = 1;
+    }
+    __syncthreads();
+    if (tid < 64) {  // wave 0: compact the active rounds, in order
+        const bool a = tid < NR && round_act[tid] != 0;
+        const unsigned long long b = __ballot(a);
+        if (a) round_list[__popcll(b & ((1ull << tid) - 1ull))] = tid;
+        if (tid == 0) n_act = __popcll(b);
+    }
+    __syncthreads();
+    const int nact = n_act;
+    if (nact > 0) {
+    if (k == 0) rotation(round_list[0], cs[0]);
     __syncthreads();
     // Per round: (1) every thread rotates its 2 x 2 block of S; barrier; (2) the first half-wave computes the NEXT round's
     // rotations from the updated S while all threads rotate their column pair of J (J is not needed for the rotations:
     // the dependent f64 chain of (2) hides behind the LDS traffic of the J update); barrier.
 #pragma unroll 1
-    for (int r = 0; r < NR; ++r) {
+    for (int ri = 0; ri < nact; ++ri) {
+        const int r = round_list[ri];
         int p, q;
         inner_pair<FULL>(r, l, p, q);
-        const double(*csr)[2] = cs[r & 1];
+        const double(*csr)[2] = cs[ri & 1];
         const double cl = csr[l][0], sl = csr[l][1], ck = csr[k][0], sk = csr[k][1];
         {
             int pk, qk;
@@ -363,7 +395,7 @@ __global__ __launch_bounds__(EIG_THREADS) void jac_eig_kernel(const double* __re
             }
         }
         __syncthreads();
-        if (k == 0 && r + 1 < NR) rotation(r + 1, cs[(r + 1) & 1]);
+        if (k == 0 && ri + 1 < nact) rotation(round_list[ri + 1], cs[(ri + 1) & 1]);
 #ifdef MVF_EIG_NO_J  // measurement arm only (wrong results): the J accumulation switched off
         if (tol < 0.0)
 #endif
@@ -376,8 +408,15 @@ __global__ __launch_bounds__(EIG_THREADS) void jac_eig_kernel(const double* __re
         }
         __syncthreads();
     }
+    }
     if (inner_sweeps > 1) {  // uniform: did this sweep rotate anything?  (nrot lives in the first half-wave)
-        if (tid == 0) sweep_rot = nrot;
+        if (tid == 0) {
+            sweep_rot = nrot;
+            if (sw < 12) {  // diagnostics (developer option lr_timing prints them): active rounds / rotations of this sweep
+                rot_total[8 + 2 * sw] = (unsigned int)nact;
+                rot_total[9 + 2 * sw] = (unsigned int)nrot;
+            }
+        }
         __syncthreads();
         const int sr = sweep_rot;
         nrot_any += sr;
@@ -1077,42 +1116,50 @@ __global__ __launch_bounds__(256) void pchol_update_kernel(double* __restrict__ 
 // first rejected column ends the use of the hint; the greedy steps above finish the factorisation (and find any column
 // the hint does not know).
 
-// Right-looking Cholesky of the gathered 64 x 64 block, register tiled like potrf_diag_kernel of mvf_solve.hip (thread
-// (ty, tx) of a 16 x 16 grid keeps a[ty + 16 p][tx + 16 q]; per column: the owners publish it UNSCALED to LDS, one
-// barrier, every thread applies the rank-1 update to its registers), stopping at the first pivot that fails the threshold.
+// Right-looking Cholesky of the gathered 64 x 64 block, register tiled like potrf64 of mvf_solve.hip (thread (ty, tx) of a
+// 16 x 16 grid keeps a[ty + 16 p][tx + 16 q], p >= q; the owners of a column publish it UNSCALED in its own LDS row, one
+// barrier per column, Newton reciprocal of the pivot, unpredicated rank-1 update with the next column first), stopping at
+// the first pivot that fails the threshold: columns 0 .. nvalid - 1 of Lu are then the accepted ones.
 template <int JQ>
-__device__ __forceinline__ bool panel_potrf_group(double (&r)[4][4], double (*col)[64], double* dgs, int tx, int ty,
+__device__ __forceinline__ bool panel_potrf_group(double (&r)[4][4], double (*Lu)[LDU], double* dgs, int tx, int ty,
                                                   double thr, int n, int& nvalid) {
+    if (16 * JQ >= n) return false;
+    if (tx == 0) {
+#pragma unroll
+        for (int p = JQ; p < 4; ++p) Lu[16 * JQ][ty + 16 * p] = r[p][JQ];
+    }
+    __syncthreads();
 #pragma unroll 1
     for (int jx = 0; jx < 16; ++jx) {
         const int j = 16 * JQ + jx;
         if (j >= n) return false;
-        if (tx == jx) {
-#pragma unroll
-            for (int p = JQ; p < 4; ++p) col[j & 1][ty + 16 * p] = r[p][JQ];
-        }
-        __syncthreads();
-        const double* cb = col[j & 1];
+        const double* cb = Lu[j];
         const double d = cb[j];
+        double ci[4], cc[4];
+#pragma unroll
+        for (int p = JQ; p < 4; ++p) {
+            ci[p] = cb[ty + 16 * p];
+            cc[p] = cb[tx + 16 * p];
+        }
         if (!(d > thr && d <= 1.79e308)) {  // uniform: every thread reads the same pivot
             nvalid = j;
             return false;
         }
         if (threadIdx.x == 0) dgs[j] = d;
-        const double inv = 1.0 / d;
-        double ci[4], cc[4];
+        const double inv = rcp_nr2(d);
 #pragma unroll
-        for (int p = JQ; p < 4; ++p) {
-            ci[p] = cb[ty + 16 * p] * inv;
-            cc[p] = cb[tx + 16 * p];
+        for (int p = JQ; p < 4; ++p) ci[p] *= inv;
+#pragma unroll
+        for (int p = JQ; p < 4; ++p) r[p][JQ] = fma(-ci[p], cc[JQ], r[p][JQ]);
+        if (tx == jx + 1) {
+#pragma unroll
+            for (int p = JQ; p < 4; ++p) Lu[j + 1][ty + 16 * p] = r[p][JQ];
         }
 #pragma unroll
-        for (int p = JQ; p < 4; ++p)
+        for (int q = JQ + 1; q < 4; ++q)
 #pragma unroll
-            for (int q = JQ; q < 4; ++q) {
-                const double u = r[p][q] - ci[p] * cc[q];
-                r[p][q] = (ty + 16 * p > j && tx + 16 * q > j) ? u : r[p][q];
-            }
+            for (int p = q; p < 4; ++p) r[p][q] = fma(-ci[p], cc[q], r[p][q]);
+        __syncthreads();
     }
     return true;
 }
@@ -1122,7 +1169,7 @@ __global__ __launch_bounds__(256) void pchol_panel_factor_kernel(const double* _
                                                                  const double* __restrict__ dg, PcholState* __restrict__ stt,
                                                                  int* __restrict__ order, double* __restrict__ piv,
                                                                  double* __restrict__ Lcc, int* __restrict__ cand_out) {
-    __shared__ double col[2][64];
+    __shared__ double Lu[64][LDU];
     __shared__ double dgs[64];
     __shared__ int cand[64];
     __shared__ double red[4];
@@ -1169,23 +1216,24 @@ __global__ __launch_bounds__(256) void pchol_panel_factor_kernel(const double* _
         }
     const double thr = fmax(PCHOL_THETA * dmax, tol);
     int nvalid = n;
-    if (panel_potrf_group<0>(r, col, dgs, tx, ty, thr, n, nvalid))
-        if (panel_potrf_group<1>(r, col, dgs, tx, ty, thr, n, nvalid))
-            if (panel_potrf_group<2>(r, col, dgs, tx, ty, thr, n, nvalid))
-                panel_potrf_group<3>(r, col, dgs, tx, ty, thr, n, nvalid);
+    if (panel_potrf_group<0>(r, Lu, dgs, tx, ty, thr, n, nvalid))
+        if (panel_potrf_group<1>(r, Lu, dgs, tx, ty, thr, n, nvalid))
+            if (panel_potrf_group<2>(r, Lu, dgs, tx, ty, thr, n, nvalid))
+                panel_potrf_group<3>(r, Lu, dgs, tx, ty, thr, n, nvalid);
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int q = 0; q < 4; ++q) {
+        const int c = tx + 16 * q;
+        const double l = c < nvalid ? sqrt(dgs[c]) : 1.0;
+        const double rl = 1.0 / l;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = ty + 16 * p, c = tx + 16 * q;
+        for (int p = 0; p < 4; ++p) {
+            const int i = ty + 16 * p;
             double v = 0.0;
-            if (i < nvalid && c <= i) {
-                const double l = sqrt(dgs[c]);
-                v = c < i ? r[p][q] / l : l;
-            }
+            if (i < nvalid && c <= i) v = c < i ? div_by(Lu[c][i], l, rl) : l;
             Lcc[i * 64 + c] = v;
         }
+    }
     if (tid < 64) {
         cand_out[tid] = tid < nvalid ? cand[tid] : -1;
         order[64 * b + tid] = tid < nvalid ? cand[tid] : -1;
@@ -1199,24 +1247,38 @@ __global__ __launch_bounds__(256) void pchol_panel_factor_kernel(const double* _
 }
 
 // rows 64 b .. 64 b + 63 of Y from the accepted panel: Y[64 b + j][i] = (S[c_j][i] - sum_{k < j} L[j][k] Y[64 b + k][i]) / L[j][j]
-// (one lane per column i; the panel's own pivot columns come out as L's columns and are forced to exact zeros behind
-// their pivot), dg -= sum_j y_j^2, the workgroup's (max, argmax) for the greedy steps that may follow.
-__global__ __launch_bounds__(PC_T) void pchol_panel_rows_kernel(const double* __restrict__ S, double* __restrict__ Y, int64_t mp,
-                                                                int b, double* __restrict__ dg, double* __restrict__ pm,
-                                                                PcholState* __restrict__ stt, const double* __restrict__ Lcc,
-                                                                const int* __restrict__ cand_in) {
+// (the panel's own pivot columns come out as L's columns and are forced to exact zeros behind their pivot), dg -= sum_j y_j^2,
+// the workgroup's (max, argmax) for the greedy steps that may follow.  FOUR lanes (one DPP quad) per column i of A, each
+// holding the 16 interleaved entries j = 4 jl + rho of that column's 64 - the substitution of trsm_panel_kernel
+// (mvf_chol_dev.h: the same multiply-subtracts in the same order as the dot-product form, one lane per column, that this
+// kernel used until round 5 - 29 us per launch behind a 2016-long dependent chain per lane).
+__global__ __launch_bounds__(4 * PC_T) void pchol_panel_rows_kernel(const double* __restrict__ S, double* __restrict__ Y, int64_t mp,
+                                                                    int b, double* __restrict__ dg, double* __restrict__ pm,
+                                                                    PcholState* __restrict__ stt, const double* __restrict__ Lcc,
+                                                                    const int* __restrict__ cand_in) {
     if (stt->panels != b + 1) return;
-    __shared__ double L[64][65];
+    __shared__ __align__(16) double Ls[NB * TLC];
     __shared__ double rd[64];
     __shared__ int cand[64];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nvalid = stt->panel_nvalid;
-    for (int e = tid; e < 64 * 64; e += PC_T) L[e >> 6][e & 63] = Lcc[e];
-    if (tid < 64) cand[tid] = cand_in[tid];
+    {
+        double v[8];  // L[i][c = lane], rows i = wave * 8 + q (Lcc: explicit zeros above the diagonal and behind nvalid)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = Lcc[(wave * 8 + q) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = wave * 8 + q;
+            Ls[lane * TLC + (i & 3) * TLQ + (i >> 2)] = (lane < i) ? v[q] : 0.0;
+        }
+        if (tid < 64) {
+            cand[tid] = cand_in[tid];
+            rd[tid] = tid < nvalid ? 1.0 / Lcc[tid * 64 + tid] : 0.0;
+        }
+    }
     __syncthreads();
-    if (tid < 64) rd[tid] = tid < nvalid ? 1.0 / L[tid][tid] : 0.0;
-    __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * PC_T + tid;
+    const int rho = tid & 3;
+    const int64_t i = (int64_t)blockIdx.x * PC_T + (tid >> 2);
     const bool live = i < mp;
     const int64_t ic = live ? i : 0;
     const double di = dg[ic];
@@ -1224,28 +1286,39 @@ __global__ __launch_bounds__(PC_T) void pchol_panel_rows_kernel(const double* __
     int pos = -1;
     for (int k = 0; k < nvalid; ++k)
         if (cand[k] == (int)ic) pos = k;
-    double y[64];
+    double y[16];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) y[j] = (j < nvalid && !used) ? S[(int64_t)max(cand[j], 0) * mp + ic] : 0.0;
+    for (int jl = 0; jl < 16; ++jl) {
+        const int j = 4 * jl + rho;
+        y[jl] = (j < nvalid && !used) ? S[(int64_t)max(cand[j], 0) * mp + ic] : 0.0;
+    }
+    const double* ls_rho = Ls + rho * TLQ;
+    double2 first[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) first[h] = reinterpret_cast<const double2*>(ls_rho)[h];
+    trsm_steps<0>(y, ls_rho, rd, first, rd[0]);
     double ss = 0.0;
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        double s = y[j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) s = fma(-L[j][k], y[k], s);
-        s *= rd[j];
-        if (pos >= 0 && j > pos) s = 0.0;
-        y[j] = s;
-        ss = fma(s, s, ss);
+    for (int jl = 0; jl < 16; ++jl) {
+        const int j = 4 * jl + rho;
+        double v = y[jl] * rd[j];
+        if (pos >= 0 && j > pos) v = 0.0;
+        y[jl] = v;
+        ss = fma(v, v, ss);
+    }
+    // the quad's four partial sums in lane order (deterministic), on every lane of the quad
+    {
+        const double s0 = quad_bcast<0>(ss), s1 = quad_bcast<1>(ss), s2 = quad_bcast<2>(ss), s3 = quad_bcast<3>(ss);
+        ss = ((s0 + s1) + s2) + s3;
     }
     const double dn = (used || pos >= 0) ? -INFINITY : di - ss;
     if (live) {
 #pragma unroll
-        for (int j = 0; j < 64; ++j) Y[((int64_t)64 * b + j) * mp + i] = y[j];
-        dg[i] = dn;
+        for (int jl = 0; jl < 16; ++jl) Y[((int64_t)64 * b + 4 * jl + rho) * mp + i] = y[jl];
+        if (rho == 0) dg[i] = dn;
     }
-    __shared__ double sv[PC_T / 64];
-    __shared__ int si[PC_T / 64];
+    __shared__ double sv[4 * PC_T / 64];
+    __shared__ int si[4 * PC_T / 64];
     double wv = live ? dn : -INFINITY;
     int wi = live ? (int)i : 0x7fffffff;
 #pragma unroll
@@ -1258,15 +1331,15 @@ __global__ __launch_bounds__(PC_T) void pchol_panel_rows_kernel(const double* __
         }
     }
     if (lane == 0) {
-        sv[tid >> 6] = wv;
-        si[tid >> 6] = wi;
+        sv[wave] = wv;
+        si[wave] = wi;
     }
     __syncthreads();
     if (tid == 0) {
         double v = sv[0];
         int ix = si[0];
 #pragma unroll
-        for (int w = 1; w < PC_T / 64; ++w)
+        for (int w = 1; w < 4 * PC_T / 64; ++w)
             if (sv[w] > v || (sv[w] == v && si[w] < ix)) {
                 v = sv[w];
                 ix = si[w];
@@ -2096,7 +2169,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         int hsweeps = 0;
         unsigned int hrot2 = 1;
         while (hsweeps < std::max(2, max_sweeps / 12)) {  // each launch runs up to 12 sweeps
-            MVF_CHECK_HIP(hipMemsetAsync(rot, 0, sizeof(unsigned int), st));
+            MVF_CHECK_HIP(hipMemsetAsync(rot, 0, 256, st));  // the counter and the per-sweep diagnostics behind it
             hipLaunchKernelGGL(jac_gram_kernel, dim3(1u, 1u), dim3(256), 0, st, Yh, (int64_t)b, hnb, 0, 1, 1, mod, hclean, Spart);
             // (the first launch starts from the previous call's total rotation when that call was a direct one; a second
             // launch - never seen - would continue from the rotated factor and must start cold)
@@ -2141,6 +2214,11 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             fprintf(stderr, "[mvf_solve_minnorm_lrd] m %lld direct form: %.2f ms (%s block, %d launch(es) of the 64 x 64 Rayleigh-Ritz, %d below the cut, info %d, state %d, lambda_max %s)%s\n",
                     (long long)m, t03, prev_direct ? "continued" : "fresh", hsweeps, (int)he[4], hinfo2, hflag,
                     lmax_ok ? "converged" : "NOT converged", ok ? "" : " -> factor form");
+            unsigned int hsw[24];
+            (void)hipMemcpy(hsw, rot + 8, sizeof(hsw), hipMemcpyDeviceToHost);
+            fprintf(stderr, "    Rayleigh-Ritz sweeps (active rounds / rotations):");
+            for (int q = 0; q < 12; ++q) fprintf(stderr, " %u/%u", hsw[2 * q], hsw[2 * q + 1]);
+            fprintf(stderr, "\n");
             for (auto& e : ev) (void)hipEventDestroy(e);
         }
         if (ok) {
@@ -2179,7 +2257,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         for (int b = 0; b < npan; ++b) {
             hipLaunchKernelGGL(pchol_panel_factor_kernel, dim3(1), dim3(256), 0, st, S, m, mp, hint, rank_hint, b, dg, stt,
                                order, piv, Lcc, candb);
-            hipLaunchKernelGGL(pchol_panel_rows_kernel, dim3((unsigned)p.nwg), dim3(PC_T), 0, st, S, Y, mp, b, dg, pm, stt,
+            hipLaunchKernelGGL(pchol_panel_rows_kernel, dim3((unsigned)p.nwg), dim3(4 * PC_T), 0, st, S, Y, mp, b, dg, pm, stt,
                                Lcc, candb);
             hipLaunchKernelGGL(pchol_update_kernel, ugrid, dim3(256), 0, st, S, Y, mp, 64 * b, stt, b + 1);
         }
@@ -2311,26 +2389,41 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             MVF_CHECK_HIP(hipMemsetAsync(mod, 0, (size_t)(hnb + (size_t)hnb * hnb) * sizeof(int), st));
             hsweeps = 0;
             hrot2 = 1;
-            while (hsweeps < max_sweeps) {
-                MVF_CHECK_HIP(hipMemsetAsync(rot, 0, sizeof(unsigned int), st));
-                for (int rd = 0; rd < hnb - 1; ++rd) {
-                    const int stamp = 1 + hsweeps * (hnb - 1) + rd;
-                    hipLaunchKernelGGL(jac_gram_kernel, dim3((unsigned)hnp, (unsigned)hnk), dim3(256), 0, st, Yh, (int64_t)b,
-                                       hnb, rd, hnk, 1, mod, hclean, Spart);
-                    if (rd == 0)  // (a 64-vector block is ONE pair: all its sweeps run inside this launch)
-                        hipLaunchKernelGGL(jac_eig_kernel<true>, dim3((unsigned)hnp), dim3(EIG_THREADS), 0, st, Spart, hnk,
-                                           htol, hnb, rd, stamp, mod, hclean, Jbuf, flags, rot, hnb == 2 ? 12 : 1);
-                    else
-                        hipLaunchKernelGGL(jac_eig_kernel<false>, dim3((unsigned)hnp), dim3(EIG_THREADS), 0, st, Spart, hnk,
-                                           htol, hnb, rd, stamp, mod, hclean, Jbuf, flags, rot);
-                    hipLaunchKernelGGL(jac_update_kernel, dim3((unsigned)hnp, (unsigned)(b / 64)), dim3(256), 0, st, Yh,
-                                       (int64_t)b, hnb, rd, Jbuf, flags);
-                }
+            // Sweeps are enqueued in batches - eight, then two at a time - with one rotation counter per sweep and ONE status
+            // read per batch (round 5 read the counter after every sweep: nine or ten host round trips of ~40 us in a
+            // 128-vector Rayleigh-Ritz).  Behind the sweep that converges every pair is clean, so the rest of its batch
+            // returns at once (pair_is_clean) and changes nothing: the result and the reported sweep count are those of
+            // the one-by-one loop.
+            while (hsweeps < max_sweeps && hrot2 != 0) {
+                const int batch = hnb == 2 ? 1 : std::min(max_sweeps - hsweeps, hsweeps == 0 ? 8 : 2);
+                MVF_CHECK_HIP(hipMemsetAsync(rot, 0, 8 * sizeof(unsigned int), st));
+                for (int sb = 0; sb < batch; ++sb)
+                    for (int rd = 0; rd < hnb - 1; ++rd) {
+                        const int stamp = 1 + (hsweeps + sb) * (hnb - 1) + rd;
+                        hipLaunchKernelGGL(jac_gram_kernel, dim3((unsigned)hnp, (unsigned)hnk), dim3(256), 0, st, Yh, (int64_t)b,
+                                           hnb, rd, hnk, 1, mod, hclean, Spart);
+                        if (rd == 0)  // (a 64-vector block is ONE pair: all its sweeps run inside this launch)
+                            hipLaunchKernelGGL(jac_eig_kernel<true>, dim3((unsigned)hnp), dim3(EIG_THREADS), 0, st, Spart, hnk,
+                                               htol, hnb, rd, stamp, mod, hclean, Jbuf, flags, rot + sb, hnb == 2 ? 12 : 1);
+                        else
+                            hipLaunchKernelGGL(jac_eig_kernel<false>, dim3((unsigned)hnp), dim3(EIG_THREADS), 0, st, Spart, hnk,
+                                               htol, hnb, rd, stamp, mod, hclean, Jbuf, flags, rot + sb);
+                        hipLaunchKernelGGL(jac_update_kernel, dim3((unsigned)hnp, (unsigned)(b / 64)), dim3(256), 0, st, Yh,
+                                           (int64_t)b, hnb, rd, Jbuf, flags);
+                    }
                 MVF_LAUNCH_CHECK();
-                ++hsweeps;
-                MVF_CHECK_HIP(hipMemcpyAsync(&hrot2, rot, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+                unsigned int hb[8];
+                MVF_CHECK_HIP(hipMemcpyAsync(hb, rot, sizeof(hb), hipMemcpyDeviceToHost, st));
                 MVF_CHECK_HIP(hipStreamSynchronize(st));
-                if (hrot2 == 0) break;
+                int done_at = -1;
+                for (int sb = 0; sb < batch && done_at < 0; ++sb)
+                    if (hb[sb] == 0) done_at = sb;
+                if (done_at >= 0) {
+                    hsweeps += done_at + 1;
+                    hrot2 = 0;
+                } else {
+                    hsweeps += batch;
+                }
             }
             hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, Yh, (int64_t)b, (int64_t)b,
                                (int64_t)b, R, 0, theta, dummy);
@@ -2415,26 +2508,36 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
     MVF_CHECK_HIP(hipMemsetAsync(mod, 0, (size_t)(nb + (size_t)nb * nb) * sizeof(int), st));  // all pairs dirty
     int sweeps = 0;
     unsigned int hrot = 1;
-    while (sweeps < max_sweeps) {
-        MVF_CHECK_HIP(hipMemsetAsync(rot, 0, sizeof(unsigned int), st));
-        for (int rd = 0; rd < nb - 1; ++rd) {
-            const int stamp = 1 + sweeps * (nb - 1) + rd;
-            hipLaunchKernelGGL(jac_gram_kernel, dim3((unsigned)npairs, (unsigned)nsplit), dim3(256), 0, st, Y, mp, nb, rd,
-                               nsplit, kchunks, mod, clean, Spart);
-            if (rd == 0)
-                hipLaunchKernelGGL(jac_eig_kernel<true>, dim3((unsigned)npairs), dim3(EIG_THREADS), 0, st, Spart, nsplit,
-                                   tol, nb, rd, stamp, mod, clean, Jbuf, flags, rot);
-            else
-                hipLaunchKernelGGL(jac_eig_kernel<false>, dim3((unsigned)npairs), dim3(EIG_THREADS), 0, st, Spart, nsplit,
-                                   tol, nb, rd, stamp, mod, clean, Jbuf, flags, rot);
-            hipLaunchKernelGGL(jac_update_kernel, dim3((unsigned)npairs, (unsigned)(mp / 64)), dim3(256), 0, st, Y, mp, nb,
-                               rd, Jbuf, flags);
-        }
+    while (sweeps < max_sweeps && hrot != 0) {  // batches of sweeps, one status read per batch (see the deflated solve above)
+        const int batch = std::min(max_sweeps - sweeps, sweeps == 0 ? 8 : 2);
+        MVF_CHECK_HIP(hipMemsetAsync(rot, 0, 8 * sizeof(unsigned int), st));
+        for (int sb = 0; sb < batch; ++sb)
+            for (int rd = 0; rd < nb - 1; ++rd) {
+                const int stamp = 1 + (sweeps + sb) * (nb - 1) + rd;
+                hipLaunchKernelGGL(jac_gram_kernel, dim3((unsigned)npairs, (unsigned)nsplit), dim3(256), 0, st, Y, mp, nb, rd,
+                                   nsplit, kchunks, mod, clean, Spart);
+                if (rd == 0)
+                    hipLaunchKernelGGL(jac_eig_kernel<true>, dim3((unsigned)npairs), dim3(EIG_THREADS), 0, st, Spart, nsplit,
+                                       tol, nb, rd, stamp, mod, clean, Jbuf, flags, rot + sb);
+                else
+                    hipLaunchKernelGGL(jac_eig_kernel<false>, dim3((unsigned)npairs), dim3(EIG_THREADS), 0, st, Spart, nsplit,
+                                       tol, nb, rd, stamp, mod, clean, Jbuf, flags, rot + sb);
+                hipLaunchKernelGGL(jac_update_kernel, dim3((unsigned)npairs, (unsigned)(mp / 64)), dim3(256), 0, st, Y, mp, nb,
+                                   rd, Jbuf, flags);
+            }
         MVF_LAUNCH_CHECK();
-        ++sweeps;
-        MVF_CHECK_HIP(hipMemcpyAsync(&hrot, rot, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        unsigned int hb[8];
+        MVF_CHECK_HIP(hipMemcpyAsync(hb, rot, sizeof(hb), hipMemcpyDeviceToHost, st));
         MVF_CHECK_HIP(hipStreamSynchronize(st));
-        if (hrot == 0) break;
+        int done_at = -1;
+        for (int sb = 0; sb < batch && done_at < 0; ++sb)
+            if (hb[sb] == 0) done_at = sb;
+        if (done_at >= 0) {
+            sweeps += done_at + 1;
+            hrot = 0;
+        } else {
+            sweeps += batch;
+        }
     }
 
     // 3. truncated minimum-norm solve

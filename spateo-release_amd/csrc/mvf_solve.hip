@@ -15,10 +15,10 @@
 // out of trsm/syrk for free; the back substitution L^T C = Y is one small kernel per block column.
 #include "mvf_common.h"
 #include "mvf_solve.h"
+#include "mvf_chol_dev.h"
 
 namespace mvf {
 
-constexpr int NB = CHOL_NB;
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // mean of the diagonal of G + ls2*K  ->  scal[0];  scal[1] = jitter * mean
@@ -75,14 +75,6 @@ __global__ __launch_bounds__(256) void chol_prepare_kernel(const double* __restr
 // Columns are scaled by 1 / sqrt(d_j) at the end; rdiag gets 1 / L_jj for the triangular solves.  The column loop is rolled
 // inside each 16-column group (the group index must be static for the register tile; straight-line code of a
 // one-workgroup kernel is paid for in instruction-cache misses).
-constexpr int LDU = NB + 1;  // LDS stride of the published columns
-
-__device__ __forceinline__ double rcp_nr2(double x) {
-    double y = __builtin_amdgcn_rcp(x);
-    y = fma(fma(-x, y, 1.0), y, y);
-    return fma(fma(-x, y, 1.0), y, y);
-}
-
 template <int JQ>
 __device__ __forceinline__ void potrf_group(double (&r)[4][4], double (*Lu)[LDU], double* dg, int tx, int ty, int k,
                                             int* __restrict__ info) {
@@ -147,12 +139,8 @@ __device__ __forceinline__ void potrf64_store(const double (*Lu)[LDU], const dou
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int i = ty + 16 * p;
-            // a / l as a * (1 / l) with one correction step: the quotient to within an ulp of the correctly rounded one
             // (16 IEEE divisions per thread would sit on the factorisation's serial path)
-            const double a = Lu[c][i];
-            const double q0 = a * rl;
-            const double q = fma(fma(-q0, l, a), rl, q0);
-            blk[(int64_t)i * mp + c] = (c < i) ? q : (c == i ? l : 0.0);
+            blk[(int64_t)i * mp + c] = (c < i) ? div_by(Lu[c][i], l, rl) : (c == i ? l : 0.0);
             if (c == i) rdiag_k[c] = rl;
         }
     }
@@ -183,41 +171,6 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ W,
 // consecutive (ds_read_b128), entries that must not change are multiplied by zero - no predicates - and the owner's x_c
 // register keeps a_c - sum (scaled once more, bit-identically, at the end).  Fully unrolled: every register index is
 // static (the round-5 kernel indexed its register tile dynamically inside a rolled loop: 32 us per launch).
-template <int O>
-__device__ __forceinline__ double quad_bcast(double v) {
-    constexpr int ctrl = O | (O << 2) | (O << 4) | (O << 6);  // quad_perm: every lane of the quad reads lane O
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), ctrl, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), ctrl, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-constexpr int TLQ = 18;           // doubles per (column, lane-of-quad) slot: 16 used, the pad de-phases the four lanes' banks
-constexpr int TLC = 4 * TLQ + 2;  // doubles per column c (the odd multiple of 2 keeps the transposing store conflict-free)
-
-// step C with the operands of step C + 1 (their LDS reads) issued before its arithmetic: the chain of a step is
-// multiply - two DPP moves - multiply-subtract, and an LDS round trip per step would triple it
-template <int C>
-__device__ __forceinline__ void trsm_steps(double (&x)[16], const double* __restrict__ ls_rho, const double* __restrict__ rd,
-                                           const double2 (&cur)[8], double rdc) {
-    constexpr int G = C / 4, O = C % 4;
-    double2 nxt[8];
-    double rdn = 0.0;
-    if constexpr (C + 1 < NB) {
-        const double2* ln = reinterpret_cast<const double2*>(ls_rho + (C + 1) * TLC);
-#pragma unroll
-        for (int h = (C + 1) / 8; h < 8; ++h) nxt[h] = ln[h];
-        rdn = rd[C + 1];
-    }
-    const double xc = quad_bcast<O>(x[G] * rdc);  // meaningful on the owning lane (rho == O), read from it
-#pragma unroll
-    for (int h = G / 2; h < 8; ++h) {
-        x[2 * h] = fma(-xc, cur[h].x, x[2 * h]);
-        x[2 * h + 1] = fma(-xc, cur[h].y, x[2 * h + 1]);
-    }
-    if constexpr (C + 1 < NB) trsm_steps<C + 1>(x, ls_rho, rd, nxt, rdn);
-}
-
 __global__ __launch_bounds__(256) void trsm_panel_kernel(double* __restrict__ W, int64_t mp, int64_t mr, int k,
                                                          const double* __restrict__ rdiag) {
     __shared__ __align__(16) double Ls[NB * TLC];

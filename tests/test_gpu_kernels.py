@@ -519,12 +519,14 @@ def test_deflated_solve_small_factor_uses_a_64_vector_block(st, n, m):
     dd = np.abs(U @ (C1r - F1)).max() / sc
     print(f"    direct form ({'taken' if int(e0[6]) == m else 'not applicable: factor rank < m'}) vs factor form on the hinted "
           f"call: {dd:.2e}; kept {int(e1r[1])} vs {int(g1[1])}")
-    assert int(e1r[1]) == int(g1[1]) and int(e1r[6]) == int(g1[6]) and dd < max(0.1 * floor, 1e-7)
+    # (absolute term 3e-7: on the m = 300 system - nothing truncated, the reference's own lstsq-vs-eigh floor 1.3e-7 - the two
+    # forms land 0.9 - 2.0e-7 apart depending on the summation order inside the Cholesky kernels: three builds of round 6)
+    assert int(e1r[1]) == int(g1[1]) and int(e1r[6]) == int(g1[6]) and dd < max(0.1 * floor, 3e-7)
     assert _relmax(C1b, 2.0 * C1r[:, :2]) < 1e-11 and _relmax(F1b, 2.0 * F1[:, :2]) < 1e-11
     assert np.abs(U @ (C1r - C1)).max() / sc < max(0.1 * floor, 1e-7)   # third call (same order, warm state) = second call
     assert int(e0[1]) == int(f0[1]) and int(e1[1]) == int(f1[1]) and abs(int(e1[1]) - int(keep.sum())) <= max(2, m // 50)
     assert np.abs(U @ C1 - F).max() / sc < max(2.0 * floor, 1e-9) and np.abs(U @ C0 - F).max() / sc < max(2.0 * floor, 1e-9)
-    assert d0 < max(0.1 * floor, 1e-7) and d1 < max(0.1 * floor, 1e-7)
+    assert d0 < max(0.1 * floor, 1e-7) and d1 < max(0.1 * floor, 3e-7)   # (d1: the direct form where it applies, see above)
     np.testing.assert_allclose(e0[2], w.max(), rtol=1e-6)
     np.testing.assert_allclose(e1[2], w.max(), rtol=1e-6)
     np.testing.assert_allclose(f1[2], w.max(), rtol=1e-6)     # the Jacobi path's hinted call is warm-started too
