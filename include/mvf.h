@@ -53,7 +53,7 @@ enum {
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
 const char* mvf_last_error(void);
-int mvf_version(void);                 /* ABI version, currently 5 */
+int mvf_version(void);                 /* ABI version, currently 6 */
 /* Developer options, process-wide: which kernel variant / launch plan is taken in A/B measurements and in the tests that
  * compare the variants bit for bit.  The library NEVER reads the environment (rounds 1 - 3 had getenv knobs in launch
  * paths); nothing but this call changes its behaviour.  value 0 = default.  Names: "conk_form" (1 rows, 2 flat, 3 2d),
@@ -260,11 +260,27 @@ int mvf_solve_minnorm_lr(const double* G, const double* K, double lambda_sigma2,
  * the field).  Accepted only if every pivot clears tolf * eps * lambda_max, lambda_max has converged and at most 40 Ritz values
  * lie below the cut; anything else re-runs the call in the factor form above.  The workspace then holds the unchanged pivot
  * order (mvf_lr_pivot_order works), einfo[0] = Rayleigh-Ritz launches (1), einfo[6] = m, einfo[7] = 64; reuse works.  Measured
- * at m = 500: 1.5 ms against 2.5 ms for the factor form and 3.6 ms for mvf_solve_minnorm. */
+ * at m = 500: 1.5 ms against 2.5 ms for the factor form and 3.6 ms for mvf_solve_minnorm (round 6: 0.9 ms).
+ * einfo[8] (ABI 6) names the form that answered: 0 = the Jacobi path, 1 = the factor form, 2 = the direct form; einfo[9] = 0.
+ *
+ * mvf_solve_minnorm_lrd_async (ABI 6): the direct form WITHOUT a single host synchronisation - the synchronous entry point
+ * reads the workspace state before it launches, the Rayleigh-Ritz counter and the acceptance numbers after (three round
+ * trips of ~40 us in a 0.9 ms call, and the host cannot run ahead of the device across any of them).  The caller says what it
+ * knows from the previous call's einfo ON THIS WORKSPACE: form_hint = 1: that call returned einfo[6] == m (all m columns
+ * kept) through the factor form, 2: through the direct form (its block is continued).  The device verifies the state
+ * (a stale or foreign workspace, a pending cool-down: not accepted) and takes the acceptance decision itself (every pivot
+ * above the tolerance, lambda_max settled after the five warm power steps, the 64 x 64 Rayleigh-Ritz converged inside its one
+ * launch, at most 40 directions below the cut): einfo[9] = 0: accepted - C, einfo[0..8] and the workspace exactly as the
+ * synchronous direct form leaves them; einfo[9] = 1: NOT accepted - C is undefined and the caller must repeat the call
+ * through mvf_solve_minnorm_lrd (the workspace carries the cool-down mark, so that call goes to the factor form at once).
+ * Asynchronous on `stream`; einfo / info are read by the caller in its own device -> host copy.  128 <= m <= 640. */
 size_t mvf_solve_minnorm_lrd_workspace_bytes(int64_t m, int nrhs);
 int mvf_solve_minnorm_lrd(const double* G, const double* K, double lambda_sigma2, double tolf, double rcond,
                           const double* R, int64_t m, int nrhs, double* C, int* info, double* einfo, int max_sweeps,
                           int reuse, int rank_hint, void* workspace, size_t workspace_bytes, void* stream);
+int mvf_solve_minnorm_lrd_async(const double* G, const double* K, double lambda_sigma2, double tolf, double rcond,
+                                const double* R, int64_t m, int nrhs, double* C, int* info, double* einfo, int form_hint,
+                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* The pivot order of the factorisation the last mvf_solve_minnorm_lr call left in `workspace` (same m): order_out (HOST,
  * room for m ints) receives the r pivots in the order they were taken, *r_out = r.  These are the control points that

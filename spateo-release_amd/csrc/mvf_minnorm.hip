@@ -59,9 +59,14 @@ __device__ __forceinline__ void rr_pair(int n, int r, int k, int& a, int& b) {
 
 // Y (mp x mp row-major) = L^T with everything outside the leading m x m lower triangle zeroed: Y[j][i] = L[i][j]
 __global__ __launch_bounds__(256) void jac_init_kernel(const double* __restrict__ W, int64_t m, int64_t mp,
-                                                       double* __restrict__ Y) {
+                                                       double* __restrict__ Y, int* __restrict__ zero_a = nullptr, int na = 0,
+                                                       unsigned int* __restrict__ zero_b = nullptr, int nzb = 0) {
     __shared__ double t[64][65];
     const int bi = blockIdx.y, bj = blockIdx.x;  // tile of L: rows bi*64.., columns bj*64..
+    if (bi == 0 && bj == 0) {  // the caller's Jacobi bookkeeping (stamps, rotation counters): saves two memset launches
+        for (int e = threadIdx.x; e < na; e += 256) zero_a[e] = 0;
+        for (int e = threadIdx.x; e < nzb; e += 256) zero_b[e] = 0u;
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int r = ty; r < 64; r += 4) {
         const int64_t i = (int64_t)bi * 64 + r, j = (int64_t)bj * 64 + tx;
@@ -629,9 +634,11 @@ __global__ __launch_bounds__(256) void jac_back_reduce_kernel(const double* __re
 
 // Afull (mp x mp) = G + ls2 K on the leading m x m, zero on the padding
 __global__ __launch_bounds__(256) void assemble_kernel(const double* __restrict__ G, const double* __restrict__ K,
-                                                       double ls2, int64_t m, int64_t mp, double* __restrict__ A) {
+                                                       double ls2, int64_t m, int64_t mp, double* __restrict__ A,
+                                                       double* __restrict__ zero32 = nullptr) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = blockIdx.y;
+    if (zero32 != nullptr && i == 0 && j < 32) zero32[j] = 0.0;  // (a 256-byte scalar slot of the caller: saves its memset launch)
     if (j >= mp) return;
     A[i * mp + j] = (i < m && j < m) ? G[i * m + j] + ls2 * K[i * m + j] : 0.0;
 }
@@ -1121,45 +1128,79 @@ __global__ __launch_bounds__(256) void pchol_update_kernel(double* __restrict__ 
 // barrier per column, Newton reciprocal of the pivot, unpredicated rank-1 update with the next column first), stopping at
 // the first pivot that fails the threshold: columns 0 .. nvalid - 1 of Lu are then the accepted ones.
 template <int JQ>
-__device__ __forceinline__ bool panel_potrf_group(double (&r)[4][4], double (*Lu)[LDU], double* dgs, int tx, int ty,
-                                                  double thr, int n, int& nvalid) {
+__device__ __forceinline__ bool panel_potrf_group(double (&r)[4][4], double (*Lu)[LDU], double (*Pub)[2][NB], double* dgs,
+                                                  int& pb, int tx, int ty, double thr, int n, int& nvalid) {
     if (16 * JQ >= n) return false;
-    if (tx == 0) {
+    if (tx < 2) {
 #pragma unroll
-        for (int p = JQ; p < 4; ++p) Lu[16 * JQ][ty + 16 * p] = r[p][JQ];
+        for (int p = JQ; p < 4; ++p) Pub[pb][tx][ty + 16 * p] = r[p][JQ];
+        if (tx == 0) {
+#pragma unroll
+            for (int p = JQ; p < 4; ++p) Lu[16 * JQ][ty + 16 * p] = r[p][JQ];
+        }
     }
     __syncthreads();
 #pragma unroll 1
-    for (int jx = 0; jx < 16; ++jx) {
+    for (int jx = 0; jx < 16; jx += 2) {  // two columns per step, as potrf64
         const int j = 16 * JQ + jx;
         if (j >= n) return false;
-        const double* cb = Lu[j];
-        const double d = cb[j];
-        double ci[4], cc[4];
+        const double* u0 = Pub[pb][0];
+        const double* u1 = Pub[pb][1];
+        const double d0 = u0[j], e = u0[j + 1], g = u1[j + 1];
+        double c0r[4], c0c[4], c1r[4], c1c[4];
 #pragma unroll
         for (int p = JQ; p < 4; ++p) {
-            ci[p] = cb[ty + 16 * p];
-            cc[p] = cb[tx + 16 * p];
+            c0r[p] = u0[ty + 16 * p];
+            c0c[p] = u0[tx + 16 * p];
+            c1r[p] = u1[ty + 16 * p];
+            c1c[p] = u1[tx + 16 * p];
         }
-        if (!(d > thr && d <= 1.79e308)) {  // uniform: every thread reads the same pivot
+        if (!(d0 > thr && d0 <= 1.79e308)) {  // uniform: every thread reads the same pivot
             nvalid = j;
             return false;
         }
-        if (threadIdx.x == 0) dgs[j] = d;
-        const double inv = rcp_nr2(d);
+        const double t1 = fma(g, d0, -(e * e));  // 1 / d1 = d0 / (g d0 - e^2): two independent reciprocal chains (potrf64)
+        const double inv0 = rcp_nr2(d0);
+        const double inv1 = d0 * rcp_nr2(t1);
+        const double d1 = t1 * inv0;
+        const bool ok1 = j + 1 < n && d1 > thr && d1 <= 1.79e308;
+        if (threadIdx.x == 0) {
+            dgs[j] = d0;
+            if (ok1) dgs[j + 1] = d1;
+        }
+        if (!ok1) {  // column j is accepted (it sits in Lu[j] since its publication), column j + 1 is not
+            nvalid = min(j + 1, n);
+            return false;
+        }
+        double l0[4], l1[4];
 #pragma unroll
-        for (int p = JQ; p < 4; ++p) ci[p] *= inv;
+        for (int p = JQ; p < 4; ++p) {
+            l0[p] = c0r[p] * inv0;
+            c1r[p] = fma(-l0[p], e, c1r[p]);
+            c1c[p] = fma(-(c0c[p] * inv0), e, c1c[p]);
+            l1[p] = c1r[p] * inv1;
+        }
 #pragma unroll
-        for (int p = JQ; p < 4; ++p) r[p][JQ] = fma(-ci[p], cc[JQ], r[p][JQ]);
+        for (int p = JQ; p < 4; ++p) r[p][JQ] = fma(-l1[p], c1c[JQ], fma(-l0[p], c0c[JQ], r[p][JQ]));
         if (tx == jx + 1) {
 #pragma unroll
-            for (int p = JQ; p < 4; ++p) Lu[j + 1][ty + 16 * p] = r[p][JQ];
+            for (int p = JQ; p < 4; ++p) Lu[j + 1][ty + 16 * p] = c1r[p];
+        }
+        if (tx == jx + 2 || tx == jx + 3) {
+            const int w = tx - jx - 2;
+#pragma unroll
+            for (int p = JQ; p < 4; ++p) Pub[pb ^ 1][w][ty + 16 * p] = r[p][JQ];
+            if (w == 0) {
+#pragma unroll
+                for (int p = JQ; p < 4; ++p) Lu[j + 2][ty + 16 * p] = r[p][JQ];
+            }
         }
 #pragma unroll
         for (int q = JQ + 1; q < 4; ++q)
 #pragma unroll
-            for (int p = q; p < 4; ++p) r[p][q] = fma(-ci[p], cc[q], r[p][q]);
+            for (int p = q; p < 4; ++p) r[p][q] = fma(-l1[p], c1c[q], fma(-l0[p], c0c[q], r[p][q]));
         __syncthreads();
+        pb ^= 1;
     }
     return true;
 }
@@ -1170,6 +1211,7 @@ __global__ __launch_bounds__(256) void pchol_panel_factor_kernel(const double* _
                                                                  int* __restrict__ order, double* __restrict__ piv,
                                                                  double* __restrict__ Lcc, int* __restrict__ cand_out) {
     __shared__ double Lu[64][LDU];
+    __shared__ double Pub[2][2][NB];
     __shared__ double dgs[64];
     __shared__ int cand[64];
     __shared__ double red[4];
@@ -1216,10 +1258,11 @@ __global__ __launch_bounds__(256) void pchol_panel_factor_kernel(const double* _
         }
     const double thr = fmax(PCHOL_THETA * dmax, tol);
     int nvalid = n;
-    if (panel_potrf_group<0>(r, Lu, dgs, tx, ty, thr, n, nvalid))
-        if (panel_potrf_group<1>(r, Lu, dgs, tx, ty, thr, n, nvalid))
-            if (panel_potrf_group<2>(r, Lu, dgs, tx, ty, thr, n, nvalid))
-                panel_potrf_group<3>(r, Lu, dgs, tx, ty, thr, n, nvalid);
+    int pb = 0;
+    if (panel_potrf_group<0>(r, Lu, Pub, dgs, pb, tx, ty, thr, n, nvalid))
+        if (panel_potrf_group<1>(r, Lu, Pub, dgs, pb, tx, ty, thr, n, nvalid))
+            if (panel_potrf_group<2>(r, Lu, Pub, dgs, pb, tx, ty, thr, n, nvalid))
+                panel_potrf_group<3>(r, Lu, Pub, dgs, pb, tx, ty, thr, n, nvalid);
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1471,7 +1514,7 @@ __global__ __launch_bounds__(256) void defl_sub_kernel(const double* __restrict_
 // DEFL_TINY_ACCEPT Ritz values lie below the cut; anything else re-runs the call in the factor form.
 __global__ __launch_bounds__(256) void direct_prepare_kernel(const double* __restrict__ S, int64_t m, int64_t mp, double tolf,
                                                              PcholState* __restrict__ stt, int* __restrict__ info,
-                                                             int* __restrict__ dflag) {
+                                                             int* __restrict__ dflag, int form_hint) {
     __shared__ double red[4];
     double mx = 0.0;
     bool finite = true;
@@ -1492,29 +1535,15 @@ __global__ __launch_bounds__(256) void direct_prepare_kernel(const double* __res
         info[0] = ok ? 0 : 1;
         // the pivot order in the workspace must be that of a finished factorisation of ALL m columns (magic / order_len stay
         // untouched: the factor form, if it has to answer, reads them for its own hint)
-        const int valid = (ok && stt->magic == PCHOL_MAGIC_V && stt->order_len == (int)m) ? 1 : 0;
+        int valid = (ok && stt->magic == PCHOL_MAGIC_V && stt->order_len == (int)m) ? 1 : 0;
+        // the asynchronous entry point (form_hint != 0) took the host's word for what the previous call left here and has
+        // launched accordingly: the state must really be that (no cool-down pending; 2 = a complete direct-form call)
+        if (form_hint != 0 && stt->direct_skip != 0) valid = 0;
+        if (form_hint == 2 && !(stt->defl == 2 && stt->pad4 == 1 && stt->defl_block == DEFL_TINY)) valid = 0;
         dflag[0] = valid;
         // the kept Rayleigh-Ritz rotation is that of the previous call only if that call was answered by the direct form
         dflag[1] = (valid && stt->defl == 2 && stt->pad4 == 1) ? 1 : 0;
     }
-}
-
-// A[i][j] = S[order[i]][order[j]] (zero padding to rp); the identity order when the state was not valid (the result is then
-// discarded, but nothing is read out of bounds)
-__global__ __launch_bounds__(256) void perm_gather_kernel(const double* __restrict__ S, int64_t mp, const int* __restrict__ order,
-                                                          int64_t m, int64_t rp, const int* __restrict__ dflag,
-                                                          double* __restrict__ A) {
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
-    if (j >= rp) return;
-    double v = 0.0;
-    if (i < m && j < m) {
-        const bool ok = dflag[0] != 0;
-        int64_t oi = ok ? order[i] : i, oj = ok ? order[j] : j;
-        if (oi < 0 || oi >= m) oi = i;
-        if (oj < 0 || oj >= m) oj = j;
-        v = S[oi * mp + oj];
-    }
-    A[i * rp + j] = v;
 }
 
 // piv[j] = Rc_jj^2 (what the pivoted factorisation records); the direct form is void unless every pivot clears the tolerance
@@ -1575,6 +1604,44 @@ __global__ void direct_finish_kernel(PcholState* __restrict__ stt, double* __res
     einfo[4] = 0.0;
     einfo[6] = (double)m;
     einfo[7] = (double)b;
+    einfo[8] = 2.0;  // answered by the direct form
+    einfo[9] = 0.0;
+}
+
+// mvf_solve_minnorm_lrd_async: the acceptance test of the direct form ON THE DEVICE (the synchronous entry point copies
+// the same eleven numbers to the host and decides there) + the closing state.  Not accepted: einfo[9] = 1, the workspace
+// keeps its pivot order and gets the cool-down mark, so that the caller's repeat through mvf_solve_minnorm_lrd goes to the
+// factor form at once.
+__global__ void direct_close_kernel(PcholState* __restrict__ stt, double* __restrict__ einfo, const int* __restrict__ info,
+                                    const int* __restrict__ dflag, const unsigned int* __restrict__ rot, int m, int b,
+                                    double accept_n) {
+    const double q_est = stt->lmax_est, q_prev = stt->lmax_prev;
+    const bool lmax_ok = fabs(q_est - q_prev) <= 1e-7 * q_est || q_est == stt->maxdiag;
+    const bool ok = info[0] == 0 && dflag[0] == 1 && rot[0] == 0u && lmax_ok && einfo[4] <= accept_n &&
+                    fabs(einfo[5]) <= 1.79e308 && einfo[5] > 0.0;
+    if (ok) {
+        const int nsel = (int)einfo[4];
+        stt->done = 1;
+        stt->r = m;
+        stt->magic = PCHOL_MAGIC_V;
+        stt->order_len = m;
+        stt->keep_len = m;
+        stt->defl = 2;
+        stt->defl_block = b;
+        stt->pad4 = 1;
+        stt->defl_nsel = nsel;
+        stt->direct_skip = 0;
+        einfo[0] = 1.0;
+        einfo[4] = 0.0;
+        einfo[6] = (double)m;
+        einfo[7] = (double)b;
+        einfo[8] = 2.0;
+        einfo[9] = 0.0;
+    } else {
+        if (stt->direct_skip == 0) stt->direct_skip = 4;  // (a cool-down that is already running keeps its count)
+        einfo[8] = 2.0;
+        einfo[9] = 1.0;
+    }
 }
 
 // T[i][0..8) = R[order[i]][0..nrhs) (zero padded), and back: C[order[i]][d] = T[i][d]
@@ -1918,7 +1985,8 @@ extern "C" size_t mvf_solve_minnorm_lr_workspace_bytes(int64_t m, int nrhs) {
 
 static int lr_solve(const double* G, const double* K, double lambda_sigma2, double tolf, double rcond, const double* R,
                     int64_t m, int nrhs, double* C, int* info, double* einfo, int max_sweeps, int reuse, int rank_hint,
-                    void* workspace, size_t workspace_bytes, void* stream, bool deflate, bool allow_direct = true) {
+                    void* workspace, size_t workspace_bytes, void* stream, bool deflate, bool allow_direct = true,
+                    int form_hint = 0) {
     MVF_REQUIRE(m >= 0 && nrhs >= 1 && nrhs <= 8,
                 "mvf_solve_minnorm_lr: need m >= 0 and 1 <= nrhs <= 8 (got m=%lld nrhs=%d)", (long long)m, nrhs);
     MVF_REQUIRE(info && einfo, "mvf_solve_minnorm_lr: null info / einfo");
@@ -2062,8 +2130,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
 
     // 1. S = G + ls2 K (zero padding), lambda_max estimate, pivoted Cholesky -> rows 0 .. r-1 of Y
     hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)cdiv(mp, 256), (unsigned)mp), dim3(256), 0, st, G, K, lambda_sigma2,
-                       m, mp, S);
-    MVF_CHECK_HIP(hipMemsetAsync(scal, 0, 256, st));
+                       m, mp, S, scal);
     // lambda_max: power iteration.  With a rank hint it starts from the dominant eigenvector the previous call on this
     // workspace (the previous EM iteration: a nearby matrix) ended with - the Rayleigh quotient is then converged to ~1e-12
     // after 5 steps where the cold start needs 12 for 1e-8 (and, at M = 500, a second run on S2: 0.45 ms of a 3 ms solve).
@@ -2094,42 +2161,45 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         // what the previous call left (64 bytes; the stream is idle behind the power iteration's few launches by now): a
         // workspace without a finished factorisation of all m columns skips this form at once, and a previous DIRECT call
         // lets the block iteration continue from its converged block
-        PcholState hprev;
-        MVF_CHECK_HIP(hipMemcpyAsync(&hprev, stt, sizeof(hprev), hipMemcpyDeviceToHost, st));
-        MVF_CHECK_HIP(hipStreamSynchronize(st));
-        if (!(hprev.magic == PCHOL_MAGIC && hprev.order_len == (int)m)) {
-            if (timing)
-                for (auto& e : ev) (void)hipEventDestroy(e);
-            return lr_solve(G, K, lambda_sigma2, tolf, rcond, R, m, nrhs, C, info, einfo, max_sweeps, reuse, rank_hint, workspace,
-                            workspace_bytes, stream, deflate, false);
-        }
-        if (hprev.direct_skip > 0 && hprev.direct_skip <= 4) {  // a recent attempt of this form failed: not again just yet
-            const int left[1] = {hprev.direct_skip - 1};
-            MVF_CHECK_HIP(hipMemcpyAsync(&stt->direct_skip, left, sizeof(left), hipMemcpyHostToDevice, st));
+        const bool nosync = form_hint != 0;  // mvf_solve_minnorm_lrd_async: no status read anywhere in this form
+        bool prev_direct = form_hint == 2 && debug_opt(DBG_DEFL_APPS) == 0;
+        if (!nosync) {
+            PcholState hprev;
+            MVF_CHECK_HIP(hipMemcpyAsync(&hprev, stt, sizeof(hprev), hipMemcpyDeviceToHost, st));
             MVF_CHECK_HIP(hipStreamSynchronize(st));
-            if (timing)
-                for (auto& e : ev) (void)hipEventDestroy(e);
-            return lr_solve(G, K, lambda_sigma2, tolf, rcond, R, m, nrhs, C, info, einfo, max_sweeps, reuse, rank_hint, workspace,
-                            workspace_bytes, stream, deflate, false);
-        }
-        const bool prev_direct = hprev.defl == 2 && hprev.pad4 == 1 && hprev.defl_block == b &&
-                                 debug_opt(DBG_DEFL_APPS) == 0;  // (defl_apps set: the cold three-application plan, for A/B)
-        // (the same copy carries THIS call's power iteration: early in a fit the matrix still moves a lot between two calls -
-        // sigma^2 falls by an order of magnitude - and five warm steps may not have settled the Rayleigh quotient; eight more,
-        // 13 in all as on the cold path, cost 50 us where a failed attempt of this form costs 1.9 ms)
-        if (!(std::fabs(hprev.lmax_est - hprev.lmax_prev) <= 1e-7 * hprev.lmax_est)) {
-            for (int it = 0; it < 8; ++it) {
-                hipLaunchKernelGGL(lr_symv_kernel, dim3((unsigned)cdiv(mp, 4)), dim3(256), 0, st, S, mp, xv, xv + mp);
-                hipLaunchKernelGGL(lr_power_kernel, dim3(1), dim3(256), 0, st, xv, xv + mp, m, mp, 0, stt, (const double*)nullptr, 0,
-                                   it == 7 ? xkeep : (double*)nullptr);
+            if (!(hprev.magic == PCHOL_MAGIC && hprev.order_len == (int)m)) {
+                if (timing)
+                    for (auto& e : ev) (void)hipEventDestroy(e);
+                return lr_solve(G, K, lambda_sigma2, tolf, rcond, R, m, nrhs, C, info, einfo, max_sweeps, reuse, rank_hint, workspace,
+                                workspace_bytes, stream, deflate, false);
+            }
+            if (hprev.direct_skip > 0 && hprev.direct_skip <= 4) {  // a recent attempt of this form failed: not again just yet
+                const int left[1] = {hprev.direct_skip - 1};
+                MVF_CHECK_HIP(hipMemcpyAsync(&stt->direct_skip, left, sizeof(left), hipMemcpyHostToDevice, st));
+                MVF_CHECK_HIP(hipStreamSynchronize(st));
+                if (timing)
+                    for (auto& e : ev) (void)hipEventDestroy(e);
+                return lr_solve(G, K, lambda_sigma2, tolf, rcond, R, m, nrhs, C, info, einfo, max_sweeps, reuse, rank_hint, workspace,
+                                workspace_bytes, stream, deflate, false);
+            }
+            prev_direct = hprev.defl == 2 && hprev.pad4 == 1 && hprev.defl_block == b &&
+                                     debug_opt(DBG_DEFL_APPS) == 0;  // (defl_apps set: the cold three-application plan, for A/B)
+            // (the same copy carries THIS call's power iteration: early in a fit the matrix still moves a lot between two calls -
+            // sigma^2 falls by an order of magnitude - and five warm steps may not have settled the Rayleigh quotient; eight more,
+            // 13 in all as on the cold path, cost 50 us where a failed attempt of this form costs 1.9 ms)
+            if (!(std::fabs(hprev.lmax_est - hprev.lmax_prev) <= 1e-7 * hprev.lmax_est)) {
+                for (int it = 0; it < 8; ++it) {
+                    hipLaunchKernelGGL(lr_symv_kernel, dim3((unsigned)cdiv(mp, 4)), dim3(256), 0, st, S, mp, xv, xv + mp);
+                    hipLaunchKernelGGL(lr_power_kernel, dim3(1), dim3(256), 0, st, xv, xv + mp, m, mp, 0, stt, (const double*)nullptr, 0,
+                                       it == 7 ? xkeep : (double*)nullptr);
+                }
             }
         }
-        hipLaunchKernelGGL(direct_prepare_kernel, dim3(1), dim3(256), 0, st, S, m, mp, tolf, stt, info, dflag);
-        hipLaunchKernelGGL(perm_gather_kernel, dim3((unsigned)cdiv(rp, 256), (unsigned)rp), dim3(256), 0, st, S, mp, order, m, rp,
-                           dflag, Ap);
+        hipLaunchKernelGGL(direct_prepare_kernel, dim3(1), dim3(256), 0, st, S, m, mp, tolf, stt, info, dflag, form_hint);
         MVF_LAUNCH_CHECK();
         CholPlan cs, cq;
-        if (int rc = chol_factor_mat_inv(st, Ap, rp, m, dw + d.cw, &cs, info, 1)) return rc;
+        // (the permuted matrix A[order][order] is gathered straight into the factorisation's work matrix)
+        if (int rc = chol_factor_mat_inv(st, S, mp, m, dw + d.cw, &cs, info, 1, order, dflag)) return rc;
         hipLaunchKernelGGL(direct_check_kernel, dim3(1), dim3(256), 0, st, cs.rdiag, m, stt, info, piv, dflag);
         const double* E = cs.W + rp * rp;                           // Rc^-T (upper triangular, identity on the padding)
         (void)Minv;
@@ -2161,15 +2231,15 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         gemm<false, false>(st, Za, rp, Lo, rp, Zb, rp, b, rp, rp);
         gemm<false, true>(st, Zb, rp, Zb, rp, H, b, b, b, rp);
         if (int rc = chol_factor_mat_inv(st, H, b, b, dw + d.cwb, &cq, info, 0)) return rc;
-        hipLaunchKernelGGL(jac_init_kernel, dim3(1u, 1u), dim3(256), 0, st, cq.W, (int64_t)b, (int64_t)b, Yh);
         const int hnb = b / JB;  // 2: one pair
+        hipLaunchKernelGGL(jac_init_kernel, dim3(1u, 1u), dim3(256), 0, st, cq.W, (int64_t)b, (int64_t)b, Yh, mod,
+                           hnb + hnb * hnb, rot, 64);  // (+ the stamps, the rotation counter and the diagnostics behind it)
         const double htol = std::sqrt((double)b) * 2.220446049250313e-16;
         int* hclean = mod + hnb;
-        MVF_CHECK_HIP(hipMemsetAsync(mod, 0, (size_t)(hnb + (size_t)hnb * hnb) * sizeof(int), st));
         int hsweeps = 0;
         unsigned int hrot2 = 1;
         while (hsweeps < std::max(2, max_sweeps / 12)) {  // each launch runs up to 12 sweeps
-            MVF_CHECK_HIP(hipMemsetAsync(rot, 0, 256, st));  // the counter and the per-sweep diagnostics behind it
+            if (hsweeps > 0) MVF_CHECK_HIP(hipMemsetAsync(rot, 0, 256, st));
             hipLaunchKernelGGL(jac_gram_kernel, dim3(1u, 1u), dim3(256), 0, st, Yh, (int64_t)b, hnb, 0, 1, 1, mod, hclean, Spart);
             // (the first launch starts from the previous call's total rotation when that call was a direct one; a second
             // launch - never seen - would continue from the rotated factor and must start cold)
@@ -2179,6 +2249,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             hipLaunchKernelGGL(jac_update_kernel, dim3(1u, 1u), dim3(256), 0, st, Yh, (int64_t)b, hnb, 0, Jbuf, flags);
             MVF_LAUNCH_CHECK();
             ++hsweeps;
+            if (nosync) break;  // (its convergence - rot[0] == 0 - is part of the device-side acceptance test)
             MVF_CHECK_HIP(hipMemcpyAsync(&hrot2, rot, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
             MVF_CHECK_HIP(hipStreamSynchronize(st));
             if (hrot2 == 0) break;
@@ -2189,6 +2260,15 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         gemm<false, false>(st, Yh, b, Za, rp, Wsel, rp, b, rp, b);  // rows = the Ritz vectors to deflate (zero rows else)
         MVF_LAUNCH_CHECK();
         if (int rc = direct_apply(rp, b)) return rc;
+        if (nosync) {
+            const long long dacc0 = debug_opt(DBG_DIRECT_ACCEPT);
+            hipLaunchKernelGGL(direct_close_kernel, dim3(1), dim3(1), 0, st, stt, einfo, info, dflag, rot, (int)m, b,
+                               dacc0 > 0 ? (double)(dacc0 - 1) : (double)DEFL_TINY_ACCEPT);
+            MVF_LAUNCH_CHECK();
+            if (timing)
+                for (auto& e : ev) (void)hipEventDestroy(e);
+            return 0;
+        }
         // ONE device -> host copy decides (einfo[0..5], info, the state flag, the power iteration's last two quotients), and
         // ONE launch writes the closing state + einfo: seven separate small copies used to cost 0.13 ms of this 1.5 ms call
         double* rep = (double*)(ws + p.off_scal) + 16;  // 11 doubles of the 256-byte scalar slot (its first two are the shift's)
@@ -2309,7 +2389,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
     if (r == 0) {  // the zero matrix: minimum-norm solution 0
         MVF_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)m * nrhs * sizeof(double), st));
         MVF_CHECK_HIP(hipMemsetAsync(einfo, 0, 6 * sizeof(double), st));
-        if (deflate) MVF_CHECK_HIP(hipMemsetAsync(einfo + 7, 0, sizeof(double), st));  // no block ran
+        if (deflate) MVF_CHECK_HIP(hipMemsetAsync(einfo + 7, 0, 3 * sizeof(double), st));  // no block ran
         MVF_CHECK_HIP(hipStreamSynchronize(st));
         return 0;
     }
@@ -2485,8 +2565,8 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             MVF_CHECK_HIP(hipMemcpyAsync(&stt->defl, dtag, sizeof(dtag), hipMemcpyHostToDevice, st));
             const double hsw[5] = {(double)hsweeps, he[1], he[2], he[3], 0.0};  // [4] = delta = 0 as on the Jacobi path
             MVF_CHECK_HIP(hipMemcpyAsync(einfo, hsw, sizeof(hsw), hipMemcpyHostToDevice, st));
-            const double hblk[1] = {(double)b};  // einfo[7] = the block size used (0: the Jacobi path answered)
-            MVF_CHECK_HIP(hipMemcpyAsync(einfo + 7, hblk, sizeof(hblk), hipMemcpyHostToDevice, st));
+            const double hblk[3] = {(double)b, 1.0, 0.0};  // einfo[7] = the block size used (0: the Jacobi path answered),
+            MVF_CHECK_HIP(hipMemcpyAsync(einfo + 7, hblk, sizeof(hblk), hipMemcpyHostToDevice, st));  // [8] = the form, [9] = 0
             MVF_CHECK_HIP(hipStreamSynchronize(st));
             if (timing)
                 for (auto& e : ev) (void)hipEventDestroy(e);
@@ -2563,7 +2643,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
     MVF_CHECK_HIP(hipMemcpyAsync(einfo, hsw, sizeof(double), hipMemcpyHostToDevice, st));
     // mvf_solve_minnorm_lrd answered by this path (small factor, launch-grid limit, lr_no_deflate, a failed attempt):
     // einfo[7] = 0, the block size of a deflated solve that did not run (mvf.h)
-    if (deflate) MVF_CHECK_HIP(hipMemsetAsync(einfo + 7, 0, sizeof(double), st));
+    if (deflate) MVF_CHECK_HIP(hipMemsetAsync(einfo + 7, 0, 3 * sizeof(double), st));  // block, form, repeat flag
     MVF_CHECK_HIP(hipStreamSynchronize(st));
     return 0;
 }
@@ -2588,6 +2668,18 @@ extern "C" int mvf_solve_minnorm_lrd(const double* G, const double* K, double la
                                      void* stream) {
     return lr_solve(G, K, lambda_sigma2, tolf, rcond, R, m, nrhs, C, info, einfo, max_sweeps, reuse, rank_hint, workspace,
                     workspace_bytes, stream, true);
+}
+
+extern "C" int mvf_solve_minnorm_lrd_async(const double* G, const double* K, double lambda_sigma2, double tolf, double rcond,
+                                           const double* R, int64_t m, int nrhs, double* C, int* info, double* einfo,
+                                           int form_hint, void* workspace, size_t workspace_bytes, void* stream) {
+    MVF_REQUIRE(form_hint == 1 || form_hint == 2, "mvf_solve_minnorm_lrd_async: form_hint must be 1 or 2 (got %d)", form_hint);
+    MVF_REQUIRE(m >= 2 * DEFL_TINY && m <= 640, "mvf_solve_minnorm_lrd_async: the direct form covers 128 <= m <= 640 (got %lld)",
+                (long long)m);
+    MVF_REQUIRE(debug_opt(DBG_LR_NO_DEFLATE) == 0 && debug_opt(DBG_LR_NO_DIRECT) == 0,
+                "mvf_solve_minnorm_lrd_async: the direct form is switched off (developer option)");
+    return lr_solve(G, K, lambda_sigma2, tolf, rcond, R, m, nrhs, C, info, einfo, 60, 0, (int)m, workspace, workspace_bytes,
+                    stream, true, true, form_hint);
 }
 
 extern "C" int mvf_lr_pivot_order(const void* workspace, size_t workspace_bytes, int64_t m, int* order_out, double* pivots_out,

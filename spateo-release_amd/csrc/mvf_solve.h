@@ -20,6 +20,6 @@ int chol_factor_mat(hipStream_t st, const double* A, int64_t ld, double shift, i
                     int* info);
 size_t chol_inv_workspace_bytes(int64_t m);
 int chol_factor_mat_inv(hipStream_t st, const double* A, int64_t ld, int64_t m, void* workspace, CholPlan* pl, int* info,
-                        int inverse);
+                        int inverse, const int* order = nullptr, const int* oflag = nullptr);
 
 }  // namespace mvf

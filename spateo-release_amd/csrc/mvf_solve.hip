@@ -63,68 +63,104 @@ __global__ __launch_bounds__(256) void chol_prepare_kernel(const double* __restr
 // columns, profiles/r05_small_m_timeline.md - on a part whose dependent-launch boundary costs 1.5 us) ----------------------
 //
 // potrf64: right-looking Cholesky of one 64 x 64 block by ONE workgroup, register tiled: thread (ty, tx) of a 16 x 16 grid
-// keeps a[ty + 16 p][tx + 16 q] (p >= q: the lower triangle of tiles).  Step j: the owners of column j have published it
-// (still UNSCALED) in its own LDS row Lu[j][.], ONE barrier, every thread applies the rank-1 update
+// keeps a[ty + 16 p][tx + 16 q] (p >= q: the lower triangle of tiles).  A step eliminates TWO columns: the owners of columns
+// j and j + 1 have published them (still UNSCALED, column j + 1 as it stood before step j) in LDS, ONE barrier, every thread
+// forms column j + 1 after step j for the rows and columns it needs - the very multiply-subtract its owners would have
+// applied - and applies both rank-1 updates
 // a[i][c] -= (a[i][j] / a[j][j]) a[c][j] to its registers.  What makes a step short:
-//   * the reciprocal of the pivot is v_rcp_f64 + two Newton steps (the IEEE divide the compiler emits is ~20 dependent
+//   * one LDS round trip and one barrier per two columns, and the two pivots' reciprocals as independent chains;
+//   * the reciprocal of a pivot is v_rcp_f64 + two Newton steps (the IEEE divide the compiler emits is ~20 dependent
 //     instructions in every step's critical chain);
 //   * no predicate on the update: an entry with i <= j or c <= j is dead once its column has been published (the columns
 //     are kept in LDS, the result is written from there), so whatever the update does to it is never read;
-//   * the NEXT column is updated and published first, the other tiles after it: their multiply-subtracts overlap the LDS
-//     round trip of the publication instead of preceding it.
+//   * the NEXT two columns are updated and published first, the other tiles after them: their multiply-subtracts overlap
+//     the LDS round trip of the publication instead of preceding it.
 // Columns are scaled by 1 / sqrt(d_j) at the end; rdiag gets 1 / L_jj for the triangular solves.  The column loop is rolled
 // inside each 16-column group (the group index must be static for the register tile; straight-line code of a
 // one-workgroup kernel is paid for in instruction-cache misses).
 template <int JQ>
-__device__ __forceinline__ void potrf_group(double (&r)[4][4], double (*Lu)[LDU], double* dg, int tx, int ty, int k,
-                                            int* __restrict__ info) {
-    if (tx == 0) {  // the group's first column (the earlier groups' updates are complete in the registers)
+__device__ __forceinline__ void potrf_group(double (&r)[4][4], double (*Lu)[LDU], double (*Pub)[2][NB], double* dg, int& pb,
+                                            int tx, int ty, int k, int* __restrict__ info) {
+    if (tx < 2) {  // the group's first two columns (the earlier groups' updates are complete in the registers)
 #pragma unroll
-        for (int p = JQ; p < 4; ++p) Lu[16 * JQ][ty + 16 * p] = r[p][JQ];
+        for (int p = JQ; p < 4; ++p) Pub[pb][tx][ty + 16 * p] = r[p][JQ];
+        if (tx == 0) {
+#pragma unroll
+            for (int p = JQ; p < 4; ++p) Lu[16 * JQ][ty + 16 * p] = r[p][JQ];
+        }
     }
     __syncthreads();
 #pragma unroll 1
-    for (int jx = 0; jx < 16; ++jx) {
+    for (int jx = 0; jx < 16; jx += 2) {
         const int j = 16 * JQ + jx;
-        const double* cb = Lu[j];
-        double d = cb[j];
-        double ci[4], cc[4];
+        const double* u0 = Pub[pb][0];
+        const double* u1 = Pub[pb][1];
+        const double d0 = u0[j], e = u0[j + 1], g = u1[j + 1];
+        double c0r[4], c0c[4], c1r[4], c1c[4];
 #pragma unroll
-        for (int p = JQ; p < 4; ++p) {  // (every LDS read of the step is in flight before the pivot is looked at)
-            ci[p] = cb[ty + 16 * p];
-            cc[p] = cb[tx + 16 * p];
+        for (int p = JQ; p < 4; ++p) {  // (every LDS read of the step is in flight before a pivot is looked at)
+            c0r[p] = u0[ty + 16 * p];
+            c0c[p] = u0[tx + 16 * p];
+            c1r[p] = u1[ty + 16 * p];
+            c1c[p] = u1[tx + 16 * p];
         }
-        if (!(d > 0.0)) {  // also catches NaN; keep going with a harmless pivot so the kernel chain completes
-            if (threadIdx.x == 0) atomicCAS(info, 0, 1 + k * NB + j);
-            d = 1.0;
+        // The two reciprocals are INDEPENDENT chains (a dependent f64 operation costs ~35 cycles on this part, a Newton
+        // reciprocal five of them: tools/clock_probe.hip): 1 / d1 = d0 / (g d0 - e^2) needs no 1 / d0.  The pivot tests
+        // stay off the chain: a non-positive (or NaN) pivot is reported, the arithmetic runs on with it (the factor is
+        // then garbage, as info says; nothing waits for a replacement value).
+        const double t1 = fma(g, d0, -(e * e));
+        const double inv0 = rcp_nr2(d0);
+        const double inv1 = d0 * rcp_nr2(t1);
+        const double d1 = t1 * inv0;  // the pivot of column j + 1 (for the final scaling)
+        const bool bad0 = !(d0 > 0.0), bad1 = !(d1 > 0.0);  // (also catch NaN)
+        if (threadIdx.x == 0) {
+            if (bad0 || bad1) atomicCAS(info, 0, 1 + k * NB + j + (bad0 ? 0 : 1));
+            dg[j] = bad0 ? 1.0 : d0;
+            dg[j + 1] = bad1 ? 1.0 : d1;
         }
-        if (threadIdx.x == 0) dg[j] = d;
-        const double inv = rcp_nr2(d);
+        double l0[4], l1[4];
 #pragma unroll
-        for (int p = JQ; p < 4; ++p) ci[p] *= inv;
-        // tile column JQ first: it holds column j + 1, which its owners publish before anybody touches the other tiles
+        for (int p = JQ; p < 4; ++p) {
+            l0[p] = c0r[p] * inv0;
+            c1r[p] = fma(-l0[p], e, c1r[p]);
+            c1c[p] = fma(-(c0c[p] * inv0), e, c1c[p]);
+            l1[p] = c1r[p] * inv1;
+        }
+        // tile column JQ first: it holds the next two columns, which their owners publish before anybody touches the rest
 #pragma unroll
-        for (int p = JQ; p < 4; ++p) r[p][JQ] = fma(-ci[p], cc[JQ], r[p][JQ]);
-        if (tx == jx + 1) {  // (never in the group's last step: the next group publishes its own first column)
+        for (int p = JQ; p < 4; ++p) r[p][JQ] = fma(-l1[p], c1c[JQ], fma(-l0[p], c0c[JQ], r[p][JQ]));
+        if (tx == jx + 1) {  // column j + 1 as it stood when it was the pivot column: what the final scaling needs
 #pragma unroll
-            for (int p = JQ; p < 4; ++p) Lu[j + 1][ty + 16 * p] = r[p][JQ];
+            for (int p = JQ; p < 4; ++p) Lu[j + 1][ty + 16 * p] = c1r[p];
+        }
+        if (tx == jx + 2 || tx == jx + 3) {  // (never in the group's last step: the next group publishes its own first two)
+            const int w = tx - jx - 2;
+#pragma unroll
+            for (int p = JQ; p < 4; ++p) Pub[pb ^ 1][w][ty + 16 * p] = r[p][JQ];
+            if (w == 0) {
+#pragma unroll
+                for (int p = JQ; p < 4; ++p) Lu[j + 2][ty + 16 * p] = r[p][JQ];
+            }
         }
 #pragma unroll
         for (int q = JQ + 1; q < 4; ++q)
 #pragma unroll
-            for (int p = q; p < 4; ++p) r[p][q] = fma(-ci[p], cc[q], r[p][q]);
+            for (int p = q; p < 4; ++p) r[p][q] = fma(-l1[p], c1c[q], fma(-l0[p], c0c[q], r[p][q]));
         __syncthreads();
+        pb ^= 1;
     }
 }
 
 // r = the block (thread (ty, tx) holds a[ty + 16 p][tx + 16 q]);  on return Lu[c][i] = unscaled column c (rows i >= c) and
 // dg[c] = the pivots; the caller scales and stores with potrf64_store.  256 threads.
-__device__ __forceinline__ void potrf64(double (&r)[4][4], double (*Lu)[LDU], double* dg, int k, int* __restrict__ info) {
+__device__ __forceinline__ void potrf64(double (&r)[4][4], double (*Lu)[LDU], double (*Pub)[2][NB], double* dg, int k,
+                                        int* __restrict__ info) {
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    potrf_group<0>(r, Lu, dg, tx, ty, k, info);
-    potrf_group<1>(r, Lu, dg, tx, ty, k, info);
-    potrf_group<2>(r, Lu, dg, tx, ty, k, info);
-    potrf_group<3>(r, Lu, dg, tx, ty, k, info);
+    int pb = 0;
+    potrf_group<0>(r, Lu, Pub, dg, pb, tx, ty, k, info);
+    potrf_group<1>(r, Lu, Pub, dg, pb, tx, ty, k, info);
+    potrf_group<2>(r, Lu, Pub, dg, pb, tx, ty, k, info);
+    potrf_group<3>(r, Lu, Pub, dg, pb, tx, ty, k, info);
 }
 
 // the factor of block column k's diagonal block to W (explicitly ZERO upper triangle: the triangular solves rely on it)
@@ -150,6 +186,7 @@ __device__ __forceinline__ void potrf64_store(const double (*Lu)[LDU], const dou
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ W, int64_t mp, int k,
                                                          double* __restrict__ rdiag, int* __restrict__ info) {
     __shared__ double Lu[NB][LDU];
+    __shared__ double Pub[2][2][NB];
     __shared__ double dg[NB];
     double* blk = W + ((int64_t)k * NB) * mp + (int64_t)k * NB;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -158,7 +195,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ W,
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) r[p][q] = blk[(int64_t)(ty + 16 * p) * mp + tx + 16 * q];
-    potrf64(r, Lu, dg, k, info);
+    potrf64(r, Lu, Pub, dg, k, info);
     potrf64_store(Lu, dg, blk, mp, rdiag + (int64_t)k * NB);
 }
 
@@ -225,6 +262,7 @@ __global__ __launch_bounds__(256) void syrk_potrf_kernel(double* __restrict__ W,
     const int j = k + 1 + t;
     __shared__ double sa[NB * LDP];
     __shared__ double sb[NB * LDP];
+    __shared__ double Pub[2][2][NB];
     __shared__ double dg[NB];
     const double* pa = W + ((int64_t)i * NB) * mp + (int64_t)k * NB;
     const double* pb = W + ((int64_t)j * NB) * mp + (int64_t)k * NB;
@@ -302,7 +340,7 @@ __global__ __launch_bounds__(256) void syrk_potrf_kernel(double* __restrict__ W,
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) r[p][q] = T[ty + 16 * p][tx + 16 * q];
-    potrf64(r, Lu, dg, k + 1, info);
+    potrf64(r, Lu, Pub, dg, k + 1, info);
     potrf64_store(Lu, dg, pc, mp, rdiag + (int64_t)(k + 1) * NB);
 }
 
@@ -624,15 +662,24 @@ __global__ __launch_bounds__(256) void mat_diag_mean_kernel(const double* __rest
 
 __global__ __launch_bounds__(256) void chol_prepare_mat_kernel(const double* __restrict__ A, int64_t ld,
                                                                const double* __restrict__ scal, int64_t m, int64_t mp,
-                                                               double* __restrict__ W, int ident) {
+                                                               double* __restrict__ W, int ident,
+                                                               const int* __restrict__ order = nullptr,
+                                                               const int* __restrict__ oflag = nullptr) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = blockIdx.y;
     if (j >= mp) return;
     double v = 0.0;
     if (i < mp) {
         if (i < m && j < m) {
-            v = A[i * ld + j];
-            if (i == j) v += scal[1];
+            int64_t oi = i, oj = j;
+            if (order != nullptr && oflag[0] != 0) {  // A[order[i]][order[j]]: the matrix in a pivot order (identity order when
+                oi = order[i];                         // the caller's flag says the order is not to be trusted)
+                oj = order[j];
+                if (oi < 0 || oi >= m) oi = i;
+                if (oj < 0 || oj >= m) oj = j;
+            }
+            v = A[oi * ld + oj];
+            if (i == j && scal != nullptr) v += scal[1];
         } else if (i == j) {
             v = 1.0;
         }
@@ -640,6 +687,56 @@ __global__ __launch_bounds__(256) void chol_prepare_mat_kernel(const double* __r
         v = 1.0;  // the identity as right-hand-side rows: they leave the factorisation as L^-T
     }
     W[i * mp + j] = v;
+}
+
+// The whole factorisation of a matrix of order <= 64 in ONE launch (the Gram matrices of the deflation block's Cholesky-QR
+// and its 64 x 64 Rayleigh-Ritz matrix: memset + prepare + potrf + trsm were four dependent launches, 31 us): load with
+// identity padding, potrf64, and - inverse != 0 - the 64 identity rows through the quad substitution of trsm_panel_kernel,
+// one quad per row: W (128 x 64) = [L ; L^-T] exactly as the blocked path leaves it.
+__global__ __launch_bounds__(256) void chol64_kernel(const double* __restrict__ A, int64_t ld, int m, double* __restrict__ W,
+                                                     double* __restrict__ rdiag, int* __restrict__ info, int inverse) {
+    __shared__ double Lu[NB][LDU];
+    __shared__ double Pub[2][2][NB];
+    __shared__ double dg[NB];
+    __shared__ __align__(16) double Ls[NB * TLC];
+    __shared__ double rd[NB];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    double r[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = ty + 16 * p, c = tx + 16 * q;
+            r[p][q] = (i < m && c < m) ? A[(int64_t)i * ld + c] : (i == c ? 1.0 : 0.0);
+        }
+    potrf64(r, Lu, Pub, dg, 0, info);
+    potrf64_store(Lu, dg, W, NB, rdiag);
+    if (!inverse) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = tx + 16 * q;
+        const double l = sqrt(dg[c]);
+        const double rl = 1.0 / l;
+        if (ty == 0) rd[c] = rl;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int i = ty + 16 * p;
+            Ls[c * TLC + (i & 3) * TLQ + (i >> 2)] = (c < i) ? div_by(Lu[c][i], l, rl) : 0.0;
+        }
+    }
+    __syncthreads();
+    const int rho = threadIdx.x & 3, row = threadIdx.x >> 2;
+    double x[16];
+#pragma unroll
+    for (int jl = 0; jl < 16; ++jl) x[jl] = (4 * jl + rho == row) ? 1.0 : 0.0;
+    const double* ls_rho = Ls + rho * TLQ;
+    double2 first[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) first[h] = reinterpret_cast<const double2*>(ls_rho)[h];
+    trsm_steps<0>(x, ls_rho, rd, first, rd[0]);
+    double* rp = W + (int64_t)(NB + row) * NB + rho;
+#pragma unroll
+    for (int jl = 0; jl < 16; ++jl) rp[4 * jl] = x[jl] * rd[4 * jl + rho];
 }
 
 int chol_factor_mat(hipStream_t st, const double* A, int64_t ld, double shift, int64_t m, void* workspace, CholPlan* pl,
@@ -665,8 +762,9 @@ size_t chol_inv_workspace_bytes(int64_t m) {
 }
 
 // inverse = 0: the factor only (one block row of zero right-hand sides keeps the kernels' trapezoidal layout)
+// order / oflag (may be NULL): factor A[order][order] instead (oflag[0] == 0: the order is not to be trusted - identity)
 int chol_factor_mat_inv(hipStream_t st, const double* A, int64_t ld, int64_t m, void* workspace, CholPlan* pl, int* info,
-                        int inverse) {
+                        int inverse, const int* order, const int* oflag) {
     const int64_t mp = solve_mp(m), mr = inverse ? 2 * mp : mp + NB;
     MVF_REQUIRE(mr <= 65535, "coefficient solve: m too large (%lld)", (long long)m);
     pl->mp = mp;
@@ -677,9 +775,13 @@ int chol_factor_mat_inv(hipStream_t st, const double* A, int64_t ld, int64_t m, 
     pl->Cp = pl->Yw = nullptr;
     pl->rdiag = (double*)((char*)workspace + align_up((size_t)mr * mp * sizeof(double), 256));
     pl->scal = (double*)((char*)pl->rdiag + align_up((size_t)mp * sizeof(double), 256));
-    MVF_CHECK_HIP(hipMemsetAsync(pl->scal, 0, 2 * sizeof(double), st));
+    if (mp == NB && order == nullptr) {  // one block: one launch
+        hipLaunchKernelGGL(chol64_kernel, dim3(1), dim3(256), 0, st, A, ld, (int)m, pl->W, pl->rdiag, info, inverse);
+        MVF_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(chol_prepare_mat_kernel, dim3((unsigned)cdiv(mp, 256), (unsigned)mr), dim3(256), 0, st, A, ld,
-                       pl->scal, m, mp, pl->W, inverse);
+                       (const double*)nullptr, m, mp, pl->W, inverse, order, oflag);
     MVF_LAUNCH_CHECK();
     return chol_run(st, pl, info);
 }

@@ -346,6 +346,19 @@ class HipKernels:
                       self._lr_ws.numel(), self._stream()), "mvf_solve_minnorm_lrd" if deflate else "mvf_solve_minnorm_lr")
 
     @_on_device
+    def solve_minnorm_lrd_async(self, G, K, lambda_sigma2, R, C_out, info, einfo, form_hint, rcond=None, tolf=0.25):
+        """The direct form of the deflated solve without any host synchronisation (mvf_solve_minnorm_lrd_async): form_hint =
+        the previous call's einfo[8] on this workspace (1 factor form / 2 direct form, with einfo[6] == m).  einfo[9] == 1
+        afterwards means NOT accepted: repeat through solve_minnorm_lr(deflate=True).  Needs the workspace of a previous call."""
+        m, nrhs = R.shape
+        if self._lr_ws is None or self._lr_ws.numel() < self.lib.mvf_solve_minnorm_lrd_workspace_bytes(m, nrhs):
+            raise RuntimeError("solve_minnorm_lrd_async without the workspace of a previous deflated solve")
+        rc = float(np.finfo(np.float64).eps) if rcond is None else float(rcond)
+        _lib.check(self.lib.mvf_solve_minnorm_lrd_async(_ptr(G), _ptr(K), float(lambda_sigma2), float(tolf), rc, _ptr(R), m, nrhs,
+                                                        _ptr(C_out), _ptr(info), _ptr(einfo), int(form_hint), _ptr(self._lr_ws),
+                                                        self._lr_ws.numel(), self._stream()), "mvf_solve_minnorm_lrd_async")
+
+    @_on_device
     def lr_pivot_order(self, m, with_values=False):
         """Host int array: the pivots (control-point indices, in the order taken) of the last solve_minnorm_lr call; with
         with_values also (the diagonal value of each pivot when it was taken, the stopping tolerance)."""

@@ -68,6 +68,7 @@ SIGNATURES = {
     "mvf_solve_minnorm_lr": (_i, [_p, _p, _d, _d, _d, _p, _i64, _i, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "mvf_solve_minnorm_lrd_workspace_bytes": (_sz, [_i64, _i]),
     "mvf_solve_minnorm_lrd": (_i, [_p, _p, _d, _d, _d, _p, _i64, _i, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
+    "mvf_solve_minnorm_lrd_async": (_i, [_p, _p, _d, _d, _d, _p, _i64, _i, _p, _p, _p, _i, _p, _sz, _p]),
     "mvf_lr_pivot_order": (_i, [_p, _sz, _i64, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.POINTER(C.c_int64), _p]),
     "mvf_pinv_diag": (_i, [_p, _i64, _p, _i64, _d, _d, _i, _p, _p, _sz, _i, _p]),

@@ -335,6 +335,7 @@ class SparseVFCEngine:
     # which truncated minimum-norm solver answers once the system is rank deficient: None = by M ("deflated" from
     # DEFLATED_MIN_M control points on, else "full"), or "deflated" | "lowrank" | "full" for every engine built afterwards
     minnorm_method = None
+    async_direct = True   # M <= 640 steady state: mvf_solve_minnorm_lrd_async + speculative field update (False: round 5's calls)
 
     def __init__(self, X, Y, ctrl, beta, *, dtype=None, device=None, distributed=False, group=None, n_total=None,
                  kernels=None, cache_u="auto", shard_sizes=None, gram_mode="full", force_collectives=False,
@@ -460,6 +461,7 @@ class SparseVFCEngine:
         # M = 500: 1.5 / 3.6 ms (profiles/r05_small_m_probe.json); below 256 control points the full-width solve stays
         self.mn_method = self.minnorm_method or ("deflated" if self.M >= DEFLATED_MIN_M else "full")
         self.rank_hint = 0
+        self._lrd_form = 0
         # lstsq_method="cholesky" (extension, not a reference mode): jitter-escalated Cholesky, the round-1 solver
         self.jitter = 0.0
         self.jitter_first = 1e-15
@@ -625,6 +627,7 @@ class SparseVFCEngine:
         self.rank_deficient = False
         self.basis_valid = False
         self.rank_hint = 0
+        self._lrd_form = 0
         self._lr_ran, self._lr_iterations, self._spr_spec = False, 0, None
 
     def _apply_all(self, ctrl4, C=None):
@@ -853,6 +856,40 @@ class SparseVFCEngine:
         # truncated minimum-norm solve (gelsd cut-off eps * max|lambda|)
         if self.mn_method in ("lowrank", "deflated") and hasattr(k, "solve_minnorm_lr"):
             dfl = {"deflate": True} if self.mn_method == "deflated" else {}
+            # M <= 640 in its steady state (the previous iteration kept all M columns): the direct form WITHOUT a host round
+            # trip inside the solve (mvf_solve_minnorm_lrd_async; the acceptance test runs on the device), and - single rank -
+            # the field update with the new coefficients enqueued behind it speculatively, so that status, statistics and
+            # sum P r come back in ONE device -> host copy per EM iteration (round 5: three reads inside the solve, one after
+            # it, one for sum P r).  Not accepted (einfo[9]): the synchronous call below answers through the factor form.
+            # Only behind an ACCEPTED direct-form call (einfo[8] == 2): the first attempt of a fit, and the first after a
+            # rejected one, go through the synchronous entry point, which knows how to help the power iteration along while
+            # the matrix still moves and keeps the cool-down after a failure.
+            if (dfl and self.async_direct and len(batches) == 1 and self._lrd_form == 2 and self.rank_hint == self.M
+                    and 128 <= self.M <= 640 and hasattr(k, "solve_minnorm_lrd_async")):
+                self._solve_batch(batches[0], lambda R, C: k.solve_minnorm_lrd_async(self.G, self.K, ls2, R, C, self.info,
+                                                                                     self.einfo, self._lrd_form))
+                spec = not self.multi
+                if spec:
+                    self.fin.zero_()
+                    self._apply_all(self.ctrl4, self.C_new)
+                h = self._host_stats(self.info, self.einfo, *([self.spr] if spec else []))
+                if int(h[0]) != 0:
+                    raise _lib.MVFError("coefficient solve failed: G + lambda sigma^2 K has non-finite entries")
+                if float(h[1 + 9]) == 0.0:
+                    self._lrd_form = 2
+                    self.solver_stats["minnorm"] += 1
+                    self.solver_stats["async"] = self.solver_stats.get("async", 0) + 1
+                    self.solver_stats["sweeps"].append(float(h[1]))
+                    self.solver_stats["rank"].append(int(h[2]))
+                    self.solver_stats.setdefault("factor_rank", []).append(self.rank_hint)
+                    self.solver_stats.setdefault("block", []).append(int(h[1 + 7]))
+                    self._lr_ran = True
+                    self._solver_signature = (3.0, 0.0, float(h[1]), float(h[2]), float(self.rank_hint), float(h[1 + 7]))
+                    if spec:
+                        self._spr_spec = float(h[13])
+                        return h[14:]
+                    return h[13:]
+                self._lrd_form = 0  # (the repeat below re-derives it)
             # rank-revealing factor (pivoted Cholesky) + Jacobi on the kept columns only; the previous iteration's factor
             # rank tells how many pivot steps to enqueue before the first status read
             self._solve_batch(batches[0], lambda R, C: k.solve_minnorm_lr(self.G, self.K, ls2, R, C, self.info, self.einfo,
@@ -862,6 +899,7 @@ class SparseVFCEngine:
                 raise _lib.MVFError("coefficient solve failed: G + lambda sigma^2 K has non-finite entries")
             self._check_converged(h[1])
             self.rank_hint = int(h[1 + 6])
+            self._lrd_form = int(h[1 + 8]) if dfl else 0   # 1 factor form / 2 direct form: what the next call may continue
             for gs in batches[1:]:
                 self._solve_batch(gs, lambda R, C: k.solve_minnorm_lr(self.G, self.K, ls2, R, C, self.info, self.einfo,
                                                                       reuse=True, **dfl))
@@ -872,7 +910,8 @@ class SparseVFCEngine:
             if dfl:
                 self.solver_stats.setdefault("block", []).append(int(h[1 + 7]))  # 256 / 128; 0 = the Jacobi form answered
             self._lr_ran = True
-            self._solver_signature = (3.0, 0.0, float(h[1]), float(h[2]), float(self.rank_hint), 0.0)
+            # (the block size - 0 when the Jacobi path answered - is part of what the ranks must agree on: ADVICE r5)
+            self._solver_signature = (3.0, 0.0, float(h[1]), float(h[2]), float(self.rank_hint), float(h[1 + 7]) if dfl else 0.0)
             return h[1 + 12:]
         # mn_method = "full": Jacobi on all M columns of the shifted Cholesky factor; the shift only has to make the
         # factorisation inside the eigensolver exist, it is subtracted from the eigenvalues again.

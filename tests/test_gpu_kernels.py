@@ -570,6 +570,70 @@ def test_direct_form_falls_back_to_the_factor_form_and_cools_down(st):
     assert int(e6[1]) == int(f0[1]) and int(e6[6]) == 500 and int(e6[7]) == 64 and e6[0] == 1.0
 
 
+def test_direct_form_without_host_synchronisation(st):
+    """mvf_solve_minnorm_lrd_async (ABI 6): the direct form with the acceptance test on the device and no status read inside
+    the call.  On a workspace whose previous call kept all m columns it gives the synchronous direct form's answer (same
+    kernels in the same order: bit for bit), reports form 2 / repeat flag 0 and leaves a state the next call continues; on a
+    workspace that does not hold what the caller claims, and when the acceptance test fails, it sets the repeat flag, and the
+    repeat through mvf_solve_minnorm_lrd is the factor form's answer."""
+    from spateo_amd import _lib
+
+    U, G, K, R, ls2 = _kernel_system(50000, 500, s2=2.4e-3)
+    dev = "cuda:0"
+    Gd, Kd, Rd = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (G, K, R))
+
+    def async_call(k, form):
+        C = torch.empty(500, R.shape[1], dtype=torch.float64, device=dev)
+        info = torch.zeros(1, dtype=torch.int32, device=dev)
+        einfo = torch.zeros(12, dtype=torch.float64, device=dev)
+        k.solve_minnorm_lrd_async(Gd, Kd, ls2, Rd, C, info, einfo, form)
+        return C.cpu().numpy(), int(info.cpu()[0]), einfo.cpu().numpy()
+
+    ks, ka = _k("float64"), _k("float64")
+    # reference: three synchronous calls (factor form, direct form fresh, direct form continued)
+    S0, _, s0 = _run_minnorm(ks, G, K, ls2, R, method="deflated")
+    S1, _, s1 = _run_minnorm(ks, G, K, ls2, R, method="deflated", rank_hint=int(s0[6]))
+    S2, _, s2 = _run_minnorm(ks, G, K, ls2, R, method="deflated", rank_hint=int(s1[6]))
+    assert int(s0[6]) == 500 and int(s0[8]) == 1 and int(s1[8]) == 2 and int(s2[8]) == 2 and s2[9] == 0.0
+    # the same sequence with the second and third call asynchronous
+    A0, _, a0 = _run_minnorm(ka, G, K, ls2, R, method="deflated")
+    A1, i1, a1 = async_call(ka, int(a0[8]))
+    A2, i2, a2 = async_call(ka, int(a1[8]))
+    assert i1 == 0 and i2 == 0 and a1[9] == 0.0 and a2[9] == 0.0 and int(a1[8]) == 2 and int(a2[8]) == 2
+    np.testing.assert_array_equal(A1, S1)
+    np.testing.assert_array_equal(A2, S2)
+    np.testing.assert_array_equal(a2[:8], s2[:8])
+    A3, _, a3 = _run_minnorm(ka, G, K, ls2, R, method="deflated", rank_hint=500)   # a synchronous call continues from it
+    S3, _, s3 = _run_minnorm(ks, G, K, ls2, R, method="deflated", rank_hint=500)
+    np.testing.assert_array_equal(A3, S3)
+    # a claim the workspace does not back (its last call was a FACTOR form, the caller says "direct"): not accepted
+    kb = _k("float64")
+    B0, _, b0 = _run_minnorm(kb, G, K, ls2, R, method="deflated")
+    _, ib, b1 = async_call(kb, 2)
+    assert ib == 0 and b1[9] == 1.0
+    Bf, _, bf = _run_minnorm(kb, G, K, ls2, R, method="deflated", rank_hint=500)   # the repeat: factor form (cool-down mark)
+    assert int(bf[8]) == 1 and int(bf[6]) == 500
+    # an acceptance test that fails (developer option: accept no deflated direction; this system truncates one)
+    kc = _k("float64")
+    C0, _, c0 = _run_minnorm(kc, G, K, ls2, R, method="deflated")
+    old = _lib.debug_option("direct_accept", 1)
+    try:
+        _, ic, c1 = async_call(kc, 1)
+        assert ic == 0 and c1[9] == 1.0
+        Cf, _, cf = _run_minnorm(kc, G, K, ls2, R, method="deflated", rank_hint=500)
+    finally:
+        _lib.debug_option("direct_accept", old)
+    old = _lib.debug_option("lr_no_direct", 1)
+    try:
+        kr = _k("float64")
+        R0, _, r0 = _run_minnorm(kr, G, K, ls2, R, method="deflated")
+        R1, _, r1 = _run_minnorm(kr, G, K, ls2, R, method="deflated", rank_hint=500)
+    finally:
+        _lib.debug_option("lr_no_direct", old)
+    assert int(cf[8]) == 1
+    np.testing.assert_array_equal(Cf, R1)
+
+
 def test_deflated_solve_falls_back_when_the_block_is_too_small(st):
     """With a cut-off far above eps more eigenvalues of the factor fall below it than the 256-vector block holds: the call
     must notice and return the Jacobi path's result."""

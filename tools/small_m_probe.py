@@ -59,7 +59,7 @@ def run(X, V, M, dtype, method, steps=12, lambda_=0.02, timing=False):
                solve_ms=[round(s, 3) for s in solve], steady_step_ms=float(np.median(walls[4:])),
                steady_solve_ms=float(np.median(solve[4:])), cholesky=st["cholesky"], minnorm=st["minnorm"],
                rank=st["rank"][-3:], factor_rank=(st.get("factor_rank") or [None])[-3:], block=(st.get("block") or [None])[-3:],
-               sweeps=st["sweeps"][-3:], sigma2=eng.sigma2)
+               sweeps=st["sweeps"][-3:], sigma2=eng.sigma2, async_calls=st.get("async", 0))
     eng.k.drop_ublk()
     return rec, Vg
 

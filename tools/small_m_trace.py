@@ -19,4 +19,4 @@ eng.init_state(0.9)
 for _ in range(8):
     eng.em_step(a=5.0, lambda_=0.02, minP=1e-5, theta=0.75)
 torch.cuda.synchronize()
-print(eng.solver_stats)
+print({k: (v[-3:] if isinstance(v, list) else v) for k, v in eng.solver_stats.items()})
