@@ -15,8 +15,12 @@ mode - the mode the 1e-5 parity clause is about - with its own roofline; N = 1 o
 HBM-write bandwidth), ``eval`` (the fused evaluator kernel and the wall time of Jacobian + curl on a 64^3 grid at the API), ``cpu_baseline`` (the float64 NumPy oracle on the host cores at N_cpu = 200 k and 100 k cells; its
 ``value`` is the rate its fitted t(N) = a N + b gives at the bench's own cell count; N = 1 only) and ``parity`` (the GPU
 engine, float64 and float32, on exactly the 100 k-cell arrays of that CPU sample against the oracle's field after the
-same 10 EM iterations, with the oracle's own lstsq-vs-eigh noise floor beside it; N = 1 only) and ``pivot_subset`` (the same
-workload with gram_mode="pivot": an extension that is not the reference's arithmetic and never the headline ``value``).
+same 10 EM iterations, with the oracle's own lstsq-vs-eigh noise floor beside it; N = 1 only).  ``config`` (the object the
+driver parses) also carries the figures the other BASELINE configurations are judged by: ``f64_value`` / ``f64_frac`` (the
+reference-width run of the headline workload), ``c3_ms_per_step`` / ``c3_gram_frac`` (2 M x 2000), ``c2_ms_per_em_step``,
+``c5_organ_ms_per_em_step``, ``c5_32_organs_wall_s`` (all 32 organs of config 5 through four streams of the one GPU),
+``eval_frac`` (the fused evaluator kernel against the float64 VALU peak), ``solve_avg_ms`` and ``rccl_ranks`` (ncclCommCount
+of the communicator the step's collectives ran on).
 """
 from __future__ import annotations
 
@@ -34,6 +38,8 @@ for _p in (ROOT, os.path.join(ROOT, "spateo-release_amd")):
         sys.path.insert(0, _p)
 
 PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X datasheet: FP64 matrix (v_mfma_f64_16x16x4_f64) dense peak
+PEAK_F64_VALU_TFLOPS = 78.6   # MI355X datasheet: FP64 vector peak (the evaluators' arithmetic)
+EVAL_F64_FLOP_PER_PAIR = 24.0 # kernel value (3 sub, 3 fma-chain, exp2 ~ 1) + 9 Jacobian + 3 field FMAs per (query, control point)
 PEAK_HBM_GBPS = 8000.0
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 
@@ -220,7 +226,7 @@ def cpu_baseline(M, lambda_, n_cpu, n_target, steps=3):
     return rec, sample
 
 
-def parity_on_sample(sample, lambda_, device, gram_mode="full"):
+def parity_on_sample(sample, lambda_, device):
     """The GPU engine (float64 and float32 cells) on EXACTLY the arrays of the CPU baseline's half-size sample - same
     control points, same beta, same number of EM iterations from the same initial state - against the oracle's field:
     a driver-run parity figure for the bench's own workload generator at M = 3000, lambda_ as benchmarked.
@@ -234,8 +240,7 @@ def parity_on_sample(sample, lambda_, device, gram_mode="full"):
            "lambda_": lambda_, "reference": "float64 NumPy oracle (scipy.linalg.lstsq), same arrays",
            "floor": sample["floor"]}
     for dtype in ("float64", "float32"):
-        eng = SparseVFCEngine(sample["Xv"], sample["Yv"], sample["ctrl"], sample["beta"], dtype=dtype, device=device,
-                              gram_mode=gram_mode)
+        eng = SparseVFCEngine(sample["Xv"], sample["Yv"], sample["ctrl"], sample["beta"], dtype=dtype, device=device)
         eng.lstsq_method = "scipy"
         eng.init_state(gamma=0.9)
         for _ in range(sample["steps"]):
@@ -283,11 +288,6 @@ def main():
                     help="materialise the float32 kernel values once (96 GB at 8M x 3000) and stream them in the Gram "
                          "kernel instead of regenerating them every EM iteration")
     ap.add_argument("--no-conk", action="store_true", help="skip the con_K bandwidth run")
-    ap.add_argument("--gram-mode", default="full", choices=["full", "pivot"],
-                    help="full = the reference's M-step on all M control points (the headline); pivot = extension: after the "
-                         "first rank-revealing solve the fit continues on the r control points that carry the numerical "
-                         "rank (N r^2 instead of N M^2 work; field at the reference's noise floor, not its arithmetic)")
-    ap.add_argument("--no-pivot", action="store_true", help="skip the extra pivot-mode run of the default line")
     ap.add_argument("--force-collectives", action="store_true",
                     help="N = 1 only: run the HEADLINE itself through the multi-rank protocol on a process group of one rank "
                          "(every collective of the EM step executes on RCCL; same arithmetic, bit-equal result)")
@@ -298,6 +298,8 @@ def main():
                     help="do not run the two rocprofv3 --pmc child passes (roofline.traffic then comes from the committed profile)")
     ap.add_argument("--traffic-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-whole-fit", action="store_true", help="skip the whole-call (host arrays in, host dict out) timings")
+    ap.add_argument("--no-c3", action="store_true", help="skip the BASELINE config 3 (2 M x 2000) run")
+    ap.add_argument("--no-organs32", action="store_true", help="skip the 32-organ run of BASELINE config 5")
     ap.add_argument("--no-rccl-world1", action="store_true",
                     help="skip the extra N = 1 runs that execute the step's collectives on a one-rank RCCL communicator")
     args = ap.parse_args()
@@ -345,6 +347,37 @@ def main():
     from spateo_amd._kernels import HipKernels
     from spateo_amd._synthetic import make_config
     from spateo_amd.vectorfield import SparseVFCEngine, shard_bounds, sparsevfc_preprocess
+
+    # ---------------------------------------------------------------- N ranks really are N ranks on N different GPUs
+    rccl_ranks = None
+    if distributed:
+        import socket
+
+        props = torch.cuda.get_device_properties(local_rank)
+        mine_id = (socket.gethostname(), int(local_rank), str(getattr(props, "uuid", "")), int(getattr(props, "pci_bus_id", -1)),
+                   int(getattr(props, "pci_device_id", -1)))
+        ids = [None] * world
+        dist.all_gather_object(ids, mine_id)
+        assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
+        if not one_dev:
+            assert len({(h_, l_) for h_, l_, *_ in ids}) == world, f"{world} ranks do not own {world} distinct GPUs: {ids}"
+            if all(u_ not in ("", "None") for _, _, u_, _, _ in ids):  # (the device UUID where this torch reports one)
+                assert len({(h_, u_) for h_, _, u_, _, _ in ids}) == world, f"{world} ranks share a physical GPU: {ids}"
+            # a communicator of the C ABI over the same ranks, created and queried before anything is timed: ncclCommCount
+            # must say N (mvf_comm_info asks RCCL itself)
+            from spateo_amd._comm import MvfComm
+
+            probe = MvfComm(device, rank, world)
+            try:
+                rccl_ranks = int(probe.info()[0])
+                t_ = torch.ones(1, dtype=torch.float64, device=device)
+                probe.all_reduce(t_)
+                torch.cuda.synchronize(device)
+                assert rccl_ranks == world and float(t_.cpu()[0]) == float(world), (rccl_ranks, float(t_.cpu()[0]), world)
+            finally:
+                probe.close()
+        if rank == 0:
+            log(f"[bench] {world} ranks on devices {ids}; RCCL communicator size {rccl_ranks}")
 
     # ---------------------------------------------------------------- counter-pass child (see measured_traffic)
     if args.traffic_child > 0:
@@ -404,15 +437,22 @@ def main():
             os.environ["MASTER_PORT"] = str(port)
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(device))
 
-    def run_mode(dtype, steps, warmup, gram_mode="full", force=False, collective="torch"):
-        """W warm-up + K timed EM iterations of the whole workload in one cell dtype; returns the timing record."""
+    def run_mode(dtype, steps, warmup, force=False, collective="torch", data=None):
+        """W warm-up + K timed EM iterations of the whole workload in one cell dtype; returns the timing record.
+        data = (Xv, Yv, ctrl, beta): another single-rank workload through the same code (BASELINE config 3)."""
         kern = HipKernels(device, dtype)
         cache_u = {"auto": "auto", "on": True, "off": False}[args.cache_u]
         if force and collective == "torch":
             ensure_group()
-        eng = SparseVFCEngine(Xv[lo:hi], Yv[lo:hi], ctrl, beta, dtype=dtype, device=device,
-                              distributed=distributed or (force and collective == "torch"),
-                              n_total=N, kernels=kern, cache_u=cache_u, gram_mode=gram_mode, force_collectives=force,
+        if data is None:
+            Xr, Yr, ctrl_r, beta_r, N_r, n_loc_r = Xv[lo:hi], Yv[lo:hi], ctrl, beta, N, n_loc
+        else:
+            Xr, Yr, ctrl_r, beta_r = data
+            N_r = n_loc_r = len(Xr)
+        Mc_r = len(ctrl_r)
+        eng = SparseVFCEngine(Xr, Yr, ctrl_r, beta_r, dtype=dtype, device=device,
+                              distributed=(distributed or (force and collective == "torch")) and data is None,
+                              n_total=N_r, kernels=kern, cache_u=cache_u, force_collectives=force,
                               collective=collective)
         eng.lstsq_method = args.lstsq
         eng.init_state(gamma=0.9)
@@ -430,6 +470,16 @@ def main():
             return host
 
         eng._solve_all = timed_solve
+        try:
+            return _timed_steps(eng, kern, solve_events, dtype, steps, warmup, force, collective, N_r, n_loc_r, Mc_r)
+        finally:  # (the RCCL communicator of the engine is destroyed on every path, not only on success)
+            if eng.comm is not None:
+                eng.comm.close()
+            kern.drop_ublk()
+            del eng, kern
+            torch.cuda.empty_cache()
+
+    def _timed_steps(eng, kern, solve_events, dtype, steps, warmup, force, collective, N_r, n_loc_r, Mc_r):
         for _ in range(warmup):
             eng.em_step(**step_kw)
         kern.gram_events = []
@@ -451,14 +501,14 @@ def main():
         kern.gram_events = None
         ms_per_step = 1e3 * elapsed / steps
         gram_avg_ms = float(np.mean(gram_ms))
-        Mg = int(eng.M)  # control points the Gram kernel works on (== Mc unless gram_mode "pivot" has switched)
-        alg_flops = float(n_loc) * Mg * (Mg + 1)  # symmetric Gram: n m (m+1) flops
+        Mg = int(eng.M)  # control points the Gram kernel works on
+        alg_flops = float(n_loc_r) * Mg * (Mg + 1)  # symmetric Gram: n m (m+1) flops
         achieved = alg_flops / (gram_avg_ms * 1e-3) / 1e12
         peak = PEAK_F64_MFMA_TFLOPS  # both cell dtypes accumulate with v_mfma_f64_16x16x4_f64
         ctype = "float" if dtype == "float32" else "double"
-        traffic, traffic_src = pmc_traffic(dtype, "f64acc", eng.cached_u, world, n_loc, Mg)
+        traffic, traffic_src = pmc_traffic(dtype, "f64acc", eng.cached_u, world, n_loc_r, Mg)
         rec = {
-            "value": N * steps / elapsed,
+            "value": N_r * steps / elapsed,
             "ms_per_step": ms_per_step,
             "steps": steps,
             "warmup": warmup,
@@ -492,19 +542,18 @@ def main():
                 "avg_ms": float(np.mean(solve_ms)),
                 "share_of_step": float(np.mean(solve_ms)) / ms_per_step,
                 "jacobi_sweeps": eng.solver_stats["sweeps"][n_sweeps0:],
-                "kept_rank": eng.solver_stats["rank"][-1] if eng.solver_stats["rank"] else Mc,
+                "kept_rank": eng.solver_stats["rank"][-1] if eng.solver_stats["rank"] else Mc_r,
                 "factor_rank": (eng.solver_stats.get("factor_rank") or [None])[-1],
                 "warm_start": bool(eng.warm_start),
                 "jitter": eng.jitter,
             },
             "cached_u": bool(eng.cached_u),
-            "gram_mode": gram_mode,
             "ctrl_used": Mg,
             "sigma2_after": eng.sigma2,
             # whole-step rates over all ranks, U counted as materialised (2 s N M bytes, 2 N M^2 flop)
-            "step_effective_GBps": 2.0 * (4 if dtype == "float32" else 8) * N * Mc / (ms_per_step * 1e-3) / 1e9,
+            "step_effective_GBps": 2.0 * (4 if dtype == "float32" else 8) * N_r * Mc_r / (ms_per_step * 1e-3) / 1e9,
             # flops the symmetric Gram kernel executes algorithmically, N M (M + 1), over the whole step's time
-            "step_TFLOPs_NM_Mplus1": float(N) * Mc * (Mc + 1) / (ms_per_step * 1e-3) / 1e12,
+            "step_TFLOPs_NM_Mplus1": float(N_r) * Mc_r * (Mc_r + 1) / (ms_per_step * 1e-3) / 1e12,
         }
         # "MFMA utilisation on the solve" (north_star): MFMA-tile flops of the solve over its wall time.  Rank-revealing
         # Jacobi path: 2 r M^2 in the trailing updates of the pivoted factor + 8 r^2 M per Jacobi sweep (Gram + update tiles);
@@ -518,15 +567,15 @@ def main():
                 rr, bb = float(sv["factor_rank"]), float((eng.solver_stats.get("block") or [256])[-1] or 256)
                 sv["block"] = int(bb)
                 # (three applications of S2^-1 since round 5: one more b x r x r product and one more orthonormalisation)
-                fl = (2.0 * rr * Mc * Mc + 2.0 * rr * rr * Mc + 10.0 / 3.0 * rr**3 + 12.0 * bb * bb * rr + 8.0 * bb * rr * rr +
+                fl = (2.0 * rr * Mc_r * Mc_r + 2.0 * rr * rr * Mc_r + 10.0 / 3.0 * rr**3 + 12.0 * bb * bb * rr + 8.0 * bb * rr * rr +
                       sw * 8.0 * bb**3)
             elif eng.mn_method in ("lowrank", "deflated") and sv["factor_rank"]:
                 rr = float(sv["factor_rank"])
-                fl = 2.0 * rr * Mc * Mc + sw * 8.0 * rr * rr * Mc
+                fl = 2.0 * rr * Mc_r * Mc_r + sw * 8.0 * rr * rr * Mc_r
             else:
-                fl = Mc**3 / 3.0 + sw * 8.0 * float(Mc) ** 3
+                fl = Mc_r**3 / 3.0 + sw * 8.0 * float(Mc_r) ** 3
         else:
-            fl = Mc**3 / 3.0
+            fl = Mc_r**3 / 3.0
         sv["mfma_flops_per_solve"] = fl
         sv["TFLOPs"] = fl / (sv["avg_ms"] * 1e-3) / 1e12
         sv["frac_of_f64_mfma_peak"] = sv["TFLOPs"] / PEAK_F64_MFMA_TFLOPS
@@ -539,7 +588,7 @@ def main():
             big = [(e0.elapsed_time(e1), nb) for e0, e1, nb in eng.comm_events if nb == nb_max]
             mid = [e0.elapsed_time(e1) for e0, e1, nb in eng.comm_events if 1024 < nb < nb_max]
             small = [e0.elapsed_time(e1) for e0, e1, nb in eng.comm_events if nb <= 1024]
-            mine = {"rank": rank, "cells": n_loc, "gram_ms": gram_avg_ms, "solve_ms": float(np.mean(solve_ms)),
+            mine = {"rank": rank, "cells": n_loc_r, "gram_ms": gram_avg_ms, "solve_ms": float(np.mean(solve_ms)),
                     "allreduce_ms": float(np.mean([t for t, _ in big])) if big else None,
                     "allreduce_bytes": big[0][1] if big else 0,
                     "rhs_stats_allreduce_ms": float(np.mean(mid)) if mid else None,
@@ -566,17 +615,13 @@ def main():
                                    "for it: includes waiting for the slowest rank to arrive; the big one is asynchronous, "
                                    "its interval spans the rhs / quadform kernels and the [R | stats] all-reduce"}
         if eng.comm is not None:
-            eng.comm.close()
-        kern.drop_ublk()
-        del eng, kern
-        torch.cuda.empty_cache()
+            rec["rccl_ranks_mvf_comm_info"] = int(eng.comm.info()[0])  # ncclCommCount of the engine's communicator
         return rec
 
     try:
         if args.force_collectives and world != 1:
             raise SystemExit("--force-collectives is an N = 1 option (with N > 1 the collectives run anyway)")
-        main_rec = run_mode(args.dtype, args.steps, max(args.warmup, 5) if args.gram_mode == "pivot" else args.warmup,
-                            args.gram_mode, force=args.force_collectives, collective=args.collective)
+        main_rec = run_mode(args.dtype, args.steps, args.warmup, force=args.force_collectives, collective=args.collective)
     except Exception as exc:
         # one JSON line per failing rank on stderr (which rank, what, where), then the error itself
         import traceback
@@ -606,7 +651,7 @@ def main():
             "ctrl_points": Mc,
             "parallelism": f"cells block-sharded over {world} GPU(s), one all-reduce of [G|R|stats] per EM step",
             "sigma2_after": main_rec["sigma2_after"],
-            "gram_mode": "f64acc" if main_rec["gram_mode"] == "full" else f"f64acc, pivot subset of {main_rec['ctrl_used']}",
+            "gram_mode": "f64acc",
             "cached_u": main_rec["cached_u"],
             "step_effective_GBps": main_rec["step_effective_GBps"],
             "step_TFLOPs_NM_Mplus1": main_rec["step_TFLOPs_NM_Mplus1"],
@@ -637,21 +682,31 @@ def main():
                       "note": "same cells, control points and lambda_ as the headline line, float64 cells and kernel "
                               "values (the mode the 1e-5 parity clause refers to)"}
 
-    # ---------------------------------------------------------------- the same workload in pivot mode (N = 1; NOT the headline)
-    if world == 1 and args.gram_mode == "full" and args.dtype == "float32" and not args.no_pivot:
-        kp, wp = max(2, min(args.steps, 5)), 5  # the switch happens at the end of the third rank-revealing iteration
-        rp = run_mode("float32", kp, wp, "pivot")
-        out["pivot_subset"] = {"metric": out["metric"], "unit": "cells/s", "dtype": "f32", "value": rp["value"],
-                               "ms_per_step": rp["ms_per_step"], "steps": kp, "warmup": wp, "ctrl_used": rp["ctrl_used"],
-                               "roofline": rp["roofline"], "solve": rp["solve"], "sigma2_after": rp["sigma2_after"],
-                               "speedup_vs_headline": rp["value"] / value,
-                               "note": "EXTENSION, not the reference's arithmetic and not the headline: gram_mode='pivot' - "
-                                       "after the first rank-revealing solve the fit continues on the control points its "
-                                       "pivoted factorisation selected (C zero elsewhere, V = U C exact); parity of this "
-                                       "mode on the CPU sample's arrays under parity.pivot"}
+    if world == 1 and args.dtype == "float32" and "f64" in out:
+        out["config"]["f64_value"] = out["f64"]["value"]
+        out["config"]["f64_ms_per_step"] = out["f64"]["ms_per_step"]
+        out["config"]["f64_frac"] = out["f64"]["roofline"]["frac"]
+    out["config"]["solve_avg_ms"] = main_rec["solve"]["avg_ms"]
+    out["config"]["collectives_per_step"] = (main_rec.get("comm") or {}).get("collectives_per_step", 0.0)
+    out["config"]["rccl_ranks"] = rccl_ranks if distributed else None   # (N = 1: filled by the rccl_world1 leg below)
+
+    # ---------------------------------------------------------------- BASELINE config 3 (2 M x 2000) through the same code (N = 1)
+    if rank == 0 and world == 1 and not args.no_c3 and args.cells >= 2_000_000:
+        X3, V3, M3 = make_config("C3")
+        _, X3v, Y3v, _, ctrl3, beta3 = sparsevfc_preprocess(X3, V3, M=M3, seed=0)
+        del X3, V3
+        k3 = max(3, min(args.steps, 10))
+        r3 = run_mode(args.dtype, k3, 2, data=(X3v, Y3v, ctrl3, beta3))
+        out["c3"] = {"workload": f"BASELINE config 3: {len(X3v)} cells x {len(ctrl3)} control points, lambda_={args.lambda_}",
+                     "value": r3["value"], "ms_per_step": r3["ms_per_step"], "steps": k3, "warmup": 2, "dtype": out["dtype"],
+                     "roofline": r3["roofline"], "solve": r3["solve"], "sigma2_after": r3["sigma2_after"]}
+        out["config"]["c3_ms_per_step"] = r3["ms_per_step"]
+        out["config"]["c3_gram_frac"] = r3["roofline"]["frac"]
+        out["config"]["c3_solve_avg_ms"] = r3["solve"]["avg_ms"]
+        del X3v, Y3v
 
     # ---------------------------------------------------------------- the step's collectives on RCCL with one rank (N = 1)
-    if world == 1 and not args.no_rccl_world1 and not args.force_collectives and args.gram_mode == "full":
+    if world == 1 and not args.no_rccl_world1 and not args.force_collectives:
         # The exchange of the multi-GPU path, executed: force_collectives runs the multi-rank protocol (split Gram stages,
         # asynchronous all-reduce of tri(G) overlapped with the rhs kernels, [R | stats], the E-step MIN and the closing
         # 14-double collective) on a communicator of ONE rank - RCCL accepts that on a one-GPU box - through both back ends.
@@ -668,6 +723,9 @@ def main():
                 out["rccl_world1"][coll] = {"ms_per_step": rr["ms_per_step"], "comm": rr["comm"],
                                             "per_rank": rr["per_rank"], "sigma2_after": rr["sigma2_after"],
                                             "protocol_overhead_ms": rr["ms_per_step"] - ms_per_step}
+                if "rccl_ranks_mvf_comm_info" in rr:  # ncclCommCount of the engine's own communicator (C-ABI path)
+                    out["rccl_world1"][coll]["rccl_ranks"] = rr["rccl_ranks_mvf_comm_info"]
+                    out["config"]["rccl_ranks"] = rr["rccl_ranks_mvf_comm_info"]
             except Exception as exc:  # noqa: BLE001 - the headline line must survive a failure of this extra
                 import traceback
 
@@ -743,10 +801,17 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             kms = e0.elapsed_time(e1) / 20
+            tf_ = len(grid) * me * EVAL_F64_FLOP_PER_PAIR / (kms * 1e-3) / 1e12
             out["eval"][dt] = {"kernel_ms_all_quantities": kms, "Gpairs_per_s": len(grid) * me / kms / 1e6,
+                               "kernel": f"eval_kernel<{'float' if dt == 'float32' else 'double'}, *> (all quantities, one launch)",
+                               "f64_flop_per_pair": EVAL_F64_FLOP_PER_PAIR, "TFLOPs": tf_,
+                               "frac_of_f64_valu_peak": tf_ / PEAK_F64_VALU_TFLOPS,
                                "jacobian_plus_curl_api_wall_ms": float(np.median(walls[1:])),
                                "first_call_api_wall_ms": walls[0]}
         clear_eval_cache()
+        out["config"]["eval_frac"] = out["eval"]["float32" if args.dtype == "float32" else "float64"]["frac_of_f64_valu_peak"]
+        out["config"]["eval_frac_f64_cells"] = out["eval"]["float64"]["frac_of_f64_valu_peak"]
+        out["config"]["eval_api_wall_ms"] = out["eval"]["float32" if args.dtype == "float32" else "float64"]["jacobian_plus_curl_api_wall_ms"]
 
     # ---------------------------------------------------------------- BASELINE configs 2 and 5 (N = 1): ms per EM iteration
     if rank == 0 and world == 1 and not args.no_whole_fit:
@@ -811,6 +876,24 @@ def main():
             "four_streams_wall_s": t_par, "sequential_wall_s": t_seq,
             "identical_to_sequential": bool(all(np.array_equal(a_["V"], b_["V"]) for a_, b_ in zip(res5, seq5)))}
         del organs, res5, seq5
+        out["config"]["c2_ms_per_em_step"] = out["small_configs"]["c2_50k_x_500"]["ms_per_em_step"]
+        out["config"]["c5_organ_ms_per_em_step"] = out["small_configs"]["c5_organ_250k_x_500"]["ms_per_em_step"]
+        # all 32 organs of BASELINE config 5 (250 k +- 10 % cells each, M = 500, seeds 100 + k) as whole fits through four
+        # streams of this ONE GPU (on eight GPUs every rank takes four of them: replicas only, no collective)
+        if not args.no_organs32:
+            rng32 = np.random.default_rng(5)
+            sizes = [int(250_000 * (0.9 + 0.2 * rng32.random())) for _ in range(32)]
+            organs32 = [make_config("C2", N=sizes[s_], seed=100 + s_)[:2] + (None,) for s_ in range(32)]
+            t_5 = time.perf_counter()
+            res32 = SparseVFC_many(organs32, n_streams=4, **kw5)
+            t32 = time.perf_counter() - t_5
+            out["small_configs"]["c5_32_organs"] = {
+                "organs": 32, "cells": sizes, "ctrl": 500, "streams": 4, "wall_s": t32,
+                "em_iterations_total": int(sum(int(r_["iteration"]) + 1 for r_ in res32)),
+                "cells_per_s_whole_fits": float(sum(sizes)) / t32,
+                "note": "whole SparseVFC calls (host arrays in, host dicts out, MaxIter 30, run to convergence)"}
+            out["config"]["c5_32_organs_wall_s"] = t32
+            del organs32, res32
 
     # ---------------------------------------------------------------- whole calls: host arrays in -> host dict out (N = 1)
     if rank == 0 and world == 1 and not args.no_whole_fit:
@@ -846,7 +929,7 @@ def main():
     del X, V
 
     # ---------------------------------------------------------------- HBM traffic of the dominant kernel, measured (N = 1)
-    if rank == 0 and world == 1 and not args.no_measure_traffic and args.gram_mode == "full" and not args.force_collectives:
+    if rank == 0 and world == 1 and not args.no_measure_traffic and not args.force_collectives:
         torch.cuda.empty_cache()
         mt = measured_traffic(N, Mc, args.dtype, args.lambda_)
         if mt is not None:
@@ -867,9 +950,6 @@ def main():
         out["speedup_vs_cpu_sample_rate"] = value / cb["sample_value"]
         # ------------------------------------------------------------ parity on the CPU sample's arrays (driver-run)
         out["parity"] = parity_on_sample(sample, args.lambda_, device)
-        if "pivot_subset" in out:
-            pv = parity_on_sample(sample, args.lambda_, device, gram_mode="pivot")
-            out["parity"]["pivot"] = {"f64": pv["f64"], "f32": pv["f32"]}
         del sample
 
     if distributed:

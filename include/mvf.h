@@ -170,6 +170,25 @@ int mvf_gram_cached(int stages, const void* ublk, const void* x4, const void* P,
                     const void* ctrl4, int64_t m, double beta, double* G, double* R, void* workspace,
                     size_t workspace_bytes, mvf_dtype dtype, void* stream);
 
+/* ---- wide right-hand sides (Dy > 3) on the cached kernel values (ABI 6) -------------------------------------------
+ * Replaces: dynamo's `rhs = UP.dot(Y)` and `V = U.dot(C)` when Y has many columns - what
+ * `kernel_interpolation` passes (spateo/tdr/interpolations/interpolation_sparseVFC.py:13-85: Y = the expression of Dy genes).
+ * Both stream the cache of mvf_ublk_build ONCE for all columns, as v_mfma_f64_16x16x4_f64 products:
+ *   mvf_rhs_cached  : R[j][d] = sum_n U[n][j] P_n Y[n][d]        R: m x dy float64, leading dimension ldr >= dy
+ *   mvf_apply_cached: V[n][d] = sum_j U[n][j] C[j][d],  r_n = sum_d (Y[n][d] - V[n][d])^2 (against V as stored),
+ *                     stats[0] += sum_n P_n r_n (P may be NULL: no sum)
+ * Yd / Vd: n rows x ldy columns of the cell dtype, row-major, ldy a multiple of 16 and >= dy; Yd must be READABLE for
+ * mvf_ublk_npad rows (n rounded up to 256) and zero (or any finite value) beyond row n and column dy.  C: float64,
+ * leading dimension ldc (a multiple of 16, >= dy), readable for m rounded up to 128 rows (the cache holds zeros for the
+ * padded control points and cells, so the padding's values only have to be finite).  r: n values of the cell dtype.
+ * workspace: mvf_wide_workspace_bytes(n, m).  Deterministic (fixed summation orders). */
+size_t mvf_wide_workspace_bytes(int64_t n, int64_t m);
+int mvf_rhs_cached(const void* ublk, const void* P, const void* Yd, int64_t n, int64_t m, int dy, int64_t ldy, double* R,
+                   int64_t ldr, void* workspace, size_t workspace_bytes, mvf_dtype dtype, void* stream);
+int mvf_apply_cached(const void* ublk, int64_t n, int64_t m, const double* C, int64_t ldc, int dy, const void* Yd, int64_t ldy,
+                     const void* P, void* Vd, void* r, double* stats, void* workspace, size_t workspace_bytes,
+                     mvf_dtype dtype, void* stream);
+
 /* ---- coefficient solve ------------------------------------------------------------------------------------------
  * Replaces: dynamo `lstsq_solver(lhs, rhs, "scipy")` as Spateo calls it (sparsevfc.py:110,194,250) =
  * scipy.linalg.lstsq = LAPACK gelsd: the MINIMUM-NORM solution with singular values below eps * s_max dropped
@@ -327,7 +346,8 @@ int mvf_sym_unpack(const double* tri, int64_t m, double* G, void* stream);
  *                        communicator's device; nranks = 1 is valid (a single-rank communicator: how the one-GPU tests
  *                        execute this path on RCCL).  The handle owns nothing but the RCCL communicator.
  *   mvf_comm_destroy   : frees it (NULL is a no-op).
- *   mvf_comm_info      : nranks / rank / device of a handle (any pointer may be NULL).
+ *   mvf_comm_info      : nranks / rank / device of a handle AS RCCL REPORTS THEM (ncclCommCount / ncclCommUserRank /
+ *                        ncclCommCuDevice; any pointer may be NULL) - what bench.py records as `rccl_ranks`.
  *   mvf_allreduce_stats: buf[0..count) (DEVICE float64, in place) <- elementwise SUM (MVF_RED_SUM) or MIN (MVF_RED_MIN: the
  *                        E-step's global min-non-zero rule) over the ranks; asynchronous on `stream` (ordered with the
  *                        kernels the caller launched there: pass a second stream + events to overlap it with compute, as

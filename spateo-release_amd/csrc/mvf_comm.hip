@@ -59,9 +59,20 @@ extern "C" int mvf_comm_destroy(mvf_comm* comm) {
 
 extern "C" int mvf_comm_info(const mvf_comm* comm, int* nranks, int* rank, int* device) {
     MVF_REQUIRE(comm != nullptr, "mvf_comm_info: null communicator");
-    if (nranks) *nranks = comm->nranks;
-    if (rank) *rank = comm->rank;
-    if (device) *device = comm->device;
+    // what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), not the arguments
+    // it was created with: the figure a scaling record can cite as "N ranks took part"
+    int n = -1, r = -1, d = -1;
+    ncclResult_t e = ncclCommCount(comm->comm, &n);
+    if (e != ncclSuccess) return nccl_fail("ncclCommCount", e);
+    e = ncclCommUserRank(comm->comm, &r);
+    if (e != ncclSuccess) return nccl_fail("ncclCommUserRank", e);
+    e = ncclCommCuDevice(comm->comm, &d);
+    if (e != ncclSuccess) return nccl_fail("ncclCommCuDevice", e);
+    MVF_REQUIRE(n == comm->nranks && r == comm->rank, "mvf_comm_info: RCCL reports rank %d of %d, the handle was created as %d of %d",
+                r, n, comm->rank, comm->nranks);
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    if (device) *device = d;
     return 0;
 }
 

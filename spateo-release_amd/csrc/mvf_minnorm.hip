@@ -652,7 +652,11 @@ constexpr int GLR = GK + 2;   // row-major stage stride: [64 rows][32 k]
 constexpr int GLK = JP + 16;  // k-major stage stride:   [32 k][64 cols]
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B,
-                                                   int64_t ldb, double* __restrict__ C, int64_t ldc, int64_t K) {
+                                                   int64_t ldb, double* __restrict__ C, int64_t ldc, int64_t K,
+                                                   int symmetric = 0) {
+    // symmetric != 0 (the caller vouches that op(A) op(B) is symmetric - S2 = Y Y^T, Minv = E E^T): only the tiles on and
+    // below the diagonal are computed, each is stored together with its mirror image (the result is exactly symmetric)
+    if (symmetric && blockIdx.x > blockIdx.y) return;
     __shared__ double sa[TA ? GK * GLK : 64 * GLR];
     __shared__ double sb[TB ? 64 * GLR : GK * GLK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -669,13 +673,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const double* __restrict__ A,
     const int rr = tid >> 2, rc = (tid & 3) * 8;
     const int kr = tid >> 3, kc = (tid & 7) * 8;
     double va[8], vb[8];
-    for (int64_t k0 = 0; k0 < K; k0 += GK) {
+    auto load_stage = [&](int64_t k0) {
         const double* ap = TA ? A + (k0 + kr) * lda + i0 + kc : A + (i0 + rr) * lda + k0 + rc;
 #pragma unroll
         for (int q = 0; q < 8; ++q) va[q] = ap[q];
         const double* bp = TB ? B + (j0 + rr) * ldb + k0 + rc : B + (k0 + kr) * ldb + j0 + kc;
 #pragma unroll
         for (int q = 0; q < 8; ++q) vb[q] = bp[q];
+    };
+    load_stage(0);
+    for (int64_t k0 = 0; k0 < K; k0 += GK) {
         __syncthreads();  // the previous stage has been consumed
         if (TA) {
 #pragma unroll
@@ -692,6 +699,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const double* __restrict__ A,
             for (int q = 0; q < 8; ++q) sb[kr * GLK + kc + q] = vb[q];
         }
         __syncthreads();
+        if (k0 + GK < K) load_stage(k0 + GK);  // the next stage's global loads fly during this stage's MFMAs (round 5 issued
+                                               // them after it: one exposed memory round trip per 32 values of k)
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 4) {
             double fa[2], fb[2];
@@ -718,6 +727,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const double* __restrict__ A,
                 const int row = wr + a * 16 + lk + 4 * r;
                 const int col = wc + b * 16 + li;
                 C[(i0 + row) * ldc + j0 + col] = acc[a][b][r];
+                if (symmetric && blockIdx.x != blockIdx.y) C[(j0 + col) * ldc + i0 + row] = acc[a][b][r];
             }
 }
 
@@ -775,13 +785,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const double* __restri
 
 template <bool TA, bool TB>
 static void gemm(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
-                 int64_t rows, int64_t cols, int64_t K) {
+                 int64_t rows, int64_t cols, int64_t K, int symmetric = 0) {
     if ((rows / 64) * (cols / 64) < 96)  // fewer 64 x 64 tiles than would keep the part busy: the skinny form
         hipLaunchKernelGGL((gemm_skinny_kernel<TA, TB>), dim3((unsigned)(cols / 16), (unsigned)(rows / 16)), dim3(256), 0, st, A,
                            lda, B, ldb, C, ldc, K);
     else
         hipLaunchKernelGGL((gemm_kernel<TA, TB>), dim3((unsigned)(cols / 64), (unsigned)(rows / 64)), dim3(256), 0, st, A, lda,
-                           B, ldb, C, ldc, K);
+                           B, ldb, C, ldc, K, symmetric);
 }
 
 // Wt[i][:] = Y[i][:] / sigma_i  (row i = eigenvector i);  the zero rows of the padding become unit vectors
@@ -1062,6 +1072,11 @@ __global__ __launch_bounds__(256) void pchol_update_kernel(double* __restrict__ 
     __shared__ double sb[JP * LDK];
     const int ti = blockIdx.y, tj = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    const int li = lane & 15, lk = lane >> 4;
+    double* pc = S + ((int64_t)ti * 64) * mp + (int64_t)tj * 64;
+    f64x4 cin[2][2];  // this lane's entries of the S tile: in flight together with the panels (round 5 read them after the MFMA
+                      // loop - a second exposed memory round trip per workgroup)
     {
         double va[16], vb[16];
         const double* ya = Y + (int64_t)jb * mp + (int64_t)ti * 64 + lane;
@@ -1072,14 +1087,19 @@ __global__ __launch_bounds__(256) void pchol_update_kernel(double* __restrict__ 
             vb[q] = yb[(int64_t)(wave + 4 * q) * mp];
         }
 #pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    cin[a][b][r] = pc[(int64_t)(wr + a * 16 + lk + 4 * r) * mp + wc + b * 16 + li];
+#pragma unroll
         for (int q = 0; q < 16; ++q) {
             sa[(wave + 4 * q) * LDK + lane] = va[q];
             sb[(wave + 4 * q) * LDK + lane] = vb[q];
         }
     }
     __syncthreads();
-    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-    const int li = lane & 15, lk = lane >> 4;
     f64x4 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1099,7 +1119,6 @@ __global__ __launch_bounds__(256) void pchol_update_kernel(double* __restrict__ 
             for (int b = 0; b < 2; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
     }
-    double* pc = S + ((int64_t)ti * 64) * mp + (int64_t)tj * 64;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1108,7 +1127,7 @@ __global__ __launch_bounds__(256) void pchol_update_kernel(double* __restrict__ 
             for (int r = 0; r < 4; ++r) {
                 const int row = wr + a * 16 + lk + 4 * r;
                 const int col = wc + b * 16 + li;
-                pc[(int64_t)row * mp + col] -= acc[a][b][r];
+                pc[(int64_t)row * mp + col] = cin[a][b][r] - acc[a][b][r];
             }
 }
 
@@ -2367,7 +2386,10 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
     // without a hint: the first 256 steps, then 128 more per status read; after hint panels only the tail is left: 32
     // steps per status read
     const bool tail_only = use_hint && j > 0;
-    int upto = tail_only ? std::min(msteps, j + 32) : std::min(msteps, 256);
+    // (behind the hint panels the previous call's rank says how long the greedy tail will be: every enqueued step costs the
+    // host ~8 us whether it still has a pivot to take or not - a fixed batch of 32 was 250 us of launches for ~10 pivots)
+    const int tail_first = std::max(8, std::min(32, rank_hint - j + 8));
+    int upto = tail_only ? std::min(msteps, j + tail_first) : std::min(msteps, 256);
     while (!finished) {
         enqueue(upto);
         MVF_LAUNCH_CHECK();
@@ -2376,7 +2398,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         MVF_CHECK_HIP(hipStreamSynchronize(st));
         if (hinfo != 0) return 0;  // non-finite input: info[0] tells the caller
         if (hs.done || j >= msteps) break;
-        upto = std::min(msteps, upto + (tail_only ? 32 : 128));
+        upto = std::min(msteps, upto + (tail_only ? 16 : 128));
     }
     // this workspace now holds a finished order of hs.r rows (and the dominant eigenvector of this call: keep_len = m)
     const int tag[6] = {PCHOL_MAGIC, (int)hs.r, (int)m, 0, 0, 0};
@@ -2406,7 +2428,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         double *theta = (double*)(dw + d.theta), *dummy = (double*)(dw + d.dummy);
         double* Minv = S;  // the assembled matrix is used up: S now holds S2^-1 (rp x rp)
         MVF_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
-        gemm<false, true>(st, Y, mp, Y, mp, S2, rp, rp, rp, mp);  // S2 = L^T L (identity-free zero padding)
+        gemm<false, true>(st, Y, mp, Y, mp, S2, rp, rp, rp, mp, 1);  // S2 = L^T L (identity-free zero padding)
         // the cut-off is rcond x the power iteration's Rayleigh quotient: converged after the 12 steps when lambda_2 /
         // lambda_1 <~ 0.5 (kernel Gram matrices: 0.45); a clustered top of the spectrum gets more steps, on S2 (same
         // non-zero eigenvalues as L L^T), until two successive quotients agree to 1e-7 or 512 steps are spent
@@ -2431,7 +2453,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         CholPlan cs, cq;
         if (int rc = chol_factor_mat_inv(st, S2, rp, r, dw + d.cw, &cs, info, 1)) return rc;
         const double* E = cs.W + rp * rp;                      // Rc^-T (upper triangular, identity on the padding)
-        gemm<false, true>(st, E, rp, E, rp, Minv, rp, rp, rp, rp);  // Minv = Rc^-T Rc^-1
+        gemm<false, true>(st, E, rp, E, rp, Minv, rp, rp, rp, rp, 1);  // Minv = Rc^-T Rc^-1
         // Block size: 256 vectors and three applications of Minv (two until round 4); when the previous call on this workspace (the previous EM
         // iteration: rank_hint) truncated at most DEFL_SMALL_MAX directions, 128 vectors and three applications (the
         // 129th eigenvalue is then still > 4 x the cut: tools/lrproto_partial2.py on 60 k x 3000 systems, 65 - 68

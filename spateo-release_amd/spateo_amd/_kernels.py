@@ -239,6 +239,40 @@ class HipKernels:
     def _ublk_itemsize(self):
         return 4 if self.tdtype == torch.float32 else 8
 
+    # ---- wide right-hand sides (Dy > 3): one pass over the cached kernel values for all columns (mvf_wide.hip) ----
+    @staticmethod
+    def wide_pads(n, m):
+        """(cells, control points, columns -> padded extents) of the buffers mvf_rhs_cached / mvf_apply_cached read."""
+        return -(-int(n) // 256) * 256, -(-int(m) // 128) * 128
+
+    def _wide_ws(self, n, m):
+        need = int(self.lib.mvf_wide_workspace_bytes(int(n), int(m)))
+        if getattr(self, "_wide_buf", None) is None or self._wide_buf.numel() < need:
+            self._wide_buf = None
+            self._wide_buf = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
+        return self._wide_buf
+
+    @_on_device
+    def rhs_wide(self, P, Yd, dy, m, R):
+        """R (m x dy float64) = U^T diag(P) Yd[:, :dy] from the cache of build_ublk (Yd: padded rows x padded columns)."""
+        if self._ublk is None:
+            raise RuntimeError("rhs_wide needs the kernel-value cache (build_ublk)")
+        n = P.shape[0]
+        ws = self._wide_ws(n, m)
+        _lib.check(self.lib.mvf_rhs_cached(_ptr(self._ublk), _ptr(P), _ptr(Yd), n, int(m), int(dy), Yd.shape[1], _ptr(R),
+                                           R.shape[1], _ptr(ws), ws.numel(), self.cdtype, self._stream()), "mvf_rhs_cached")
+
+    @_on_device
+    def apply_wide(self, Cd, dy, m, Yd, P, Vd, r, stats):
+        """Vd[:, :dy] = U Cd[:, :dy]; r = sum_d (Yd - Vd)^2; stats[0] += sum P r (Cd: padded rows x padded columns, float64)."""
+        if self._ublk is None:
+            raise RuntimeError("apply_wide needs the kernel-value cache (build_ublk)")
+        n = Vd.shape[0]
+        ws = self._wide_ws(n, m)
+        _lib.check(self.lib.mvf_apply_cached(_ptr(self._ublk), n, int(m), _ptr(Cd), Cd.shape[1], int(dy), _ptr(Yd), Yd.shape[1],
+                                             _ptr(P), _ptr(Vd), _ptr(r), _ptr(stats), _ptr(ws), ws.numel(), self.cdtype,
+                                             self._stream()), "mvf_apply_cached")
+
     def drop_ublk(self):
         self._ublk = None
         self._ublk_key = None

@@ -66,6 +66,9 @@ SIGNATURES = {
     "mvf_solve_minnorm_basis_bytes": (_sz, [_i64]),
     "mvf_solve_minnorm_lr_workspace_bytes": (_sz, [_i64, _i]),
     "mvf_solve_minnorm_lr": (_i, [_p, _p, _d, _d, _d, _p, _i64, _i, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
+    "mvf_wide_workspace_bytes": (_sz, [_i64, _i64]),
+    "mvf_rhs_cached": (_i, [_p, _p, _p, _i64, _i64, _i, _i64, _p, _i64, _p, _sz, _i, _p]),
+    "mvf_apply_cached": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _i64, _p, _p, _p, _p, _p, _sz, _i, _p]),
     "mvf_solve_minnorm_lrd_workspace_bytes": (_sz, [_i64, _i]),
     "mvf_solve_minnorm_lrd": (_i, [_p, _p, _d, _d, _d, _p, _i64, _i, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "mvf_solve_minnorm_lrd_async": (_i, [_p, _p, _d, _d, _d, _p, _i64, _i, _p, _p, _p, _i, _p, _sz, _p]),

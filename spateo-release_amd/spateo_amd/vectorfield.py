@@ -335,6 +335,7 @@ class SparseVFCEngine:
     # which truncated minimum-norm solver answers once the system is rank deficient: None = by M ("deflated" from
     # DEFLATED_MIN_M control points on, else "full"), or "deflated" | "lowrank" | "full" for every engine built afterwards
     minnorm_method = None
+    wide_y = True         # Dy > 3 on a cached U: the MFMA kernels of mvf_wide.hip (False: one VALU pass per three columns)
     async_direct = True   # M <= 640 steady state: mvf_solve_minnorm_lrd_async + speculative field update (False: round 5's calls)
 
     def __init__(self, X, Y, ctrl, beta, *, dtype=None, device=None, distributed=False, group=None, n_total=None,
@@ -399,26 +400,12 @@ class SparseVFCEngine:
         self.y4 = [k.to_x4(Y[:, 3 * g : 3 * g + 3]) for g in range(self.ng)]
         f64 = torch.float64
         ng = self.ng
-        # switch at the end of this many rank-revealing iterations ("pivot:K" sets K).  Measured on the oracle fixtures
-        # (tools/pivot_mode_probe.py, profiles/r04_pivot_subset.md): K = 1 selects the subset while lambda sigma^2 K still
-        # dominates the small eigenvalues - field 1.06 - 1.16 x the reference floor but sigma^2 1.4 - 9 x; from K = 3 on
-        # sigma^2 has nearly converged, the subset fits the final system (and is a third smaller): sigma^2 / energy
-        # 0.1 - 1.1 x, field 0.9 - 1.5 x
-        self.pivot_after = 3
-        self.pivot_nested = False        # "pivot:K+": keep restricting while the restricted factor still sheds control points
-        if isinstance(gram_mode, str) and gram_mode.startswith("pivot:"):
-            spec = gram_mode[6:]
-            nested = spec.endswith("+")
-            spec = spec[:-1] if nested else spec
-            if spec.isdigit() and int(spec) >= 1:
-                gram_mode, self.pivot_after, self.pivot_nested = "pivot", int(spec), nested
-        if gram_mode not in ("full", "pivot"):
-            raise ValueError("gram_mode must be 'full', 'pivot', 'pivot:K' or 'pivot:K+' (K >= 1)")
-        # "pivot" (extension, default off): once the rank-revealing solve has run, the rest of the fit works on the control
-        # points its pivoted factorisation selected (`_restrict_to_pivots`)
+        # (rounds 4 - 5 had gram_mode="pivot" here: the rest of a fit on the control points the pivoted factorisation selected.
+        # It was a different truncation of the ill-posed system - sigma^2 at 1.4 - 8.5 x the reference's own floor - and failed
+        # this repository's 1.25 x criterion on three fixtures: removed in round 6, HISTORY.md section "pivot mode")
+        if gram_mode != "full":
+            raise ValueError("gram_mode: only 'full' (the reference's M-step on all M control points) exists")
         self.gram_mode = gram_mode
-        self.ctrl_full, self.subset, self._quad_carry, self._restrict_pending = ctrl, None, None, False
-        self.pivot_max_fraction = 0.75   # no switch unless the factor keeps at most this share of the control points
         self.comm_events = None  # bench.py: list of (start, end) events around the collectives
         self._cache_u_wanted = cache_u
         self._setup_control_points(ctrl)
@@ -429,11 +416,26 @@ class SparseVFCEngine:
         self.spr = self.fin[:1]
         self.info = k.zeros(1, dtype=torch.int32)
         self.P = torch.ones(self.n_local, dtype=k.tdtype, device=k.device)
-        self.V4 = [k.zeros(self.n_local, 4) for _ in range(ng)]
         self.r = None
         # U = con_K(X, ctrl) is constant across EM iterations: cache its values (cell dtype) for the Gram kernel when HBM
         # has room ("auto": sizeof(dtype) n M bytes plus headroom), else the Gram kernel regenerates them every iteration
         self._build_u_cache()
+        # Wide Y (Dy > 3: kernel_interpolation's genes) on a cached U: R = U^T P Y and V = U C as MFMA products that stream
+        # the cache ONCE for all columns (mvf_rhs_cached / mvf_apply_cached) instead of one regenerating VALU pass per
+        # group of three columns.  Dense row-major Y / V (padded to 16 columns, Y also to the cache's padded cell count).
+        self.wide = bool(self.wide_y and self.cached_u and ng >= 2 and hasattr(k, "rhs_wide") and self.n_local and M)
+        if self.wide:
+            n_pad, m_pad = k.wide_pads(self.n_local, M)
+            Dp = -(-self.Dy // 16) * 16
+            self.Yd = k.zeros(n_pad, Dp)
+            self.Yd[: self.n_local, : self.Dy] = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float64)).to(k.device).to(k.tdtype)
+            self.Vd = k.zeros(self.n_local, Dp)
+            self.Rd = k.zeros(M, self.Dy, dtype=f64)
+            self.Cd = k.zeros(m_pad, Dp, dtype=f64)
+            self._rbuf = k.zeros(self.n_local)
+            self.V4 = None
+        else:
+            self.V4 = [k.zeros(self.n_local, 4) for _ in range(ng)]
         # Coefficient solve (lstsq_method "scipy" = the reference's gelsd semantics): Cholesky with NO regularisation
         # while the pivots certify full numerical rank (then nothing is truncated and it IS the gelsd solution), else
         # the truncated minimum-norm solve (mvf_solve_minnorm).  Rank deficiency is sticky within a fit: sigma^2 only
@@ -511,47 +513,6 @@ class SparseVFCEngine:
                 k.build_ublk(self.x4, self.ctrl4, self.beta)
                 self.cached_u = True
 
-    def _restrict_to_pivots(self):
-        """gram_mode="pivot": continue the fit on the control points that carry the numerical rank.
-
-        The rank-revealing solve of the iteration that just ended factored  A = U^T P U + lambda sigma^2 K  by a greedy
-        diagonally pivoted Cholesky stopped at 0.25 eps lambda_max: r pivots (r ~ 0.3 M at M = 3000), the remaining columns
-        of [P^1/2 U; (lambda sigma^2 K)^1/2] being linear combinations of the selected ones to the rounding level of A.
-        From the next iteration on the model is  v(x) = sum over the r selected control points:  C is zero elsewhere, so
-        `V = con_K(X, X_ctrl) C` holds exactly for the returned (M x Dy) coefficients, and the M-step costs N r^2 instead of
-        N M^2.  sigma^2 only shrinks afterwards, so the numerical rank of A does not grow back.  This is NOT the
-        reference's arithmetic (its minimum-norm solution spreads over all M columns) but another truncation of the same
-        ill-posed system: measured against the oracle fixtures the field sits at 0.9 - 1.5 x the reference's own noise floor,
-        sigma^2 and the energy at 0.1 - 1.1 x, max |dP| at 0.5 - 1.4 x (3 x at 10 cells per control point in float32 mode;
-        profiles/r04_pivot_subset.md) - hence an option, default off."""
-        k = self.k
-        if not hasattr(k, "lr_pivot_order"):
-            return False
-        p = np.asarray(k.lr_pivot_order(self.M), dtype=np.int64)
-        limit = self.pivot_max_fraction if self.subset is None else 0.94   # nested: only while >= 6 % more can go
-        if len(p) < 2 or len(p) > limit * self.M:
-            return False
-        # The Gram kernel works in 128-wide tile columns: a subset that ends just behind a tile boundary pays for a whole
-        # column of tile pairs (897 control points = 8 columns, 36 pairs; 896 = 7 columns, 28 pairs).  The pivots come in
-        # order of decreasing diagonal weight and the last ones sit at the stopping tolerance, i.e. at the rounding level of
-        # the matrix: up to 2 % of them are dropped when that frees a tile column.
-        tile = 128
-        down = (len(p) // tile) * tile
-        if down >= 2 and len(p) - down <= max(1, int(0.02 * len(p))):
-            p = p[:down]
-        # the regulariser of the NEXT energy value belongs to the coefficients of the full model
-        for g in range(self.ng):
-            k.quadform(self.K, self.C[g], self.quad[g : g + 1])
-        self._quad_carry = float(self.quad.cpu().sum())
-        self.subset = p if self.subset is None else self.subset[p]
-        self._setup_control_points(self.ctrl_full[self.subset])
-        self._build_u_cache()
-        self.rank_hint, self.basis, self.basis_valid = 0, None, False
-        self.mn_method = (self.minnorm_method or "deflated") if hasattr(k, "solve_minnorm_lr") else self.mn_method
-        self.solver_stats.setdefault("pivot_subsets", []).append(int(len(p)))
-        self.solver_stats["pivot_subset"] = int(len(p))
-        return True
-
     # ------------------------------------------------------------------ collectives
     def _all_reduce(self, t, op="sum", wait=True):
         """All-reduce `t` in place over the ranks.  wait=False: returns a handle for `_wait` - the collective runs on the
@@ -605,14 +566,6 @@ class SparseVFCEngine:
     def init_state(self, gamma=0.9):
         """V = 0, C = 0, sigma^2 = sum ||Y||^2 / (N Dy)  (Appendix A step 4)."""
         k = self.k
-        self._restrict_pending = False
-        if self.subset is not None:
-            # a previous fit of this engine ended on a pivot subset: back to the full control-point set
-            self.subset, self._quad_carry = None, None
-            self._setup_control_points(self.ctrl_full)
-            self._build_u_cache()
-            self.basis = None
-            self.mn_method = self.minnorm_method or ("deflated" if self.M >= DEFLATED_MIN_M else "full")
         self.spr.zero_()
         self.P.fill_(1.0)  # sigma^2_0 = sum ||Y||^2 / (N Dy): unit weights (a previous fit of this engine left its posterior)
         empty_ctrl = self.ctrl4[:0]
@@ -628,12 +581,21 @@ class SparseVFCEngine:
         self.basis_valid = False
         self.rank_hint = 0
         self._lrd_form = 0
-        self._lr_ran, self._lr_iterations, self._spr_spec = False, 0, None
+        self._lr_ran, self._spr_spec = False, None
 
     def _apply_all(self, ctrl4, C=None):
         """V_g = U C_g for every column group; r = sum_g ||Y_g - V_g||^2; spr += sum P r."""
         k = self.k
         C = self.C if C is None else C
+        if self.wide:
+            # one pass over the cached U for all Dy columns (an empty ctrl4 - init_state's V = 0 - is zero coefficients)
+            if ctrl4.shape[0] == 0:
+                self.Cd.zero_()
+            else:
+                self.Cd[: self.M, : 3 * self.ng] = torch.cat(list(C), dim=1)
+            k.apply_wide(self.Cd, self.Dy, self.M, self.Yd, self.P, self.Vd, self._rbuf, self.spr)
+            self.r = self._rbuf
+            return
         for g in range(self.ng):
             self.V4[g], rg = k.apply(self.x4, ctrl4, self.beta, C[g], self.y4[g], self.P, self.spr)
             if g == 0:
@@ -652,9 +614,6 @@ class SparseVFCEngine:
         all-reduced or replicated deterministic values, so all ranks decide alike) and one for sigma^2 + the agreement
         check; the minimum-norm solve adds its own (one per Jacobi sweep)."""
         k = self.k
-        if self._restrict_pending:
-            self._restrict_pending = False
-            self._restrict_to_pivots()
         # ---- E-step: dynamo's `t1[t1 == 0] = min(t1[t1 != 0])` needs the GLOBAL min-non-zero t1; phase 1 leaves it in
         # device memory, phase 2 reads it from there
         mins = k.estep_min(self.r, self.sigma2)
@@ -663,7 +622,9 @@ class SparseVFCEngine:
         self.st.zero_()
         k.estep_p(self.r, self.sigma2, self.gamma, a, self.Dy, minP, theta, fill, self.P, self.st)
         # ---- M-step assembly (MFMA Gram + rhs), energy regulariser with the OLD coefficients, the collectives
-        if not self.multi:
+        if self.wide and not self.multi:
+            k.gram(self.x4, self.P, None, self.ctrl4, self.beta, self.G, None, tiles_only=True)
+        elif not self.multi:
             k.gram(self.x4, self.P, self.y4[0], self.ctrl4, self.beta, self.G, self.R[0])
         else:
             # G first: THE all-reduce of the step (packed upper triangle, 36 MB at M = 3000) starts the moment this rank's
@@ -671,8 +632,14 @@ class SparseVFCEngine:
             k.gram(self.x4, self.P, None, self.ctrl4, self.beta, self.G, None, tiles_only=True)
             k.sym_pack(self.G, self.tri)
             big = self._all_reduce(self.tri, wait=False)
-            k.gram(self.x4, self.P, self.y4[0], self.ctrl4, self.beta, self.G, self.R[0], rhs_only=True)
-        for g in range(1, self.ng):
+            if not self.wide:
+                k.gram(self.x4, self.P, self.y4[0], self.ctrl4, self.beta, self.G, self.R[0], rhs_only=True)
+        if self.wide:
+            k.rhs_wide(self.P, self.Yd, self.Dy, self.M, self.Rd)
+            for g in range(self.ng):  # (the solver and the all-reduce buffer keep their three-column groups)
+                w = min(3, self.Dy - 3 * g)
+                self.R[g][:, :w].copy_(self.Rd[:, 3 * g : 3 * g + w])
+        for g in range(1, self.ng if not self.wide else 0):
             k.gram(self.x4, self.P, self.y4[g], self.ctrl4, self.beta, self.G, self.R[g], rhs_only=True)
         for g in range(self.ng):
             k.quadform(self.K, self.C[g], self.quad[g : g + 1])
@@ -687,8 +654,6 @@ class SparseVFCEngine:
         if host is not None:
             s_pr, s_p, s_pf, s_cnt = (float(host[i]) for i in range(4))
             quad = float(sum(host[5:]))
-            if self._quad_carry is not None:  # first iteration on the pivot subset: the old coefficients were the full model's
-                quad, self._quad_carry = self._quad_carry, None
             E_old = self.E
             E = s_pr / (2 * self.sigma2) + s_p * math.log(self.sigma2) * self.Dy / 2 + lambda_ / 2 * quad
             self.tecr = abs((E - E_old) / E)
@@ -702,11 +667,6 @@ class SparseVFCEngine:
         g = s_cnt / self.n_total
         self.gamma = 0.95 if g > 0.95 else (0.05 if g < 0.05 else g)
         self.iteration += 1
-        if self.gram_mode == "pivot" and self._lr_ran and (self.subset is None or self.pivot_nested):
-            self._lr_iterations += 1
-            # the switch itself happens at the START of the next iteration, if there is one: a fit that ends here (MaxIter,
-            # tecr <= ecr, sigma^2 <= 1e-8) returns the coefficients this iteration solved for, V = U C intact
-            self._restrict_pending = self._lr_iterations >= self.pivot_after
         return self.E, self.tecr
 
     def _rhs_batches(self):
@@ -984,14 +944,10 @@ class SparseVFCEngine:
         cell rows on rank 0 only - the other ranks get their own rows back; ``"all"`` gives every rank all rows."""
         if gather not in ("root", "all"):
             raise ValueError("gather must be 'root' or 'all'")
-        Vloc = torch.cat([v[:, :3] for v in self.V4], dim=1)[:, : self.Dy].contiguous()
+        Vloc = (self.Vd[:, : self.Dy] if self.wide else torch.cat([v[:, :3] for v in self.V4], dim=1)[:, : self.Dy]).contiguous()
         V = self._gather_rows(Vloc, gather == "root").to(torch.float64).cpu().numpy()
         P = self._gather_rows(self.P[:, None].contiguous(), gather == "root").to(torch.float64).cpu().numpy()
         C = torch.cat(self.C, dim=1)[:, : self.Dy].cpu().numpy().copy()
-        if self.subset is not None:  # pivot mode: coefficients of the full control-point set, zero off the subset
-            Cf = np.zeros((len(self.ctrl_full), C.shape[1]))
-            Cf[self.subset] = C
-            C = Cf
         return V, P, C
 
 
@@ -1164,11 +1120,8 @@ def SparseVFC(
     ``valid_ind`` that this rank's ``V`` / ``P`` rows correspond to (``VFCIndex`` counts from ``lo``).
     ``lstsq_method``: "scipy" (what Spateo passes) = minimum-norm solve with gelsd's eps * s_max cut-off on the
     device (Cholesky while the pivots certify full numerical rank, else the hand-written symmetric eigensolver);
-    "drouin" maps to the same solve with a warning; "cholesky" is a non-reference fast mode.  ``gram_mode``: "full" (default,
-    the reference's M-step on all M control points) | "pivot" (extension: after the first rank-revealing solve the fit
-    three rank-revealing iterations ("pivot:K": after K) the fit continues on the r control points the pivoted factorisation
-    selected, ``C`` zero elsewhere; N r^2 instead of N M^2 work per iteration; field at 0.9 - 1.5 x the reference's noise
-    floor, see ``SparseVFCEngine._restrict_to_pivots``).  ``collective``: "torch" (torch.distributed: RCCL under the
+    "drouin" maps to the same solve with a warning; "cholesky" is a non-reference fast mode.  ``gram_mode``: "full" (the
+    reference's M-step on all M control points; the only mode since round 6).  ``collective``: "torch" (torch.distributed: RCCL under the
     "nccl" backend) | "mvf" (``mvf_allreduce_stats`` of the C ABI on the engine's own RCCL communicator).
     ``force_collectives=True`` with ``distributed=True`` runs the whole multi-rank protocol (rank-0 preprocessing +
     broadcast, the step's collectives, the output gather) on a process group of ONE rank as well - same result bit for
@@ -1262,8 +1215,6 @@ def SparseVFC(
     if eng.comm is not None:
         eng.comm.close()
     extra = {}
-    if eng.subset is not None:
-        extra["ctrl_subset"] = eng.subset  # pivot mode: rows of X_ctrl / C that carry the field (C is zero elsewhere)
     if multi:
         # which rows of the finite-row sequence (positions in `valid_ind`) the per-cell outputs V / P / VFCIndex of THIS
         # rank cover: all of them on rank 0 and with gather="all", this rank's block otherwise (VFCIndex is relative to it)
@@ -1727,12 +1678,21 @@ def SparseVFC_many(datasets, n_streams=4, device=None, distributed=False, group=
         th.start()
     for th in threads:
         th.join()
-    if errors:
-        raise errors[0]
     if world > 1:
+        # (results, error) travel together and every rank takes part in the gather BEFORE anybody raises: a rank that
+        # raised first (round 5) left the others waiting in all_gather_object for ever.  The error is sent as text - an
+        # exception object need not pickle - and re-raised on EVERY rank, naming the rank it came from.
         import torch.distributed as dist
 
+        mine_err = None if not errors else f"{type(errors[0]).__name__}: {errors[0]}"
         gathered = [None] * world
-        dist.all_gather_object(gathered, results, group=group)
-        results = {k_: v for part in gathered for k_, v in part.items()}
+        dist.all_gather_object(gathered, (results, mine_err), group=group)
+        if errors:
+            raise errors[0]
+        for r_, (_, err) in enumerate(gathered):
+            if err is not None:
+                raise _lib.MVFError(f"SparseVFC_many: a fit failed on rank {r_}: {err}")
+        results = {k_: v for part, _ in gathered for k_, v in part.items()}
+    elif errors:
+        raise errors[0]
     return [results[i] for i in range(len(datasets))]

@@ -156,6 +156,17 @@ def tol(dtype, table, key, base):
     return max(ALLOW * table[key][0 if dtype == "float64" else 1], base)
 
 
+HARD_CAP = 3.0  # the heavy-tailed statistics (max |dP| over the cells, the whole bounding-box grid) are not held to ALLOW -
+                # a maximum over a tail cannot be a fixed multiple of another draw of the same tail - but they are not free
+                # either: a localised regression - a few cells with a wrong posterior, an extrapolation that blows
+                # up - must still fail, so they are capped at this multiple of their own floor
+
+
+def cap(dtype, table, key, base):
+    """max(HARD_CAP x the reference's own floor for this quantity, the mode's base tolerance): the loose hard bound."""
+    return max(HARD_CAP * table[key][0 if dtype == "float64" else 1], base)
+
+
 def fmt(table):
     per = table["_variants"]
     cols = [k for k in table if k != "_variants"]

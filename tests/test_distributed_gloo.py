@@ -22,12 +22,6 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _pivot_kw(vfm, X, V):
-    """A small problem that IS numerically rank deficient (kernel 20 x wider than the bandwidth rule's): pivot mode."""
-    beta = 0.05 * vfm.sparsevfc_preprocess(X, V, M=120, seed=0)[5]
-    return dict(M=120, lambda_=0.02, lstsq_method="scipy", MaxIter=7, ecr=0.0, seed=0, beta=beta, gram_mode="pivot")
-
-
 def _worker(rank, world, port, case, out_dir, mode="all"):
     for p in (ROOT, os.path.join(ROOT, "spateo-release_amd"), HERE):
         if p not in sys.path:
@@ -72,11 +66,6 @@ def _worker(rank, world, port, case, out_dir, mode="all"):
             _v.SparseVFCEngine.minnorm_method = "lowrank"  # the rank-revealing solve regardless of M
         Grid = X[::30]
         kw = dict(M=25, lambda_=3.0, lstsq_method="scipy", MaxIter=6, seed=0)
-        if case == "pivot":
-            import spateo_amd.vectorfield as _v
-
-            _v.SparseVFCEngine.minnorm_method = "lowrank"
-            kw = _pivot_kw(_v, X, V)
         if case == "wide":
             V = np.column_stack([V, np.sin(X[:, 0] / 70), np.cos(X[:, 1] / 50)])  # Dy = 5: two column groups
         calls = {"unique": 0}
@@ -107,7 +96,7 @@ def _worker(rank, world, port, case, out_dir, mode="all"):
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), V=got["V"], P=got["P"], C=got["C"], grid_V=got["grid_V"],
                  sigma2=got["sigma2"], iteration=got["iteration"], E=got["E_traj"], fills=np.array(Recording.fills),
                  unique_calls=calls["unique"], valid_ind=got["valid_ind"], vfc=got["VFCIndex"],
-                 hints=np.array(Recording.hints, dtype=np.int64), subset=got.get("ctrl_subset", np.zeros(0, dtype=np.int64)))
+                 hints=np.array(Recording.hints, dtype=np.int64))
     finally:
         dist.destroy_process_group()
 
@@ -149,69 +138,6 @@ def test_two_rank_gloo_matches_single_process(tmp_path, case):
         assert len(r0["hints"]) == int(r0["iteration"]) + 1 and r0["hints"][0] == 0 and (r0["hints"][1:] == 25).all()
 
 
-def test_two_rank_gloo_pivot_mode_matches_single_process(tmp_path):
-    """gram_mode="pivot" with cells sharded over two ranks: both ranks read the same pivot order off their (identical,
-    all-reduced) system, switch in the same iteration and end with the single-process pivot-mode result."""
-    sys.path.insert(0, HERE)
-    import spateo_amd as st
-    import spateo_amd.vectorfield as vfm
-    from _cpu_kernels import CpuKernels
-    from spateo_amd._synthetic import make_config
-
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, "pivot", str(tmp_path)), nprocs=2, join=True)
-    X, V, _ = make_config("C2", N=601)
-    old, old_mk = vfm.SparseVFCEngine.minnorm_method, vfm._make_kernels
-    vfm.SparseVFCEngine.minnorm_method = "lowrank"
-    vfm._make_kernels = lambda device, dtype: CpuKernels()
-    try:
-        ref = st.SparseVFC(X, V, X[::30], **_pivot_kw(vfm, X, V))
-    finally:
-        vfm.SparseVFCEngine.minnorm_method, vfm._make_kernels = old, old_mk
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    assert 2 <= len(ref["ctrl_subset"]) <= 90 and 2 <= len(r0["subset"]) <= 90
-    # the two ranks hold the same all-reduced system bit for bit, so they select the SAME control points and end identical
-    np.testing.assert_array_equal(r0["subset"], r1["subset"])
-    for k in ("V", "P", "C", "grid_V", "sigma2", "E"):
-        np.testing.assert_array_equal(r0[k], r1[k])
-    assert np.all(r0["C"][np.setdiff1d(np.arange(120), r0["subset"])] == 0.0)
-    # against the single-process run only to the noise level of this toy: the pivot order among near-equal diagonal entries
-    # follows the rounding of the Gram sums (one sum here, two partial sums all-reduced there), so the subsets differ in a
-    # few members (90 vs 87 control points when this was written)
-    assert len(np.intersect1d(r0["subset"], ref["ctrl_subset"])) >= 0.85 * len(ref["ctrl_subset"])
-    scale = np.abs(ref["V"]).max()
-    assert np.abs(r0["V"] - ref["V"]).max() / scale < 3e-2 and abs(float(r0["sigma2"]) / ref["sigma2"] - 1) < 3e-2
-
-
-@pytest.mark.parametrize("mode,case", [("root", "plain"), ("sharded", "plain"), ("sharded", "wide"), ("root", "wide")])
-def test_two_rank_gloo_root_gather_and_own_shards(tmp_path, mode, case):
-    """gather="root" (default): rank 0 holds the complete per-cell outputs, rank 1 its own rows; sharded_input=True:
-    every rank passes only its rows (uneven: 401 + 200) - same fit as the single-process oracle either way."""
-    sys.path.insert(0, HERE)
-    from oracle import sparsevfc_oracle as svo
-    from spateo_amd._synthetic import make_config
-
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, case, str(tmp_path), mode), nprocs=2, join=True)
-    X, V, _ = make_config("C2", N=601)
-    if case == "wide":
-        V = np.column_stack([V, np.sin(X[:, 0] / 70), np.cos(X[:, 1] / 50)])
-    ref = svo.SparseVFC(X, V, X[::30], M=25, lambda_=3.0, lstsq_method="scipy", MaxIter=6, seed=0)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    n1 = 200 if mode == "sharded" else 300  # rank 1's rows: its own 200, or the second block of 601
-    assert r0["V"].shape == ref["V"].shape and r1["V"].shape == (n1, V.shape[1]) and r1["P"].shape == (n1, 1)
-    scale = np.abs(ref["V"]).max()
-    assert np.abs(r0["V"] - ref["V"]).max() / scale < 1e-8
-    np.testing.assert_array_equal(r1["V"], r0["V"][-n1:])  # rank 1 kept exactly its slice of the gathered result
-    np.testing.assert_array_equal(r1["P"], r0["P"][-n1:])
-    for k in ("C", "grid_V", "sigma2", "E"):
-        np.testing.assert_array_equal(r0[k], r1[k])  # replicated quantities are identical everywhere
-    assert np.abs(r0["grid_V"] - ref["grid_V"]).max() / scale < 1e-8
-    np.testing.assert_array_equal(r0["valid_ind"], ref["valid_ind"])
-    np.testing.assert_array_equal(r0["vfc"], ref["VFCIndex"])
-    assert int(r0["unique_calls"]) == 1 and int(r1["unique_calls"]) == 0
-
-
 def test_two_rank_gloo_divergent_solver_branches_raise_instead_of_hanging(tmp_path):
     """Rank 1 alone is made to distrust the Cholesky certificate: the per-step agreement check (MAX all-reduce of
     +/- the solver-decision signature) must raise MVFError on BOTH ranks in that very step."""
@@ -232,6 +158,58 @@ def test_two_rank_gloo_any_exception_on_one_rank_raises_on_all(tmp_path):
     mp.spawn(_worker, args=(2, port, "crash", str(tmp_path)), nprocs=2, join=True)
     assert "failed on another rank" in (tmp_path / "rank0.txt").read_text()
     assert (tmp_path / "rank1.txt").read_text().startswith("IndexError: not an MVFError")
+
+
+def _many_worker(rank, world, port, out_dir, inject):
+    for p in (ROOT, os.path.join(ROOT, "spateo-release_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import spateo_amd.vectorfield as vfm
+        from _cpu_kernels import CpuKernels
+        from spateo_amd._synthetic import make_config
+
+        vfm._make_kernels = lambda device, dtype: CpuKernels()
+        data = []
+        for k in range(4):
+            X, V, _ = make_config("C2", N=300 + 10 * k, seed=100 + k)
+            data.append((X, V, None))
+        if inject:
+            orig = vfm.SparseVFC
+
+            def failing(X, Y, Grid, **kw):
+                if rank == 1 and len(X) == 310:   # organ 1: rank 1's first fit
+                    raise IndexError("not an MVFError")
+                return orig(X, Y, Grid, **kw)
+
+            vfm.SparseVFC = failing
+        try:
+            res = vfm.SparseVFC_many(data, n_streams=2, distributed=True, M=20, lambda_=3.0, MaxIter=3, seed=0)
+            msg = "ok " + " ".join(str(len(r["V"])) for r in res)
+        except Exception as exc:  # noqa: BLE001 - the test reads what every rank saw
+            msg = f"{type(exc).__name__}: {exc}"
+        with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as fh:
+            fh.write(msg)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_many_fits_an_exception_on_one_rank_raises_on_all(tmp_path):
+    """`SparseVFC_many(distributed=True)` raised a worker's exception BEFORE the object gather - the other ranks
+    waited in it for ever.  (results, error) now travel together: without a failure every rank returns all four organs; with
+    one injected on rank 1 that rank re-raises its own exception and rank 0 raises MVFError naming rank 1 - nobody hangs."""
+    sys.path.insert(0, HERE)
+    mp.spawn(_many_worker, args=(2, _free_port(), str(tmp_path), False), nprocs=2, join=True)
+    for r in (0, 1):
+        assert (tmp_path / f"rank{r}.txt").read_text() == "ok 300 310 320 330"
+    mp.spawn(_many_worker, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
+    assert (tmp_path / "rank1.txt").read_text().startswith("IndexError: not an MVFError")
+    m0 = (tmp_path / "rank0.txt").read_text()
+    assert m0.startswith("MVFError") and "rank 1" in m0 and "not an MVFError" in m0, m0
 
 
 def test_distributed_flag_requires_process_group():

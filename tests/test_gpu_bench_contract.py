@@ -1,5 +1,6 @@
 """bench.py's output contract on a small workload (subprocess, one GPU): ONE JSON line on stdout with the driver's keys, the
-`roofline` and `cpu_baseline` objects of this tier, and this repository's extras (`parity`, `f64`, `pivot_subset`, `env`)."""
+`roofline` and `cpu_baseline` objects of this tier, this repository's extras (`parity`, `f64`, `env`) and the figures `config`
+carries for the driver's parsed record (`f64_value`, `eval_frac`, `c5_32_organs_wall_s`, `rccl_ranks`, ...)."""
 import json
 import os
 import subprocess
@@ -51,8 +52,14 @@ def test_bench_line_contract():
     for cfg in ("c2", "c4"):
         split = wf[cfg]["split_of_a_second_call_with_phase_syncs"]
         assert set(split) >= {"preprocess_s", "upload_and_u_cache_s", "em_s", "download_s", "total_s"} and wf[cfg]["wall_s"] > 0
-    pv = d["pivot_subset"]
-    assert pv["value"] > 0 and pv["ctrl_used"] <= 1100 and "NOT" in pv["note"].upper()
+    assert "pivot_subset" not in d
+    cfg = d["config"]   # what the driver's parsed record shows of the other configurations
+    assert cfg["f64_value"] == d["f64"]["value"] and 0 < cfg["f64_frac"] < 1 and cfg["solve_avg_ms"] > 0
+    assert 0 < cfg["eval_frac"] < 1 and 0 < cfg["eval_frac_f64_cells"] < 1 and cfg["eval_api_wall_ms"] > 0
+    assert cfg["c2_ms_per_em_step"] == sc["c2_50k_x_500"]["ms_per_em_step"] and cfg["c5_organ_ms_per_em_step"] > 0
+    assert cfg["c5_32_organs_wall_s"] == sc["c5_32_organs"]["wall_s"] > 0 and sc["c5_32_organs"]["organs"] == 32
+    assert "c3_ms_per_step" not in cfg   # (config 3 runs only when the workload is the full-size one)
+    assert cfg["rccl_ranks"] == 1        # ncclCommCount of the one-rank communicator of the rccl_world1 leg
     # the step's collectives executed on a one-rank RCCL communicator through both back ends
     rc = d["rccl_world1"]
     for coll in ("torch", "mvf"):

@@ -7,7 +7,6 @@
 * one BASELINE config 5 organ at its size (250 k cells x 500);
 * the benchmark's own sizes against the STREAMED oracle's fixtures (round 4): one EM iteration at 8 M x 3000, five at
   1 M x 3000 (one rank's share) and at 2 M x 2000 (BASELINE config 3 at its stated size), every quantity at 1.25 x its floor;
-* the optional pivot-subset mode against the same fixtures, held to its own (documented) limits;
 * float32 mode vs float64 mode at 1 M x 3000 (supplement).
 
 Tolerances (BASELINE.json north_star): field within 1e-5 relative in float64 mode, 1e-3 in float32 mode, wherever the
@@ -105,35 +104,36 @@ def _base_tolerances(dtype, tight=TIGHT):
             "P": 10 * TOL[dtype], "P999": 10 * TOL[dtype]}
 
 
-# Two statistics are REPORTED, not asserted, because a maximum over a heavy tail cannot be held to a fixed multiple of another
-# draw of the same tail (rounds 3 - 4 asserted them with constants fitted to the measurement, 1.75 x / 1.85 x; VERDICT r4
-# weak #3): "P" = max over the cells of |dP| (set by the single worst cell at the inlier / outlier boundary) and "grid" = the
-# whole bounding-box grid (corners 1.75 hull radii out, pure extrapolation).  What is asserted in their place, at the same
-# 1.25 x of every other quantity: "P999" = the 99.9th percentile of |dP| and "grid12" = the grid within 1.2 hull radii
-# (tests/_floors.py: P_QUANTILE, NEAR_RADIUS - definitions, not fits).
-REPORTED_ONLY = {"P": "P999", "grid": "grid12"}
+# Two statistics are held to a LOOSE bound instead of the 1.25 x of every other quantity, because a maximum over a heavy tail
+# cannot be held to a tight multiple of another draw of the same tail (rounds 3 - 4 asserted them with constants fitted to the
+# measurement, 1.75 x / 1.85 x; round 5 only printed them - ADVICE r5: a localised regression must still
+# fail): "P" = max over the cells of |dP| (set by the single worst cell at the inlier / outlier boundary) and "grid" = the
+# whole bounding-box grid (corners 1.75 hull radii out, pure extrapolation) are capped at F.HARD_CAP = 3 x their own floor.
+# What carries the 1.25 x in their place: "P999" = the 99.9th percentile of |dP| and "grid12" = the grid within 1.2 hull
+# radii (tests/_floors.py: P_QUANTILE, NEAR_RADIUS - definitions, not fits).
+LOOSE = {"P": "P999", "grid": "grid12"}
 
 
 def _limits(dtype, table, dev, base):
-    """max(1.25 x floor, base tolerance) for every asserted quantity; None for a reported-only one whose asserted
-    counterpart is present."""
+    """max(1.25 x floor, base tolerance) for every quantity; max(3 x floor, base tolerance) for the two heavy-tailed ones whose
+    tight counterpart is present."""
     lim = {}
     for k in dev:
-        lim[k] = None if (k in REPORTED_ONLY and REPORTED_ONLY[k] in dev) else F.tol(dtype, table, k, base[k])
+        loose = k in LOOSE and LOOSE[k] in dev
+        lim[k] = F.cap(dtype, table, k, base[k]) if loose else F.tol(dtype, table, k, base[k])
     return lim
 
 
 def _report(tag, dtype, dev, fl, lim, extra=""):
     print(f"{tag} {dtype}: {extra}" + "; ".join(
-        f"{k} gpu {dev[k]:.2e} / floor {fl[k]:.2e} (x{dev[k] / max(fl[k], 1e-300):.2f}, " +
-        (f"limit {lim[k]:.2e})" if lim[k] is not None else "reported)") for k in dev))
+        f"{k} gpu {dev[k]:.2e} / floor {fl[k]:.2e} (x{dev[k] / max(fl[k], 1e-300):.2f}, limit {lim[k]:.2e})" for k in dev))
 
 
 def _check_fit(tag, dtype, got, ref, table, masks=None, tight=TIGHT):
     """Every quantity of a whole fit against the oracle, each within max(1.25 x its own reference floor, its base
     tolerance): the field (cells; grid inside the hull; grid within 1.2 hull radii) at the mode's tolerance, sigma^2 /
-    energy at min(mode tolerance, ...) >= `tight`, the 99.9th percentile of |dP| at 10 x the mode's tolerance.  max |dP| and
-    the whole bounding-box grid are printed beside them.  Nothing is conditional."""
+    energy at min(mode tolerance, ...) >= `tight`, the 99.9th percentile of |dP| at 10 x the mode's tolerance; max |dP| and
+    the whole bounding-box grid within max(3 x their floor, their base tolerance).  Nothing is conditional."""
     assert got["iteration"] == ref["iteration"], (got["iteration"], ref["iteration"])
     in_hull, near = masks if masks is not None else (None, None)
     dev = F.deviations(got, ref, in_hull, near)
@@ -142,7 +142,7 @@ def _check_fit(tag, dtype, got, ref, table, masks=None, tight=TIGHT):
     fl = {k: table[k][0 if dtype == "float64" else 1] for k in dev}
     _report(tag, dtype, dev, fl, lim, f"iterations {got['iteration'] + 1}; ")
     print(F.fmt(table))
-    bad = {k: (dev[k], lim[k]) for k in dev if lim[k] is not None and not dev[k] <= lim[k]}
+    bad = {k: (dev[k], lim[k]) for k in dev if not dev[k] <= lim[k]}
     assert not bad, bad
     return dev
 
@@ -239,7 +239,7 @@ def _check_fixture_fit(tag, dtype, got, ref, table, stride=1, tight=TIGHT):
     fl = {k: table[k][0 if dtype == "float64" else 1] for k in dev}
     _report(tag, dtype, dev, fl, lim)
     print(F.fmt(table))
-    bad = {k: (dev[k], lim[k]) for k in dev if lim[k] is not None and not dev[k] <= lim[k]}
+    bad = {k: (dev[k], lim[k]) for k in dev if not dev[k] <= lim[k]}
     assert not bad, bad
     return dev
 
@@ -456,13 +456,13 @@ HEADLINE_SOLVE_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspat
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_the_deflated_solve_on_the_benchmark_system_against_scipy_lstsq(st, dtype):
-    """VERDICT r4 "missing" #5: the 20 timed steps of bench.py run the rank-deficient DEFLATED solve (kept rank ~830 of
-    3000) on the 8 M x 3000 system, but the oracle fixture of that size covers one (full-rank) iteration.  Here the fifth EM
-    iteration's own system  A = U^T P U + lambda sigma^2 K,  R = U^T P Y  (72 MB) is copied to the host and solved with the
-    reference's call, ``scipy.linalg.lstsq`` (gelsd; reached through sparsevfc.py:110,194,250), and with its `gelss` / truncated
-    `eigh` variants for the floor; the fields  V = U C  on every 256th cell (U = the GPU's own kernel values of the mode, the
-    U that was fitted) of the GPU's deflated solve - and, for the record, of its Jacobi path on the same factor - must sit
-    within 1.25 x that floor."""
+    """VERDICT r4 "missing" #5 / r5 next #7: the 20 timed steps of bench.py run the rank-deficient DEFLATED solve (kept rank
+    ~830 of 3000) on the 8 M x 3000 system, but the one-iteration oracle fixture of that size is a full-rank step.  Here the
+    systems of the SECOND to FIFTH EM iteration  A = U^T P U + lambda sigma^2 K,  R = U^T P Y  (72 MB each, P from the GPU
+    fit itself) are copied to the host and solved with the reference's call, ``scipy.linalg.lstsq`` (gelsd; reached through
+    sparsevfc.py:110,194,250), and with its `gelss` / truncated `eigh` variants for the floor; the fields  V = U C  on every
+    256th cell (U = the GPU's own kernel values of the mode, the U that was fitted) of the GPU's solve of that iteration -
+    and, for the fifth, of its Jacobi path on the same factor for the record - must sit within 1.25 x that floor."""
     import json
 
     import scipy.linalg
@@ -475,171 +475,67 @@ def test_the_deflated_solve_on_the_benchmark_system_against_scipy_lstsq(st, dtyp
     eng = SparseVFCEngine(Xv, Yv, ctrl, beta, dtype=dtype, device="cuda:0")
     eng.init_state(gamma=0.9)
     kw = dict(a=5, lambda_=0.02, minP=1e-5, theta=0.75)
-    for _ in range(4):
-        eng.em_step(**kw)
-    assert eng.rank_deficient and eng.mn_method == "deflated"
-    cap = {}
+    caps = []
     inner = eng._solve_all
 
     def capturing(ls2):
         host = inner(ls2)
-        cap.update(G=eng.G.clone(), R=eng.R[0].clone(), C=eng.C_new[0].clone(), ls2=float(ls2))
+        st_ = eng.solver_stats
+        caps.append(dict(G=eng.G.cpu().numpy(), R=eng.R[0].cpu().numpy(), C=eng.C_new[0].cpu().numpy(), ls2=float(ls2),
+                         path=("deflated" if eng.rank_deficient else "cholesky"),
+                         kept=(st_["rank"][-1] if eng.rank_deficient else M),
+                         frank=((st_.get("factor_rank") or [M])[-1] if eng.rank_deficient else M),
+                         block=((st_.get("block") or [0])[-1] if eng.rank_deficient else 0)))
         return host
 
+    eng.em_step(**kw)                       # iteration 1 (the streamed-oracle fixture c4_step covers it)
     eng._solve_all = capturing
-    eng.em_step(**kw)
-    assert eng.solver_stats["block"][-1] in (128, 256), eng.solver_stats  # the deflated block answered, not the fallback
-    kept, frank = eng.solver_stats["rank"][-1], eng.solver_stats["factor_rank"][-1]
+    for _ in range(4):                      # iterations 2 - 5
+        eng.em_step(**kw)
+    assert eng.rank_deficient and eng.mn_method == "deflated"
+    assert caps[-1]["block"] in (128, 256), eng.solver_stats  # the deflated block answered the fifth, not the fallback
     k = eng.k
-    # the Jacobi path on the same system (fresh workspace, no hint), for the record
-    Cj = torch.empty_like(cap["C"])
+    # the Jacobi path on the fifth system (fresh workspace, no hint), for the record
+    Gd, Rd = torch.from_numpy(caps[-1]["G"]).to(k.device), torch.from_numpy(caps[-1]["R"]).to(k.device)
+    Cj = torch.empty_like(Rd)
     info, einfo = k.zeros(1, dtype=torch.int32), k.zeros(12, dtype=torch.float64)
     k._lr_ws = None
-    k.solve_minnorm_lr(cap["G"], eng.K, cap["ls2"], cap["R"], Cj, info, einfo)
+    k.solve_minnorm_lr(Gd, eng.K, caps[-1]["ls2"], Rd, Cj, info, einfo)
     assert int(info.cpu()[0]) == 0
+    Cjh = Cj.cpu().numpy()
     # U on every 256th cell, generated by the mode's own kernel_value (the U that was fitted)
     rows = torch.arange(0, eng.n_local, 256, device=k.device)
     Us = k.con_k(eng.x4[rows][:, :3].contiguous(), eng.ctrl4[:, :3].contiguous(), eng.beta).to(torch.float64).cpu().numpy()
-    A = (cap["G"] + cap["ls2"] * eng.K).cpu().numpy()
-    R = cap["R"].cpu().numpy()
-    Cg, Cjh = cap["C"].cpu().numpy(), Cj.cpu().numpy()
+    Kh = eng.K.cpu().numpy()
     eng.k.drop_ublk()
-    del eng
+    del eng, Gd, Rd, Cj
     torch.cuda.empty_cache()
-    C_ref = scipy.linalg.lstsq(A, R)[0]                      # the reference's call (gelsd)
-    C_gelss = scipy.linalg.lstsq(A, R, lapack_driver="gelss")[0]
-    C_eigh = _eigh_solver(A, R)
-    Vr = Us @ C_ref
-    vmax = np.abs(Vr).max()
-    dev = lambda C: float(np.abs(Us @ C - Vr).max() / vmax)  # noqa: E731
-    floors = {"gelss": dev(C_gelss), "eigh": dev(C_eigh)}
-    floor = max(floors.values())
-    got, jac = dev(Cg), dev(Cjh)
-    rec = {"case": "c4_solve (8000000 x 3000, system of the 5th EM iteration)", "dtype": dtype, "kept_rank": int(kept),
-           "factor_rank": int(frank), "V_deflated": got, "V_jacobi": jac, "floor": floor, "floors": floors,
-           "ratio_deflated": got / floor, "ratio_jacobi": jac / floor, "cells_compared": int(len(Us))}
-    print(json.dumps(rec))
     os.makedirs(os.path.dirname(HEADLINE_SOLVE_LOG), exist_ok=True)
-    with open(HEADLINE_SOLVE_LOG, "a") as fh:
-        fh.write(json.dumps(rec) + "\n")
-    assert got <= max(F.ALLOW * floor, TOL[dtype]), rec
-
-
-# ------------------------------------------------------------------------------------------- gram_mode = "pivot" (extension)
-# How far the pivot-subset mode (SparseVFCEngine._restrict_to_pivots; NOT the reference's arithmetic, default off) sits
-# from the oracle, per quantity.  It is a different truncation of the same ill-posed M-step, so the field is not held to the
-# 1.25 x-floor rule of the default mode; what the mode IS held to, and what was measured on one MI355X (round 4,
-# tools/pivot_mode_probe.py -> profiles/r04_pivot_subset.md; float64 / float32 mode, switch after 3 iterations):
-#   field on the cells   <= 1.75 x the reference's own floor         (measured 0.91 - 1.55 x)
-#   sigma^2, energy      <= 1.75 x floor or the mode's base tolerance (measured 0.13 - 1.28 x; the subset moves by a control
-#                        point or two with the rounding of the factor rank at the switch, and sigma^2 with it)
-#   P (max |dP|)         <= 1.75 x floor at >= 60 cells per control point (0.65 - 1.46 x); 3.5 x at 10 cells per control
-#                        point (0.5 - 3.05 x; the default mode itself measures 1.68 x there in float32 mode)
-PIVOT_V, PIVOT_P_LARGE, PIVOT_P_SMALL = 1.75, 1.75, 3.5
-
-
-def _pivot_check(tag, dtype, dev, table, allow_p):
-    base = _base_tolerances(dtype)
-    fl = {k: table[k][0 if dtype == "float64" else 1] for k in dev}
-    lim = {k: F.tol(dtype, table, k, base[k]) for k in dev}
-    for q in ("V", "sigma2", "E"):
-        if q in dev:
-            lim[q] = max(PIVOT_V * fl[q], base[q])
-    lim["P"] = max(allow_p * fl["P"], base["P"])
-    print(f"PIVOT {tag} {dtype}: " + "; ".join(
-        f"{k} gpu {dev[k]:.2e} / floor {fl[k]:.2e} (x{dev[k] / max(fl[k], 1e-300):.2f}, limit {lim[k]:.2e})" for k in dev))
-    bad = {k: (dev[k], lim[k]) for k in dev if not dev[k] <= lim[k]}
+    bad = []
+    for it, cp in enumerate(caps, start=2):
+        A = cp["G"] + cp["ls2"] * Kh
+        C_ref = scipy.linalg.lstsq(A, cp["R"])[0]                      # the reference's call (gelsd)
+        C_gelss = scipy.linalg.lstsq(A, cp["R"], lapack_driver="gelss")[0]
+        C_eigh = _eigh_solver(A, cp["R"])
+        Vr = Us @ C_ref
+        vmax = np.abs(Vr).max()
+        dev = lambda C: float(np.abs(Us @ C - Vr).max() / vmax)  # noqa: E731
+        floors = {"gelss": dev(C_gelss), "eigh": dev(C_eigh)}
+        floor = max(floors.values())
+        got = dev(cp["C"])
+        rec = {"case": f"c4_solve (8000000 x 3000, system of EM iteration {it})", "iteration": it, "dtype": dtype,
+               "path": cp["path"], "block": int(cp["block"]), "kept_rank": int(cp["kept"]), "factor_rank": int(cp["frank"]),
+               "V_gpu": got, "floor": floor, "floors": floors, "ratio": got / max(floor, 1e-300),
+               "cells_compared": int(len(Us))}
+        if it == 5:
+            rec["V_jacobi"] = dev(Cjh)
+            rec["ratio_jacobi"] = rec["V_jacobi"] / max(floor, 1e-300)
+        print(json.dumps(rec))
+        with open(HEADLINE_SOLVE_LOG, "a") as fh:
+            fh.write(json.dumps(rec) + "\n")
+        if not got <= max(F.ALLOW * floor, TOL[dtype]):
+            bad.append(rec)
     assert not bad, bad
-
-
-def _fixture_devs(got, ref, stride):
-    return {"V": float(np.abs(got["V"][::stride] - ref["V"]).max() / ref["vmax"]),
-            "sigma2": abs(got["sigma2"] - ref["sigma2"]) / ref["sigma2"],
-            "P": float(np.abs(got["P"][::stride] - ref["P"]).max()),
-            "E": float(np.abs((got["E_traj"] - ref["E_traj"]) / ref["E_traj"]).max())}
-
-
-@pytest.mark.parametrize("dtype", ["float64", "float32"])
-@pytest.mark.parametrize("case", ["c4_200k", "c4_rank", "c3_full", "m3000_20k", "m2000_20k"])
-def test_pivot_mode_against_the_oracle(st, case, dtype):
-    """gram_mode="pivot" against the same committed oracle fixtures as the default mode: the C4 generator at 200 k x 3000
-    (10 iterations), 1 M x 3000 and 2 M x 2000 (5 iterations, streamed oracle), and the two 20 k-cell cases."""
-    from spateo_amd._synthetic import make_config
-
-    if case == "c4_200k":
-        X, V, kw, ref, table = _c4_sample_case()
-        stride, allow = _C4_SAMPLE["stride"], PIVOT_P_LARGE
-    elif case in ("c4_rank", "c3_full"):
-        fx, ref, table = _stream_fixture(case)
-        cfg, n, M = _STREAM_CASES[case]
-        X, V, _ = make_config(cfg, N=n)
-        kw = dict(M=M, lambda_=0.02, lstsq_method="scipy", MaxIter=int(fx["steps"]), ecr=0.0, seed=0)
-        stride, allow = int(fx["stride"]), PIVOT_P_LARGE
-    else:
-        X, V, kw, ref, table = _large_m_case(3000 if case == "m3000_20k" else 2000, 0.02)
-        stride, allow = 1, PIVOT_P_SMALL
-    got = st.SparseVFC(X, V, None, dtype=dtype, device="cuda:0", gram_mode="pivot", **kw)
-    assert got["iteration"] == ref["iteration"]
-    sub = got["ctrl_subset"]
-    M = kw["M"]
-    assert 2 <= len(sub) <= 0.75 * M and np.all(got["C"][np.setdiff1d(np.arange(M), sub)] == 0.0)
-    print(f"PIVOT {case} {dtype}: {len(sub)} of {M} control points carry the field")
-    _pivot_check(case, dtype, _fixture_devs(got, ref, stride), table, allow)
-    # the dict contract: V = con_K(X, X_ctrl) C for the returned full-size coefficients (checked on a sample of the cells)
-    rows = np.arange(0, len(got["V"]), max(1, len(got["V"]) // 2000))
-    Xv = np.asarray(X)[got["valid_ind"]][rows]
-    Vs = st.vector_field_function(Xv, got, dtype=dtype, device="cuda:0")
-    assert np.abs(Vs - got["V"][rows]).max() / np.abs(got["V"]).max() < (1e-9 if dtype == "float64" else 1e-4)
-    del got
-    torch.cuda.empty_cache()
-
-
-def _pivot_two_rank_worker(rank, world, port, out_dir):
-    import sys
-
-    here = os.path.dirname(os.path.abspath(__file__))
-    root = os.path.dirname(here)
-    for p in (root, os.path.join(root, "spateo-release_amd"), here):
-        if p not in sys.path:
-            sys.path.insert(0, p)
-    import torch.distributed as dist
-
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks on cuda:0 (RCCL refuses that; gloo does not)
-    try:
-        import spateo_amd as st
-        from spateo_amd._synthetic import make_config
-
-        X, V, _ = make_config("C3", N=20_000)
-        kw = dict(M=2000, lambda_=0.02, lstsq_method="scipy", MaxIter=10, ecr=0.0, seed=0)
-        got = st.SparseVFC(X, V, None, dtype="float64", device="cuda:0", distributed=True, gather="all",
-                           gram_mode="pivot", **kw)
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), V=got["V"], P=got["P"], C=got["C"], sigma2=got["sigma2"],
-                 E=got["E_traj"], iteration=got["iteration"], subset=got["ctrl_subset"])
-    finally:
-        dist.destroy_process_group()
-
-
-def test_pivot_mode_with_two_ranks_sharing_one_gpu(st, tmp_path):
-    """gram_mode="pivot" with the cells sharded over two processes (real kernels, gloo collectives on device tensors): both
-    ranks read the same pivot order off their bit-identical all-reduced system, rebuild the same restricted model, pass the
-    per-step agreement check and end bit-identical - at the pivot mode's distance from the oracle (20 k x 2000 fixture)."""
-    import socket
-
-    import torch.multiprocessing as mp
-
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    mp.spawn(_pivot_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    for k in ("V", "P", "C", "sigma2", "E", "subset"):
-        np.testing.assert_array_equal(r0[k], r1[k])
-    X, V, kw, ref, table = _large_m_case(2000, 0.02)
-    assert int(r0["iteration"]) == ref["iteration"] and 2 <= len(r0["subset"]) <= 1500
-    got = dict(V=r0["V"], P=r0["P"], sigma2=float(r0["sigma2"]), E_traj=r0["E"])
-    _pivot_check("2 ranks, 20 k x 2000", "float64", _fixture_devs(got, ref, 1), table, PIVOT_P_SMALL)
 
 
 # ------------------------------------------------------------------------------------------- BASELINE config 5 organ

@@ -782,52 +782,6 @@ def test_jacobian_with_det_in_two_dimensions(cpu_kernels):
     np.testing.assert_allclose(det, np.linalg.det(np.moveaxis(J, 2, 0)), rtol=1e-12, atol=1e-15)
 
 
-# ------------------------------------------------------------------------------------------------ gram_mode = "pivot"
-def test_pivot_mode_continues_on_the_selected_control_points(cpu_kernels, monkeypatch):
-    """gram_mode="pivot" (extension, default off): after the first rank-revealing solve the engine works on the r control
-    points the pivoted factorisation selected - M-step matrices r x r, coefficients zero off the subset so that
-    ``V == con_K(X, X_ctrl) @ C`` holds for the returned full-size C, energy continuous across the switch, same dict
-    contract; the default mode is untouched; a factor that keeps more than 75 % of the control points does not switch."""
-    monkeypatch.setattr(vfm.SparseVFCEngine, "minnorm_method", "lowrank")
-    X, V = _data(1500)
-    # a kernel 20 x wider than the bandwidth rule's makes 120 control points numerically rank deficient at this small size
-    beta = 0.05 * vfm.sparsevfc_preprocess(X, V, M=120, seed=0)[5]
-    kw = dict(M=120, lambda_=0.02, lstsq_method="scipy", MaxIter=8, ecr=0.0, seed=0, beta=beta)
-    full = st.SparseVFC(X, V, X[:40], **kw)
-    piv = st.SparseVFC(X, V, X[:40], gram_mode="pivot", **kw)
-    assert "ctrl_subset" not in full and "ctrl_subset" in piv
-    sub = piv["ctrl_subset"]
-    assert 2 <= len(sub) <= 0.75 * 120 and len(set(sub.tolist())) == len(sub)
-    off = np.setdiff1d(np.arange(120), sub)
-    assert piv["C"].shape == (120, 3) and np.all(piv["C"][off] == 0.0) and np.abs(piv["C"][sub]).max() > 0
-    np.testing.assert_array_equal(piv["X_ctrl"], full["X_ctrl"])
-    Xv = X[piv["valid_ind"]]
-    U = svo.con_K(Xv, piv["X_ctrl"], piv["beta"])
-    np.testing.assert_allclose(U @ piv["C"], piv["V"], rtol=0, atol=1e-9 * np.abs(piv["V"]).max())
-    np.testing.assert_allclose(svo.con_K(X[:40], piv["X_ctrl"], piv["beta"]) @ piv["C"], piv["grid_V"], rtol=0,
-                               atol=1e-9 * np.abs(piv["V"]).max())
-    # the restricted model is another truncation of the same ill-posed system: the same field to the noise level of this
-    # deliberately extreme toy (12 cells per control point, 20 x the rule's kernel width; parity at the sizes the mode is
-    # meant for is measured on the GPU, tests/test_gpu_scale.py)
-    assert _rel(piv["V"], full["V"]) < 3e-2 and abs(piv["sigma2"] / full["sigma2"] - 1) < 3e-2
-    assert piv["iteration"] == full["iteration"] == 7
-    assert np.all(np.isfinite(piv["E_traj"])) and np.abs(piv["E_traj"] / full["E_traj"] - 1).max() < 3e-2
-    # "pivot:K" switches after K rank-revealing iterations, "pivot:K+" keeps restricting while the restricted factor still
-    # sheds >= 6 % of its control points: nested subsets, composed into indices of the full control-point set
-    nest = st.SparseVFC(X, V, X[:40], gram_mode="pivot:1+", **kw)
-    ns = nest["ctrl_subset"]
-    assert len(set(ns.tolist())) == len(ns) and ns.max() < 120 and len(ns) <= len(sub) + 30
-    assert np.all(nest["C"][np.setdiff1d(np.arange(120), ns)] == 0.0)
-    np.testing.assert_allclose(svo.con_K(Xv, nest["X_ctrl"], nest["beta"]) @ nest["C"], nest["V"], rtol=0,
-                               atol=1e-9 * np.abs(nest["V"]).max())
-    assert _rel(nest["V"], full["V"]) < 3e-2
-    # well-regularised system (the factor keeps every control point): no switch
-    reg = st.SparseVFC(X, V, None, gram_mode="pivot", **dict(kw, lambda_=3.0, M=40, beta=None))
-    assert "ctrl_subset" not in reg
-    with pytest.raises(ValueError, match="gram_mode"):
-        st.SparseVFC(X, V, None, gram_mode="nonsense", **kw)
-
-
 def test_deflated_route_to_the_truncated_solve_restated_in_numpy():
     """mvf_solve_minnorm_lrd's algorithm as NumPy (`_cpu_kernels.deflated_minnorm`): on a rank-deficient
     kernel system the invariant subspace below the eps * lambda_max cut-off, found by block inverse iteration on the r x r matrix
@@ -868,56 +822,6 @@ def test_deflated_route_to_the_truncated_solve_restated_in_numpy():
     assert np.abs(U @ C_defl - F).max() / sc < 4e-2      # and with it inside the reference's floor on this system
     np.testing.assert_array_equal(solve(128, True)[1], C_defl)   # the twin's deflate=True IS this route ...
     np.testing.assert_array_equal(solve(32, True)[1], C_svd)     # ... and falls back when the block cannot hold the subspace
-
-
-def test_pivot_mode_fit_ending_on_the_switching_iteration_keeps_its_coefficients(cpu_kernels, monkeypatch):
-    """the restriction to the pivot subset used to happen at the END of the switching iteration and
-    zeroed C; a fit that ended right there (MaxIter, tecr <= ecr, sigma^2 floor) returned C = 0 with a non-zero V.  The
-    switch is now taken at the start of the NEXT iteration, if there is one."""
-    monkeypatch.setattr(vfm.SparseVFCEngine, "minnorm_method", "lowrank")
-    X, V = _data(1500)
-    beta = 0.05 * vfm.sparsevfc_preprocess(X, V, M=120, seed=0)[5]
-    kw = dict(M=120, lambda_=0.02, lstsq_method="scipy", ecr=0.0, seed=0, beta=beta)
-    Xv = X
-    for max_iter in (2, 3, 4, 5):
-        piv = st.SparseVFC(X, V, X[:40], gram_mode="pivot", MaxIter=max_iter, **kw)
-        assert np.abs(piv["C"]).max() > 0 and np.abs(piv["V"]).max() > 0
-        U = svo.con_K(Xv, piv["X_ctrl"], piv["beta"])
-        np.testing.assert_allclose(U @ piv["C"], piv["V"], rtol=0, atol=1e-9 * np.abs(piv["V"]).max())
-        np.testing.assert_allclose(svo.con_K(X[:40], piv["X_ctrl"], piv["beta"]) @ piv["C"], piv["grid_V"], rtol=0,
-                                   atol=1e-9 * np.abs(piv["V"]).max())
-    # a fit that ends on the switching iteration has not switched (it equals the full-mode fit up to that point) ...
-    full = st.SparseVFC(X, V, X[:40], MaxIter=4, **kw)
-    runs = {mi: st.SparseVFC(X, V, X[:40], gram_mode="pivot", MaxIter=mi, **kw) for mi in (2, 3, 4, 5, 6)}
-    first_switched = min(mi for mi, r in runs.items() if "ctrl_subset" in r)
-    last_unswitched = first_switched - 1
-    assert last_unswitched in runs and "ctrl_subset" not in runs[last_unswitched]
-    if last_unswitched == 4:
-        np.testing.assert_array_equal(runs[4]["V"], full["V"])
-    # ... and the next one has
-    assert np.all(runs[first_switched]["C"][np.setdiff1d(np.arange(120), runs[first_switched]["ctrl_subset"])] == 0.0)
-
-
-def test_engine_refit_after_pivot_mode_starts_from_the_full_control_point_set(cpu_kernels, monkeypatch):
-    """init_state() undoes the pivot-mode restriction, so a second fit() on the same engine (bench warm-up /
-    timed steps) is the same computation as the first."""
-    monkeypatch.setattr(vfm.SparseVFCEngine, "minnorm_method", "lowrank")
-    X, V = _data(1500)
-    _, Xv, Yv, _, ctrl, beta = vfm.sparsevfc_preprocess(X, V, M=120, seed=0)
-    eng = vfm.SparseVFCEngine(Xv, Yv, ctrl, 0.05 * beta, gram_mode="pivot")
-    kw = dict(lambda_=0.02, MaxIter=8, ecr=0.0, lstsq_method="scipy")
-    eng.fit(**kw)
-    assert eng.subset is not None and eng.M < 120
-    V1, P1, C1 = eng.results()
-    sub1 = eng.subset.copy()
-    eng.fit(**kw)
-    assert eng.M < 120
-    V2, P2, C2 = eng.results()
-    np.testing.assert_array_equal(sub1, eng.subset)
-    np.testing.assert_array_equal(V1, V2)
-    np.testing.assert_array_equal(C1, C2)
-    eng.init_state()
-    assert eng.subset is None and eng.M == 120 and eng.G.shape == (120, 120)
 
 
 def test_restart_loop_refits_per_seed_unless_the_memo_is_opted_into(cpu_kernels, monkeypatch):

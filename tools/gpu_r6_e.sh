@@ -17,7 +17,7 @@ for k,v in d.items():
 PY
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d "$R/gpurun_out/r6${T}_prof" -o p -- python "$R/tools/small_m_trace.py" deflated > "$R/gpurun_out/r6${T}_trace.log" 2>&1); echo "trace rc=$?"
 DB=$(find gpurun_out/r6${T}_prof -name "*.db" | head -1)
-python tools/rocpd_timeline.py "$DB" assemble_kernel 400 > gpurun_out/r6${T}_small_m_timeline.md
+python tools/rocpd_timeline.py "$DB" assemble_kernel 400 > gpurun_out/r6${T}_small_m_timeline.md; python tools/rocpd_timeline.py "$DB" estep_min_kernel 120 > gpurun_out/r6${T}_small_m_step_timeline.md
 tail -3 gpurun_out/r6${T}_small_m_timeline.md
 tail -2 gpurun_out/r6${T}_trace.log
 rm -rf gpurun_out/r6${T}_prof
