@@ -94,13 +94,13 @@ __global__ __launch_bounds__(256) void apply_kernel(const T* __restrict__ x4, in
 
 // out[k] += sum over b (in order) of partials[b * stride + k]   (one workgroup, K <= 8 columns; fixed summation order)
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partials, int64_t nb, int stride,
-                                                           int K, double* __restrict__ out) {
+                                                           int K, double* __restrict__ out, int overwrite = 0) {
     __shared__ double red[4];
     for (int k = 0; k < K; ++k) {
         double s = 0.0;
         for (int64_t b = threadIdx.x; b < nb; b += 256) s += partials[b * stride + k];
         const double t = block_sum<256>(s, red);
-        if (threadIdx.x == 0) out[k] += t;
+        if (threadIdx.x == 0) out[k] = overwrite ? t : out[k] + t;  // (overwrite: saves the caller a memset launch)
         __syncthreads();
     }
 }
@@ -335,11 +335,13 @@ extern "C" int mvf_quadform(const double* K, const double* C, int64_t m, int nrh
     MVF_REQUIRE(m >= 0 && nrhs >= 1, "mvf_quadform: bad shape");
     MVF_REQUIRE(out && (m == 0 || scratch), "mvf_quadform: null out / scratch");
     hipStream_t st = (hipStream_t)stream;
-    MVF_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(double), st));
-    if (m == 0) return 0;
+    if (m == 0) {
+        MVF_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(double), st));
+        return 0;
+    }
     MVF_REQUIRE(K && C, "mvf_quadform: null pointer");
     hipLaunchKernelGGL(quadform_kernel, dim3((unsigned)m), dim3(256), 0, st, K, C, m, nrhs, scratch);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, scratch, m, 1, 1, out);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, scratch, m, 1, 1, out, 1);
     MVF_LAUNCH_CHECK();
     return 0;
 }

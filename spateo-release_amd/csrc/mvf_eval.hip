@@ -271,16 +271,29 @@ extern "C" int mvf_eval_affine(const void* x4, int64_t n, const void* ctrl4, int
     const double s = std::sqrt(beta * LOG2E);
     // (x - c) = (scaled difference) / s, with s as the kernel rounds it
     const double jscale = -2.0 * beta / ((dtype == MVF_F32) ? (double)(float)s : s);
-    constexpr int CPT = 2;
-    dim3 grid((unsigned)cdiv(n, 256 * CPT));
-    if (dtype == MVF_F32)
-        hipLaunchKernelGGL((eval_kernel<float, CPT>), grid, dim3(256), 0, st, (const float*)x4, n, (const float*)ctrl4,
-                           m, (float)s, jscale, af, C, flags, v, jac, div, curl, acc, curv, tors, jdet);
-    else if (dtype == MVF_F64)
-        hipLaunchKernelGGL((eval_kernel<double, CPT>), grid, dim3(256), 0, st, (const double*)x4, n,
-                           (const double*)ctrl4, m, s, jscale, af, C, flags, v, jac, div, curl, acc, curv, tors, jdet);
-    else
+    // Two query points per lane amortise the LDS broadcast of a control point; a grid-sized launch (64^3 = 262 144 queries:
+    // 512 workgroups = 2 per CU, 2 waves per SIMD) then leaves the float64 pipe short of independent work between its
+    // dependent chains (0.30 of the float64 VALU peak) - below one million queries one point per lane
+    // and twice the workgroups.
+    const bool one = n < (int64_t)(1 << 20);
+    dim3 grid((unsigned)cdiv(n, 256 * (one ? 1 : 2)));
+    if (dtype == MVF_F32) {
+        if (one)
+            hipLaunchKernelGGL((eval_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x4, n, (const float*)ctrl4,
+                               m, (float)s, jscale, af, C, flags, v, jac, div, curl, acc, curv, tors, jdet);
+        else
+            hipLaunchKernelGGL((eval_kernel<float, 2>), grid, dim3(256), 0, st, (const float*)x4, n, (const float*)ctrl4,
+                               m, (float)s, jscale, af, C, flags, v, jac, div, curl, acc, curv, tors, jdet);
+    } else if (dtype == MVF_F64) {
+        if (one)
+            hipLaunchKernelGGL((eval_kernel<double, 1>), grid, dim3(256), 0, st, (const double*)x4, n,
+                               (const double*)ctrl4, m, s, jscale, af, C, flags, v, jac, div, curl, acc, curv, tors, jdet);
+        else
+            hipLaunchKernelGGL((eval_kernel<double, 2>), grid, dim3(256), 0, st, (const double*)x4, n,
+                               (const double*)ctrl4, m, s, jscale, af, C, flags, v, jac, div, curl, acc, curv, tors, jdet);
+    } else {
         return set_error("mvf_eval: bad dtype %d", (int)dtype);
+    }
     MVF_LAUNCH_CHECK();
     return 0;
 }

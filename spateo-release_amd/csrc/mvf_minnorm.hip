@@ -1518,6 +1518,39 @@ __global__ __launch_bounds__(256) void defl_sub_kernel(const double* __restrict_
     T[e] -= s;
 }
 
+// T (n x 8) -= Wsel^T (Wsel T) for a 64-row Wsel in ONE single-workgroup launch (the three-launch form - rowstat, back,
+// sub - costs 14 us of launch floor per projection at n = 512; a 64 x 512 Wsel is 256 KB, one compute unit's worth)
+__global__ __launch_bounds__(1024) void defl_project64_kernel(const double* __restrict__ Wsel, int64_t n, double* __restrict__ T) {
+    __shared__ double cb[64][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // 16 waves
+    for (int i = wave; i < 64; i += 16) {  // cb[i][:] = Wsel[i][:] . T
+        const double* w = Wsel + (int64_t)i * n;
+        double t[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) t[d] = 0.0;
+        for (int64_t k = lane; k < n; k += 64) {
+            const double v = w[k];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) t[d] = fma(v, T[k * 8 + d], t[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) t[d] = wave_sum(t[d]);
+        if (lane == 0) {
+#pragma unroll
+            for (int d = 0; d < 8; ++d) cb[i][d] = t[d];
+        }
+    }
+    __syncthreads();
+    for (int64_t e = tid; e < n * 8; e += 1024) {  // T[k][d] -= sum_i Wsel[i][k] cb[i][d]  (i ascending: fixed order)
+        const int64_t k = e >> 3;
+        const int d = (int)(e & 7);
+        double s = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) s = fma(Wsel[(int64_t)i * n + k], cb[i][d], s);
+        T[e] -= s;
+    }
+}
+
 // ---- the direct form of the small deflated solve (round 5) ---------------------------------------------------------------
 // When the previous call on the workspace factored ALL m columns (factor rank r = m: what M <= 640 control points give, BASELINE
 // configs 2 and 5) the pivoted Cholesky of the next, nearby matrix is, in that pivot order, an ordinary Cholesky of the permuted
@@ -2071,6 +2104,10 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         double *dummy = (double*)(dw + d.dummy), *dpart = (double*)(dw + d.part), *Wsel = (double*)(dw + d.wsel);
         const double* Minv = S;
         auto project = [&](double* T) {  // T -= Wsel^T (Wsel T)
+            if (b == DEFL_TINY) {
+                hipLaunchKernelGGL(defl_project64_kernel, dim3(1), dim3(1024), 0, st, (const double*)Wsel, rp, T);
+                return;
+            }
             hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, Wsel, (int64_t)b, rp, rp, T, 8,
                                dummy, cb);
             hipLaunchKernelGGL(jac_back_kernel, dim3((unsigned)(rp / 64), 4u), dim3(256), 0, st, Wsel, (int64_t)b, rp, rp, cb,
@@ -2105,6 +2142,10 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         double *Ta = (double*)(dw + d.ta), *Tb = (double*)(dw + d.tb), *cb = (double*)(dw + d.cb);
         double *dummy = (double*)(dw + d.dummy), *dpart = (double*)(dw + d.part), *Wsel = (double*)(dw + d.wsel);
         auto project = [&](double* T) {  // T -= Wsel^T (Wsel T)
+            if (b == DEFL_TINY) {
+                hipLaunchKernelGGL(defl_project64_kernel, dim3(1), dim3(1024), 0, st, (const double*)Wsel, rp, T);
+                return;
+            }
             hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, Wsel, (int64_t)b, rp, rp, T, 8,
                                dummy, cb);
             hipLaunchKernelGGL(jac_back_kernel, dim3((unsigned)(rp / 64), 4u), dim3(256), 0, st, Wsel, (int64_t)b, rp, rp, cb,
@@ -2491,14 +2532,14 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             MVF_CHECK_HIP(hipMemsetAsync(mod, 0, (size_t)(hnb + (size_t)hnb * hnb) * sizeof(int), st));
             hsweeps = 0;
             hrot2 = 1;
-            // Sweeps are enqueued in batches - eight, then two at a time - with one rotation counter per sweep and ONE status
+            // Sweeps are enqueued in batches - ten, then two at a time - with one rotation counter per sweep and ONE status
             // read per batch (round 5 read the counter after every sweep: nine or ten host round trips of ~40 us in a
             // 128-vector Rayleigh-Ritz).  Behind the sweep that converges every pair is clean, so the rest of its batch
             // returns at once (pair_is_clean) and changes nothing: the result and the reported sweep count are those of
             // the one-by-one loop.
             while (hsweeps < max_sweeps && hrot2 != 0) {
-                const int batch = hnb == 2 ? 1 : std::min(max_sweeps - hsweeps, hsweeps == 0 ? 8 : 2);
-                MVF_CHECK_HIP(hipMemsetAsync(rot, 0, 8 * sizeof(unsigned int), st));
+                const int batch = hnb == 2 ? 1 : std::min(max_sweeps - hsweeps, hsweeps == 0 ? 10 : 2);  // (9 - 10 at b = 128)
+                MVF_CHECK_HIP(hipMemsetAsync(rot, 0, 16 * sizeof(unsigned int), st));
                 for (int sb = 0; sb < batch; ++sb)
                     for (int rd = 0; rd < hnb - 1; ++rd) {
                         const int stamp = 1 + (hsweeps + sb) * (hnb - 1) + rd;
@@ -2514,7 +2555,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
                                            (int64_t)b, hnb, rd, Jbuf, flags);
                     }
                 MVF_LAUNCH_CHECK();
-                unsigned int hb[8];
+                unsigned int hb[16];
                 MVF_CHECK_HIP(hipMemcpyAsync(hb, rot, sizeof(hb), hipMemcpyDeviceToHost, st));
                 MVF_CHECK_HIP(hipStreamSynchronize(st));
                 int done_at = -1;

@@ -67,27 +67,34 @@ class HipKernels:
         a = np.asarray(arr, dtype=np.float64)
         if a.ndim != 2 or not (1 <= a.shape[1] <= 3):
             raise ValueError(f"expected an (n, d) array with d <= 3, got shape {a.shape}")
-        if center is not None:
-            a = a - np.asarray(center, dtype=np.float64)[None, : a.shape[1]]
-        return self.h2d_padded(a, 4, self.tdtype)
+        c = None if center is None else np.asarray(center, dtype=np.float64)[None, : a.shape[1]]
+        return self.h2d_padded(a, 4, self.tdtype, minus=c)
 
     # pinned staging: host arrays up to this size travel through page-locked tensors of torch's caching host allocator
     # (one DMA, no driver-side bounce copies); larger ones keep the pageable path so that a fit of 8 M cells does not
     # leave hundreds of MB of the host page-locked for the life of the process
     PINNED_MAX_BYTES = 128 << 20
 
-    def h2d_padded(self, a, width, tdtype):
-        """Host (n, d <= width) float64 array -> device (n, width) tensor of `tdtype`, zero padded."""
+    def h2d_padded(self, a, width, tdtype, minus=None):
+        """Host (n, d <= width) float64 array -> device (n, width) tensor of `tdtype`, zero padded.  minus (1 x d float64, may
+        be None): subtracted in float64 on the way - the difference is rounded to `tdtype` as it is written into the staging
+        buffer, ONE pass over the data (the evaluator API used to make a centred float64 temporary first)."""
         n, d = a.shape
         nbytes = n * width * (4 if tdtype == torch.float32 else 8)
+
+        def fill(hv):
+            if minus is None:
+                hv[:, :d] = a
+            else:
+                np.subtract(a, minus, out=hv[:, :d], casting="same_kind")
+            hv[:, d:] = 0
+
         if 0 < nbytes <= self.PINNED_MAX_BYTES:
             host = torch.empty((n, width), dtype=tdtype, pin_memory=True)
-            hv = host.numpy()
-            hv[:, :d] = a
-            hv[:, d:] = 0
+            fill(host.numpy())
             return host.to(self.device, non_blocking=True)
-        buf = np.zeros((n, width), dtype=np.float32 if tdtype == torch.float32 else np.float64)
-        buf[:, :d] = a
+        buf = np.empty((n, width), dtype=np.float32 if tdtype == torch.float32 else np.float64)
+        fill(buf)
         return torch.from_numpy(buf).to(self.device)
 
     @_on_device

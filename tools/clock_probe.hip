@@ -43,6 +43,31 @@ __global__ void chain_kernel(double* out, unsigned long long* t, int n, int mode
             y3 = fma(y3, a, b);
         }
         x = y0 + y1 + y2 + y3;
+    } else if (mode == 9) {
+        double y[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) y[q] = x + q;
+#pragma unroll 4
+        for (int i = 0; i < n; ++i) {                                      // 16 independent f64 FMA chains: issue rate
+#pragma unroll
+            for (int q = 0; q < 16; ++q) y[q] = fma(y[q], a, b);
+        }
+        x = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x += y[q];
+    } else if (mode == 10) {
+        float y[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) y[q] = (float)x + q;
+#pragma unroll 4
+        for (int i = 0; i < n; ++i) {                                      // 16 independent f32 FMA chains: issue rate
+#pragma unroll
+            for (int q = 0; q < 16; ++q) y[q] = fmaf(y[q], 1.0000001f, 1e-9f);
+        }
+        float z = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) z += y[q];
+        x = z;
     } else {
         for (int i = 0; i < n; ++i) {                                      // f64 -> f32 -> f64 conversion round trip
             float f = (float)x;
@@ -75,10 +100,10 @@ int main() {
     hipStream_t s1, s2;
     hipStreamCreate(&s1);
     hipStreamCreate(&s2);
-    const char* names[9] = {"f64 fma chain", "v_rcp_f64 + add chain", "LDS round trip + 2 barriers", "IEEE sqrt chain", "f32 fma chain", "v_rsq_f32 + add chain", "f64 fma chain unrolled", "4 independent f64 fma chains", "cvt f64->f32->f64 + add"};
+    const char* names[11] = {"f64 fma chain", "v_rcp_f64 + add chain", "LDS round trip + 2 barriers", "IEEE sqrt chain", "f32 fma chain", "v_rsq_f32 + add chain", "f64 fma chain unrolled", "4 independent f64 fma chains", "cvt f64->f32->f64 + add", "16 independent f64 fma (per step = 16 FMAs)", "16 independent f32 fma (per step = 16 FMAs)"};
     const int n = 20000;
     for (int loaded = 0; loaded < 2; ++loaded)
-        for (int mode = 0; mode < 9; ++mode) {
+        for (int mode = 0; mode < 11; ++mode) {
             for (int rep = 0; rep < 3; ++rep) {
                 if (loaded) hipLaunchKernelGGL(busy_kernel, dim3(1020), dim3(256), 0, s2, busy, 4000000);
                 hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(256), 0, s1, out, t, n, mode);
