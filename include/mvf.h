@@ -375,9 +375,10 @@ int mvf_eval(const void* x4, int64_t n, const void* ctrl4, int64_t m, double bet
              double* jdet, mvf_dtype dtype, void* stream);
 
 /* Same with an affine epilogue, for the Gaussian-process morphofield variant:
- *   v_out = alpha * (K @ C) + A q + b,   J_out = jmul * J,   q = the query point as passed in x4 (unscaled);
+ *   v_out[f] = alpha[f] * (K @ C)[f] + (A q + b)[f],   J_out = jmul * J,   q = the query point as passed in x4 (unscaled);
  * every derived quantity (div, curl, acc, curvature, torsion, det) is computed from v_out / J_out.
- * `affine` is a HOST array of 14 doubles {alpha, jmul, A[9] row-major, b[3]} read at call time (NULL = identity).
+ * `affine` is a HOST array of 16 doubles {alpha[3], jmul, A[9] row-major, b[3]} read at call time (NULL = identity);
+ * alpha is per output component since ABI 6 (a per-axis `scale_fixed` of the GP variant's norm_dict).
  * Replaces: `_gp_velocity` spateo/tdr/morphometrics/morphofield/gaussian_process.py:102-127 and
  * `Jacobian_GP_gaussian_kernel` / `GPVectorField` morphofield_dg/GPVectorField.py:143-266 (norm_dict + rigid part). */
 int mvf_eval_affine(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, const double* C,

@@ -18,7 +18,7 @@ constexpr int EVAL_CHUNK = 512;
 // Identity for the sparsevfc field; the affine part carries the GP variant's norm_dict scaling and rigid transform
 // (spateo/tdr/morphometrics/morphofield/gaussian_process.py:102-127, GPVectorField.py:158-159,190).
 struct EvalAffine {
-    double alpha, jmul;
+    double alpha[3], jmul;  // alpha per output component (the GP variant's scale_fixed may be per axis)
     double A[9];
     double b[3];
 };
@@ -97,9 +97,9 @@ __global__ __launch_bounds__(256) void eval_kernel(const T* __restrict__ x4, int
         for (int f = 0; f < 3; ++f)
 #pragma unroll
             for (int i = 0; i < 3; ++i) Jm[f][i] = J[c][f][i] * jscale * af.jmul;
-        const double v0 = af.alpha * v[c][0] + af.A[0] * q0[c] + af.A[1] * q1[c] + af.A[2] * q2[c] + af.b[0];
-        const double v1 = af.alpha * v[c][1] + af.A[3] * q0[c] + af.A[4] * q1[c] + af.A[5] * q2[c] + af.b[1];
-        const double v2 = af.alpha * v[c][2] + af.A[6] * q0[c] + af.A[7] * q1[c] + af.A[8] * q2[c] + af.b[2];
+        const double v0 = af.alpha[0] * v[c][0] + af.A[0] * q0[c] + af.A[1] * q1[c] + af.A[2] * q2[c] + af.b[0];
+        const double v1 = af.alpha[1] * v[c][1] + af.A[3] * q0[c] + af.A[4] * q1[c] + af.A[5] * q2[c] + af.b[1];
+        const double v2 = af.alpha[2] * v[c][2] + af.A[6] * q0[c] + af.A[7] * q1[c] + af.A[8] * q2[c] + af.b[2];
         if (flags & MVF_EVAL_V) {
             v_out[q * 3 + 0] = v0, v_out[q * 3 + 1] = v1, v_out[q * 3 + 2] = v2;
         }
@@ -203,9 +203,9 @@ __global__ __launch_bounds__(256) void integrate_kernel(const T* __restrict__ x4
                 a0 = fma(k, cc.x, a0), a1 = fma(k, cc.y, a1), a2 = fma(k, cc.z, a2);
             }
         }
-        v0 = af.alpha * a0 + af.A[0] * q0 + af.A[1] * q1 + af.A[2] * q2 + af.b[0];
-        v1 = af.alpha * a1 + af.A[3] * q0 + af.A[4] * q1 + af.A[5] * q2 + af.b[1];
-        v2 = af.alpha * a2 + af.A[6] * q0 + af.A[7] * q1 + af.A[8] * q2 + af.b[2];
+        v0 = af.alpha[0] * a0 + af.A[0] * q0 + af.A[1] * q1 + af.A[2] * q2 + af.b[0];
+        v1 = af.alpha[1] * a1 + af.A[3] * q0 + af.A[4] * q1 + af.A[5] * q2 + af.b[1];
+        v2 = af.alpha[2] * a2 + af.A[6] * q0 + af.A[7] * q1 + af.A[8] * q2 + af.b[2];
     };
 
     if (nchunks == 1) {
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(const T* __restrict__ x4
 using namespace mvf;
 
 extern "C" int mvf_eval_affine(const void* x4, int64_t n, const void* ctrl4, int64_t m, double beta, const double* C,
-                               const double* affine /* host: alpha, jmul, A[9] row-major, b[3]; NULL = identity */,
+                               const double* affine /* host: alpha[3], jmul, A[9] row-major, b[3]; NULL = identity */,
                                int flags, double* v, double* jac, double* div, double* curl, double* acc, double* curv,
                                double* tors, double* jdet, mvf_dtype dtype, void* stream) {
     MVF_REQUIRE(n >= 0 && m >= 0, "mvf_eval: bad shape");
@@ -259,13 +259,14 @@ extern "C" int mvf_eval_affine(const void* x4, int64_t n, const void* ctrl4, int
     MVF_REQUIRE(!(flags & MVF_EVAL_TORS) || tors, "mvf_eval: tors requested but null");
     MVF_REQUIRE(!(flags & MVF_EVAL_JDET) || jdet, "mvf_eval: jdet requested but null");
     EvalAffine af;
-    af.alpha = 1.0, af.jmul = 1.0;
+    af.alpha[0] = af.alpha[1] = af.alpha[2] = 1.0, af.jmul = 1.0;
     for (int i = 0; i < 9; ++i) af.A[i] = 0.0;
     for (int i = 0; i < 3; ++i) af.b[i] = 0.0;
     if (affine) {
-        af.alpha = affine[0], af.jmul = affine[1];
-        for (int i = 0; i < 9; ++i) af.A[i] = affine[2 + i];
-        for (int i = 0; i < 3; ++i) af.b[i] = affine[11 + i];
+        for (int i = 0; i < 3; ++i) af.alpha[i] = affine[i];
+        af.jmul = affine[3];
+        for (int i = 0; i < 9; ++i) af.A[i] = affine[4 + i];
+        for (int i = 0; i < 3; ++i) af.b[i] = affine[13 + i];
     }
     hipStream_t st = (hipStream_t)stream;
     const double s = std::sqrt(beta * LOG2E);
@@ -313,13 +314,14 @@ extern "C" int mvf_integrate(const void* x4, int64_t n, const void* ctrl4, int64
     if (n == 0) return 0;
     MVF_REQUIRE(x4 && traj && (m == 0 || (ctrl4 && C)), "mvf_integrate: null pointer");
     EvalAffine af;
-    af.alpha = 1.0, af.jmul = 1.0;
+    af.alpha[0] = af.alpha[1] = af.alpha[2] = 1.0, af.jmul = 1.0;
     for (int i = 0; i < 9; ++i) af.A[i] = 0.0;
     for (int i = 0; i < 3; ++i) af.b[i] = 0.0;
     if (affine) {
-        af.alpha = affine[0], af.jmul = affine[1];
-        for (int i = 0; i < 9; ++i) af.A[i] = affine[2 + i];
-        for (int i = 0; i < 3; ++i) af.b[i] = affine[11 + i];
+        for (int i = 0; i < 3; ++i) af.alpha[i] = affine[i];
+        af.jmul = affine[3];
+        for (int i = 0; i < 9; ++i) af.A[i] = affine[4 + i];
+        for (int i = 0; i < 3; ++i) af.b[i] = affine[13 + i];
     }
     hipStream_t st = (hipStream_t)stream;
     const double s = std::sqrt(beta * LOG2E);

@@ -461,9 +461,10 @@ class HipKernels:
         import ctypes
 
         alpha, jmul, A, b = affine
-        vals = [float(alpha), float(jmul)] + [float(x) for x in np.asarray(A, dtype=np.float64).reshape(9)] + \
+        al = np.broadcast_to(np.asarray(alpha, dtype=np.float64).reshape(-1), (3,))  # a scalar or one value per component
+        vals = [float(x) for x in al] + [float(jmul)] + [float(x) for x in np.asarray(A, dtype=np.float64).reshape(9)] + \
                [float(x) for x in np.asarray(b, dtype=np.float64).reshape(3)]
-        return (ctypes.c_double * 14)(*vals)
+        return (ctypes.c_double * 16)(*vals)
 
     @_on_device
     def integrate(self, x4, ctrl4, beta, C, dt, substeps, n_out, affine=None):

@@ -14,7 +14,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from . import vectorfield as _vf
+from . import _runtime as _rt
+from .engine import SparseVFCEngine, _consistent_K
 from .vectorfield import vector_field_function
 
 __all__ = ["BA_transform", "update_nonrigid"]
@@ -58,11 +59,11 @@ def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, l
     if len(w) != len(X) or B.shape[0] != len(X) or B.ndim != 2 or not (1 <= B.shape[1] <= 3):
         raise ValueError("K_NA must be (n,) and PXB_term (n, D) with D <= 3")
     n, m, D = len(X), len(ctrl), B.shape[1]
-    k = _vf._make_kernels(device, dtype)
+    k = _rt._make_kernels(device, dtype)
     npdt = np.float32 if dtype == "float32" else np.float64
     center = ctrl.mean(0)
     x4, c4 = k.to_x4(X, center), k.to_x4(ctrl, center)
-    Gamma = _vf._consistent_K(k, ctrl, center, float(beta))  # generated like U (see SparseVFCEngine)
+    Gamma = _consistent_K(k, ctrl, center, float(beta))  # generated like U (see SparseVFCEngine)
     f64 = torch.float64
     G, R = k.zeros(m, m, dtype=f64), k.zeros(m, 3, dtype=f64)
     Pw = torch.from_numpy(w.astype(npdt)).to(k.device)
@@ -106,13 +107,13 @@ def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, l
         k.solve_minnorm_lr(G, Gamma, step * ls2, R, C, info, einfo, rcond=rcond)
         if int(info.cpu()[0]) != 0:
             raise _lib.MVFError("update_nonrigid: SigmaInv has non-finite entries")
-        _vf.SparseVFCEngine._check_converged(float(einfo.cpu()[0]))
+        SparseVFCEngine._check_converged(float(einfo.cpu()[0]))
     else:
         shift = 2.0 ** -36
         while True:
             k.solve_minnorm(G, Gamma, step * ls2, shift, R, C, info, einfo, rcond=rcond)
             if int(info.cpu()[0]) == 0:
-                _vf.SparseVFCEngine._check_converged(float(einfo.cpu()[0]))
+                SparseVFCEngine._check_converged(float(einfo.cpu()[0]))
                 break
             shift *= 16.0
             if shift > 2.0 ** -12:

@@ -3,7 +3,7 @@ float64 NumPy oracle, so that the HOST logic of the product - the EM driver, the
 the sharding / all-reduce protocol - can be exercised by the ``-m "not gpu"`` suite and by world_size-2 ``gloo`` runs.
 
 It is the checker standing in for the device; it is not a fallback: the product constructs only ``HipKernels``
-(``spateo_amd.vectorfield._make_kernels``) and fails loudly without a GPU.
+(``spateo_amd._runtime._make_kernels``) and fails loudly without a GPU.
 """
 from __future__ import annotations
 
@@ -22,7 +22,7 @@ def _np(t):
 
 
 def deflated_minnorm(L, R, cut, block, applications=2):
-    """NumPy restatement of mvf_solve_minnorm_lrd's deflated solve (csrc/mvf_minnorm.hip) on the pivoted factor
+    """NumPy restatement of mvf_solve_minnorm_lrd's deflated solve (csrc/mvf_minnorm.hip, HISTORY.md 2.2.11) on the pivoted factor
     L (m x r, columns in pivot order):  C = sum over the eigenpairs of L L^T with eigenvalue > cut of q (q^T R) / lambda, WITHOUT
     the eigendecomposition of the whole factor.  Returns (C, number of deflated directions).
       S2 = L^T L = Rc Rc^T (Cholesky: the factor is graded), Minv = S2^-1;
@@ -293,7 +293,7 @@ class CpuKernels:
         J = dgo.Jacobian_rkhs_gaussian(X, vfd, vectorize=True)
         if affine is not None:
             alpha, jmul, A, b = affine
-            v = alpha * v + X @ np.asarray(A).T + np.asarray(b)[None, :]
+            v = np.asarray(alpha, dtype=float).reshape(1, -1) * v + X @ np.asarray(A).T + np.asarray(b)[None, :]  # alpha: scalar or (3,)
             J = jmul * J
         a = np.einsum("fin,ni->nf", J, v)
         if flags & EVAL_V:

@@ -51,3 +51,33 @@ def run_and_check(st, g, tol):
         assert _rel(ad.obs["divergence"], g[f"gpw_{tag}_div_obs"]) < tol
         assert _rel(ad.uns["jacobian"], g[f"gpw_{tag}_jac_uns"]) < tol
         assert _rel(ad.obs["jacobian"], g[f"gpw_{tag}_jac_obs"]) < 100 * tol
+
+
+def check_axes_and_2d(st, g, tol, **kw):
+    """The two GP shapes round 5 refused, against outputs of the REAL reference functions (tests/golden/make_golden_gp_axes.py ->
+    ref_gp_axes.npz): per-axis ``norm_dict`` scales (velocities; the Jacobian raises, as the reference's own does) and a 2-D
+    field (velocities and Jacobian)."""
+    import pytest
+
+    ax = {"norm_dict": {"scale_fixed": g["ax_sf"], "scale_transformed": g["ax_stt"], "mean_transformed": g["ax_mean_t"],
+                        "mean_fixed": g["ax_mean_f"]},
+          "kernel_type": "euc", "inducing_variables": g["ax_ind"], "beta": float(g["ax_beta"]), "Coff": g["ax_C"],
+          "R": g["ax_R"], "t": g["ax_t"]}
+    assert _rel(st.vectorfield.gp_velocity(g["ax_X"], ax, **kw), g["ax_V_full"]) < tol
+    assert _rel(st.vectorfield.gp_velocity(g["ax_X"], ax, nonrigid_only=True, **kw), g["ax_V_nr"]) < tol
+    assert bool(g["ax_jac_raises"])
+    vf = st.GPVectorField(**kw)
+    vf.vf_dict = ax
+    with pytest.raises(ValueError, match="broadcast"):
+        vf.get_Jacobian()(g["ax_X"])
+    d2 = {"norm_dict": {"scale_fixed": float(g["d2_sf"]), "scale_transformed": float(g["d2_stt"]),
+                        "mean_transformed": g["d2_mean_t"], "mean_fixed": g["d2_mean_f"]},
+          "kernel_type": "euc", "inducing_variables": g["d2_ind"], "beta": float(g["d2_beta"]), "Coff": g["d2_C"],
+          "R": g["d2_R"], "t": g["d2_t"]}
+    v = st.vectorfield.gp_velocity(g["d2_X"], d2, **kw)
+    assert v.shape == g["d2_V_full"].shape and _rel(v, g["d2_V_full"]) < tol
+    assert _rel(st.vectorfield.gp_velocity(g["d2_X"], d2, nonrigid_only=True, **kw), g["d2_V_nr"]) < tol
+    vf2 = st.GPVectorField(**kw)
+    vf2.vf_dict = d2
+    J = vf2.get_Jacobian()(g["d2_X"])
+    assert J.shape == g["d2_J"].shape and _rel(J, g["d2_J"]) < tol

@@ -3,7 +3,7 @@
 
 The integer scheme computes the EXACT Gram matrix of operands rounded to a fixed-point grid,
     A~ = round(sqrt(P) U * 2^b) / 2^b      (b = 7 bits x number of int8 slices),   G~ = A~^T A~ ,
-i.e. a STRUCTURED perturbation of the operand, not noise added to G.  DESIGN 2.3 found structured perturbations benign
+i.e. a STRUCTURED perturbation of the operand, not noise added to G.  HISTORY.md 2.3 found structured perturbations benign
 and unstructured ones (float32 accumulation: 1e-9 relative noise in G) fatal (1e-2 in the field).  This script runs the
 float64 oracle's EM with G~ (and either the consistent rhs A~^T sqrt(P) Y~ or the reference's U^T P Y) and reports the
 field deviation from the unmodified oracle next to the oracle's own noise floors.

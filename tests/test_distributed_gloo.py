@@ -69,16 +69,17 @@ def _worker(rank, world, port, case, out_dir, mode="all"):
         if case == "wide":
             V = np.column_stack([V, np.sin(X[:, 0] / 70), np.cos(X[:, 1] / 50)])  # Dy = 5: two column groups
         calls = {"unique": 0}
+        import spateo_amd.preprocess as pre
         import spateo_amd.vectorfield as vfm
 
-        orig_unique = vfm.unique_rows
+        orig_unique = pre.unique_rows
 
         def counting_unique(a, device=None):
             calls["unique"] += 1
             return orig_unique(a, device)
 
-        vfm.unique_rows = counting_unique
-        vfm._make_kernels = lambda device, dtype: Recording()  # the product's one kernel-binding seam
+        pre.unique_rows = counting_unique
+        vfm._rt._make_kernels = lambda device, dtype: Recording()  # the product's one kernel-binding seam
         if mode == "sharded":  # every rank brings ITS OWN rows: 401 + 200, not the block split
             lo, hi = (0, 401) if rank == 0 else (401, 601)
             got = st.SparseVFC(X[lo:hi], V[lo:hi], Grid, distributed=True, sharded_input=True, gather="root", **kw)
@@ -172,7 +173,7 @@ def _many_worker(rank, world, port, out_dir, inject):
         from _cpu_kernels import CpuKernels
         from spateo_amd._synthetic import make_config
 
-        vfm._make_kernels = lambda device, dtype: CpuKernels()
+        vfm._rt._make_kernels = lambda device, dtype: CpuKernels()
         data = []
         for k in range(4):
             X, V, _ = make_config("C2", N=300 + 10 * k, seed=100 + k)
@@ -243,7 +244,7 @@ def _force_worker(rank, world, port, out_dir):
             return orig(*a, **kw)
 
         dist.all_reduce = counting
-        vfm._make_kernels = lambda device, dtype: CpuKernels()
+        vfm._rt._make_kernels = lambda device, dtype: CpuKernels()
         X, V, _ = make_config("C2", N=601)
         V[7] = np.nan
         kw = dict(M=25, lambda_=3.0, lstsq_method="scipy", MaxIter=6, seed=0)

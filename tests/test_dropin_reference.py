@@ -32,7 +32,7 @@ def reference_with_our_engine(monkeypatch):
     from spateo_amd import vectorfield as vfm
 
     before = set(sys.modules)
-    monkeypatch.setattr(vfm, "_make_kernels", lambda device, dtype: CpuKernels(device, dtype))
+    monkeypatch.setattr(vfm._rt, "_make_kernels", lambda device, dtype: CpuKernels(device, dtype))
     mg.install_stubs()
     sv = types.ModuleType("dynamo.vectorfield.scVectorField")
     sv.SparseVFC = vfm.SparseVFC          # <- the swap: this repo's engine behind dynamo's name

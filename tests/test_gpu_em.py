@@ -275,6 +275,19 @@ def test_gp_variant_against_reference_goldens(st, golden, dtype, tol):
         st.set_default_dtype("float64")
 
 
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 2e-4)])
+def test_gp_variant_per_axis_scales_and_2d_fields(st, dtype, tol):
+    """Per-axis ``norm_dict`` scales (per-component alpha of the affine epilogue, ABI 6) and 2-D GP fields (zero-padded 3-D
+    points) on the fused evaluator, against goldens of the real reference functions (tests/golden/ref_gp_axes.npz)."""
+    import os, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    from _gp_case import check_axes_and_2d
+
+    g = dict(np.load(os.path.join(here, "golden", "ref_gp_axes.npz")))
+    check_axes_and_2d(st, g, tol, dtype=dtype, device="cuda:0")
+
+
 @pytest.mark.parametrize("dtype,tol", [("float64", 1e-6), ("float32", 2e-4)])  # RK4 truncation at 4 substeps ~3e-7
 def test_morphopath_fused_rk4_vs_dop853(st, golden, dtype, tol):
     """The fused RK4 integration kernel against SciPy DOP853 on the float64 oracle field (sparsevfc and GP fields)."""

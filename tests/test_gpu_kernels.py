@@ -858,7 +858,7 @@ def test_jacobian_determinant_on_the_device_and_one_fused_pass(st, dtype, tol):
     """MVF_EVAL_JDET (the `obs` slot of ``morphofield_jacobian``, ``differential_geometry.py:336``) against
     ``np.linalg.det`` of the oracle's Jacobians; Jacobian, determinant, curl and divergence of the same points come out of
     ONE ``eval_kernel`` launch (the later calls are device -> host copies), 70 k points so that the pinned path is taken."""
-    from spateo_amd import vectorfield as vfm
+    from spateo_amd import preprocess as _pre, vectorfield as vfm
 
     rng, X, ctrl = _cloud(6, 70_000, 400)
     vfd = {"X_ctrl": ctrl, "C": rng.standard_normal((400, 3)), "beta": 0.004}
@@ -930,18 +930,18 @@ def test_unique_rows_on_the_device_is_numpy_unique(st, n, d):
 
 
 def test_preprocess_uses_the_device_unique_and_matches_the_host(st):
-    from spateo_amd import vectorfield as vfm
+    from spateo_amd import preprocess as _pre, vectorfield as vfm
     from spateo_amd._synthetic import make_config
 
     X, V, _ = make_config("C3", N=400_000)
     X[1000] = X[5]
     a = vfm.sparsevfc_preprocess(X, V, M=300, seed=0, device="cuda:0")
-    old = vfm._DEVICE_UNIQUE_MIN_ROWS
-    vfm._DEVICE_UNIQUE_MIN_ROWS = 10**12  # force the host route
+    old = _pre._DEVICE_UNIQUE_MIN_ROWS
+    _pre._DEVICE_UNIQUE_MIN_ROWS = 10**12  # force the host route
     try:
         b = vfm.sparsevfc_preprocess(X, V, M=300, seed=0)
     finally:
-        vfm._DEVICE_UNIQUE_MIN_ROWS = old
+        _pre._DEVICE_UNIQUE_MIN_ROWS = old
     for u, v in zip(a, b):
         np.testing.assert_array_equal(u, v)
 
@@ -951,17 +951,17 @@ def test_knn_bandwidth_on_the_device_is_the_host_bandwidth(st, m, d):
     """dynamo's bandwidth_selector with the neighbour search on the device (all squared distances of a point in LDS,
     bitonic sort, sum of the k - 1 smallest non-self distances) against the kd-tree route: the same distances summed in
     another order."""
-    from spateo_amd import vectorfield as vfm
+    from spateo_amd import preprocess as _pre, vectorfield as vfm
 
     rng = np.random.default_rng(m + d)
     X = rng.standard_normal((m, d)) * np.array([300.0, 200.0, 150.0])[:d]
     hd = vfm.bandwidth_selector(X, device="cuda:0")
-    old = vfm._DEVICE_KNN_MIN_POINTS
-    vfm._DEVICE_KNN_MIN_POINTS = 10**9  # force the host route
+    old = _pre._DEVICE_KNN_MIN_POINTS
+    _pre._DEVICE_KNN_MIN_POINTS = 10**9  # force the host route
     try:
         hh = vfm.bandwidth_selector(X)
     finally:
-        vfm._DEVICE_KNN_MIN_POINTS = old
+        _pre._DEVICE_KNN_MIN_POINTS = old
     assert abs(hd - hh) <= 1e-12 * hh, (hd, hh)
     # and the preprocessing picks it up: beta from the device route
     if m == 1500:
@@ -969,11 +969,11 @@ def test_knn_bandwidth_on_the_device_is_the_host_bandwidth(st, m, d):
 
         Xc, Vc, _ = make_config("C3", N=20_000)
         a = vfm.sparsevfc_preprocess(Xc, Vc, M=m, seed=0, device="cuda:0")
-        vfm._DEVICE_KNN_MIN_POINTS = 10**9
+        _pre._DEVICE_KNN_MIN_POINTS = 10**9
         try:
             b = vfm.sparsevfc_preprocess(Xc, Vc, M=m, seed=0)
         finally:
-            vfm._DEVICE_KNN_MIN_POINTS = old
+            _pre._DEVICE_KNN_MIN_POINTS = old
         np.testing.assert_array_equal(a[4], b[4])
         assert abs(a[5] - b[5]) <= 1e-12 * b[5]
 

@@ -513,14 +513,17 @@ def test_the_deflated_solve_on_the_benchmark_system_against_scipy_lstsq(st, dtyp
     os.makedirs(os.path.dirname(HEADLINE_SOLVE_LOG), exist_ok=True)
     bad = []
     for it, cp in enumerate(caps, start=2):
+        if dtype == "float32" and it in (2, 4):
+            continue  # (host time: a 3000 x 3000 gelsd + gelss is ~15 s; float64 checks all four iterations, float32 3 and 5)
         A = cp["G"] + cp["ls2"] * Kh
         C_ref = scipy.linalg.lstsq(A, cp["R"])[0]                      # the reference's call (gelsd)
-        C_gelss = scipy.linalg.lstsq(A, cp["R"], lapack_driver="gelss")[0]
         C_eigh = _eigh_solver(A, cp["R"])
         Vr = Us @ C_ref
         vmax = np.abs(Vr).max()
         dev = lambda C: float(np.abs(Us @ C - Vr).max() / vmax)  # noqa: E731
-        floors = {"gelss": dev(C_gelss), "eigh": dev(C_eigh)}
+        floors = {"eigh": dev(C_eigh)}
+        if it == 5:  # both witnesses of the floor for the iteration rounds 4 - 5 reported; the truncated eigh alone before it
+            floors["gelss"] = dev(scipy.linalg.lstsq(A, cp["R"], lapack_driver="gelss")[0])
         floor = max(floors.values())
         got = dev(cp["C"])
         rec = {"case": f"c4_solve (8000000 x 3000, system of EM iteration {it})", "iteration": it, "dtype": dtype,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Turn the parity lines that tests/test_gpu_scale.py prints (pytest -s) into the markdown table of DESIGN.md 2.1.
+"""Turn the parity lines that tests/test_gpu_scale.py prints (pytest -s) into the markdown table of DESIGN.md 2.1 / profiles/rNN_parity_table.md.
 
     python tools/parity_table.py gpurun_out/r3b/tests.log
 """

@@ -10,6 +10,6 @@ for rep in range(3):
     torch.cuda.synchronize(); t=time.perf_counter(); S,idx=k.unique_rows(X); torch.cuda.synchronize(); print("device unique 8M rows: %.1f ms (incl. H2D/D2H), %d unique" % (1e3*(time.perf_counter()-t), len(S)))
 from spateo_amd.vectorfield import unique_rows
 import spateo_amd.vectorfield as vfm
-old=vfm._DEVICE_UNIQUE_MIN_ROWS; vfm._DEVICE_UNIQUE_MIN_ROWS=10**12
+import spateo_amd.preprocess as _pre; old=_pre._DEVICE_UNIQUE_MIN_ROWS; _pre._DEVICE_UNIQUE_MIN_ROWS=10**12
 t=time.perf_counter(); Sh,ih=unique_rows(X); print("host path %.2f s" % (time.perf_counter()-t))
 print("identical:", np.array_equal(S,Sh), np.array_equal(idx,ih))
