@@ -4,6 +4,26 @@
 #include "../spateo-release_amd/csrc/mvf_gram.hip"
 #include <vector>
 #include <random>
+#include <cstring>
+#include <cmath>
+namespace mvf {
+#include "gram_pc_kernel.h"
+// the tile stage of mvf_gram_cached with the producer / consumer kernel (same plan, same partial-tile buffer, same reduction)
+static int gram_pc_tiles(const float* ublk, const float* P, int64_t n, int64_t m, double* G, void* workspace) {
+    const GramPlan p = make_plan(n, m, MVF_F32);
+    if (hipFuncSetAttribute((const void*)gram_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS_BYTES) != hipSuccess) return 1;
+    for (int64_t ph = 0; ph < p.nphases; ++ph) {
+        const int64_t s0 = ph * p.phase_slices, ns = std::min(p.phase_slices, p.nslices - s0);
+        const unsigned njobs = (unsigned)(ns * p.npairs);
+        hipLaunchKernelGGL(gram_pc_kernel, dim3(njobs), dim3(512), PC_LDS_BYTES, 0, ublk, P, n, ublk_npad(n), m, p.nt, p.npairs,
+                           p.slice_len, s0, (double*)workspace);
+        if (ph + 1 < p.nphases)
+            hipLaunchKernelGGL(gram_reduce_kernel, dim3(GT * GT / 256, (unsigned)p.npairs), dim3(256), 0, 0,
+                               (const double*)workspace, ns, p.nt, p.npairs, m, G, ph > 0 ? 1 : 0);
+    }
+    return hipGetLastError() != hipSuccess;
+}
+}  // namespace mvf
 
 int main(int argc, char** argv) {
     const int64_t n = argc > 1 ? atoll(argv[1]) : 1000000, m = argc > 2 ? atoll(argv[2]) : 3000;
@@ -33,5 +53,20 @@ int main(int argc, char** argv) {
     timeit("recompute f64acc<float>", [&] { mvf_gram_stages(1, x, p, y, n, c, m, beta, G, R, ws, wsb, MVF_F32, nullptr); });
     timeit("cached-U", [&] { mvf_gram_cached(1, ub, x, p, y, n, c, m, beta, G, R, ws, wsb, MVF_F32, nullptr); });
     timeit("ublk_build", [&] { mvf_ublk_build(x, n, c, m, beta, ub, ubb, MVF_F32, nullptr); });
+    // A/B: producer / consumer-wave kernel (developer option gram_pc) against the shipped one, G compared bit for bit
+    std::vector<double> g0((size_t)m * m), g1((size_t)m * m);
+    mvf_gram_cached(1 | 4, ub, x, p, y, n, c, m, beta, G, R, ws, wsb, MVF_F32, nullptr);
+    hipMemcpy(g0.data(), G, (size_t)m * m * 8, hipMemcpyDeviceToHost);
+    hipMemset(G, 0, (size_t)m * m * 8);
+    int rc = mvf::gram_pc_tiles(ub, p, n, m, G, ws);
+    if (!rc) rc = mvf_gram_cached(4, ub, x, p, y, n, c, m, beta, G, R, ws, wsb, MVF_F32, nullptr);
+    hipError_t he = hipDeviceSynchronize();
+    if (rc || he != hipSuccess) { printf("gram_pc failed: rc=%d %s / %s\n", rc, mvf_last_error(), hipGetErrorString(he)); return 1; }
+    hipMemcpy(g1.data(), G, (size_t)m * m * 8, hipMemcpyDeviceToHost);
+    size_t ndiff = 0; double maxd = 0;
+    for (size_t i = 0; i < g0.size(); ++i) if (memcmp(&g0[i], &g1[i], 8)) { ++ndiff; maxd = std::max(maxd, std::fabs(g0[i] - g1[i])); }
+    printf("gram_pc vs shipped: %zu of %zu entries differ (max |d| %.3e)\n", ndiff, g0.size(), maxd);
+    timeit("cached-U gram_pc", [&] { mvf::gram_pc_tiles(ub, p, n, m, G, ws); });
+    timeit("cached-U shipped (again)", [&] { mvf_gram_cached(1, ub, x, p, y, n, c, m, beta, G, R, ws, wsb, MVF_F32, nullptr); });
     return 0;
 }
