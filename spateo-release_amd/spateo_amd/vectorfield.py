@@ -325,14 +325,18 @@ def SparseVFC(
                           group=group, n_total=N, shard_sizes=shard_sizes, gram_mode=gram_mode,
                           force_collectives=force_collectives, collective=collective)
     ph.mark("upload_and_u_cache_s")
-    tecr_vec, E_vec = eng.fit(a=a, gamma=gamma, lambda_=lambda_, minP=minP, MaxIter=MaxIter, theta=theta, ecr=ecr,
-                              lstsq_method=lstsq_method)
-    ph.mark("em_s")
-    V, P, C = eng.results(gather=gather)
-    grid_V = eng.predict(Grid) if Grid is not None else None
-    i = eng.iteration
-    if eng.comm is not None:
-        eng.comm.close()
+    try:
+        tecr_vec, E_vec = eng.fit(a=a, gamma=gamma, lambda_=lambda_, minP=minP, MaxIter=MaxIter, theta=theta, ecr=ecr,
+                                  lstsq_method=lstsq_method)
+        ph.mark("em_s")
+        V, P, C = eng.results(gather=gather)
+        grid_V = eng.predict(Grid) if Grid is not None else None
+        i = eng.iteration
+    finally:
+        # the RCCL communicator is destroyed here on EVERY path (a failure raises on all ranks in the same EM step, so they
+        # all arrive here together) - not at garbage collection with the ranks out of step
+        if eng.comm is not None:
+            eng.comm.close()
     extra = {}
     if multi:
         # which rows of the finite-row sequence (positions in `valid_ind`) the per-cell outputs V / P / VFCIndex of THIS
