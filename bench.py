@@ -803,7 +803,7 @@ def main():
             kms = e0.elapsed_time(e1) / 20
             tf_ = len(grid) * me * EVAL_F64_FLOP_PER_PAIR / (kms * 1e-3) / 1e12
             out["eval"][dt] = {"kernel_ms_all_quantities": kms, "Gpairs_per_s": len(grid) * me / kms / 1e6,
-                               "kernel": f"eval_kernel<{'float' if dt == 'float32' else 'double'}, *> (all quantities, one launch)",
+                               "kernel": f"eval_mfma_kernel<{'float' if dt == 'float32' else 'double'}> (all quantities, one launch)",
                                "f64_flop_per_pair": EVAL_F64_FLOP_PER_PAIR, "TFLOPs": tf_,
                                "frac_of_f64_valu_peak": tf_ / PEAK_F64_VALU_TFLOPS,
                                "jacobian_plus_curl_api_wall_ms": float(np.median(walls[1:])),

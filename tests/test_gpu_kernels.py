@@ -857,7 +857,7 @@ def test_evaluators_large_vs_oracle(st):
 def test_jacobian_determinant_on_the_device_and_one_fused_pass(st, dtype, tol):
     """MVF_EVAL_JDET (the `obs` slot of ``morphofield_jacobian``, ``differential_geometry.py:336``) against
     ``np.linalg.det`` of the oracle's Jacobians; Jacobian, determinant, curl and divergence of the same points come out of
-    ONE ``eval_kernel`` launch (the later calls are device -> host copies), 70 k points so that the pinned path is taken."""
+    ONE ``eval_mfma_kernel`` launch (the later calls are device -> host copies), 70 k points so that the pinned path is taken."""
     from spateo_amd import preprocess as _pre, vectorfield as vfm
 
     rng, X, ctrl = _cloud(6, 70_000, 400)
