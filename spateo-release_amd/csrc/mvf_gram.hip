@@ -29,6 +29,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 struct GramPlan {
     int nt = 0, npairs = 0;
+    int njobs = 0, edge2 = 0;              // cached kernel: jobs per slice (edge2: narrow last-column tiles run two per job)
     int64_t slice_len = 0, nslices = 0;    // Gram jobs
     int64_t phase_slices = 0, nphases = 1; // slices per launch; the partial-tile buffer holds one phase
     int64_t rslice_len = 0, rslices = 0;   // rhs jobs
@@ -46,6 +47,10 @@ static GramPlan make_plan(int64_t n, int64_t m, mvf_dtype dtype) {
     GramPlan p;
     p.nt = (int)cdiv(m, GT);
     p.npairs = p.nt * (p.nt + 1) / 2;
+    // float64 cached kernel: when the last tile column has <= 64 live control points (m = 3000: 56) its nt tiles run TWO per
+    // job (4 row blocks x 4 column blocks per wave = the 16 MFMAs per k-step of every other job), see gram_cached_kernel
+    p.edge2 = (dtype == MVF_F64 && p.nt >= 2 && m - (int64_t)(p.nt - 1) * GT <= GT / 2) ? 1 : 0;
+    p.njobs = p.edge2 ? p.npairs - p.nt + (p.nt + 1) / 2 : p.npairs;
     // Jobs = tile pairs x cell slices.  All jobs cost the same, so the launch runs in ceil(jobs / slots) rounds of
     // (slice_len + OVERHEAD) cell-times, OVERHEAD = the 128 KB partial tile a job writes and the reduce kernel reads
     // back, expressed in cells of MFMA work (measured ~150: at 50 k cells x 500 control points 1024-cell slices beat
@@ -317,12 +322,16 @@ template <> struct CachedPipe<double> { static constexpr int UGT = MVF_DBL_UG, N
 // DW >= 0 (diagonal tile, balanced): NA = 2, NB = 8; this wave takes row blocks DW and 7 - DW of the tile and, of each, only
 // the blocks on or above the diagonal (8 - DW and DW + 1 of them: 9 for every wave - the four waves of a diagonal tile finish
 // together and execute 36 of the 64 blocks; same registers as the full 2 x 8 shape, of which it is a sub-shape).
-template <typename T, int NA, int NB, bool TRI, int DW = -1>
+// PAIR2 (NA = 4, NB = 4): the row blocks a = 0, 1 belong to one tile (rb0, out) and a = 2, 3 to ANOTHER tile of the same tile
+// column (rb1, out1) - two narrow last-column tiles in one job of full length.
+template <typename T, int NA, int NB, bool TRI, int DW = -1, bool PAIR2 = false>
 __device__ __forceinline__ void cached_block(const T* __restrict__ ublk, const T* __restrict__ P, int64_t n,
                                              int64_t n_pad, int64_t n0, int64_t n1, int64_t rb0, int64_t cb0,
-                                             double* __restrict__ out, int orow0, int ocol0) {
+                                             double* __restrict__ out, int orow0, int ocol0, int64_t rb1 = 0,
+                                             double* __restrict__ out1 = nullptr) {
     constexpr int UGT = CachedPipe<T>::UGT, NBUF = CachedPipe<T>::NBUF;
     static_assert(DW < 0 || (NA == 2 && NB == 8 && !TRI && DW < 4), "balanced diagonal shape is a sub-shape of 2 x 8");
+    static_assert(!PAIR2 || (NA == 4 && NB == 4 && !TRI && DW < 0), "paired edge shape: 2 + 2 row blocks x 4 column blocks");
     const int lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
     // block (a, b) is computed iff ...
@@ -336,7 +345,8 @@ __device__ __forceinline__ void cached_block(const T* __restrict__ ublk, const T
     const T* pa[NA];
     const T* pb[NB];
 #pragma unroll
-    for (int a = 0; a < NA; ++a) pa[a] = ublk + ((rb0 + rblk(a)) * n_pad + n0 + lk) * UB + li;
+    for (int a = 0; a < NA; ++a)
+        pa[a] = ublk + ((PAIR2 ? (a < 2 ? rb0 + a : rb1 + (a - 2)) : rb0 + rblk(a)) * n_pad + n0 + lk) * UB + li;
 #pragma unroll
     for (int b = 0; b < NB; ++b) pb[b] = ublk + ((cb0 + b) * n_pad + n0 + lk) * UB + li;
 
@@ -448,9 +458,10 @@ __device__ __forceinline__ void cached_block(const T* __restrict__ ublk, const T
             if (blk_live(a, b)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = orow0 + rblk(a) * 16 + lk + 4 * r;
+                    const int row = orow0 + (PAIR2 ? (a & 1) : rblk(a)) * 16 + lk + 4 * r;
                     const int col = ocol0 + b * 16 + li;
-                    __builtin_nontemporal_store(acc[a][b][r], &out[row * GT + col]);  // read once, by the reduction
+                    double* o = (PAIR2 && a >= 2) ? out1 : out;
+                    __builtin_nontemporal_store(acc[a][b][r], &o[row * GT + col]);  // read once, by the reduction
                 }
             }
 }
@@ -459,7 +470,7 @@ template <typename T>
 __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const T* __restrict__ ublk, const T* __restrict__ P,
                                                              int64_t n, int64_t n_pad, int64_t m, int nt, int npairs,
                                                              int64_t slice_len, int64_t slice0,
-                                                             double* __restrict__ partial) {
+                                                             double* __restrict__ partial, int njobs, int edge2) {
     // Off-diagonal tile: wave tile 32 x 128 (2 row blocks x 8 column blocks of 16) - the four waves stack in the row
     // direction and all read the same 8 column panels (L1 hits); per k-step a lane does 10 loads and only TWO
     // v_mul_f64 (P K, kept exact) for 16 MFMAs - the f64 VALU work is what steals MFMA time on gfx950.
@@ -467,15 +478,46 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
     //  * last tile column with <= 64 live control points (m = 3000: 56 of 128): 2 x 4 blocks per wave;
     //  * diagonal tile: only blocks on or above the diagonal - waves 0, 1 take the upper-right 64 x 64 quadrant
     //    (2 x 4 blocks each), waves 2, 3 the upper triangles of the two diagonal quadrants (10 of 16 blocks each).
-    const int pair = blockIdx.x % npairs;
-    const int64_t slice = blockIdx.x / npairs;
-    int ti, tj;
-    decode_pair(pair, nt, ti, tj);
+    constexpr int TB = GT / UB;  // 8 blocks per tile side
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int ti, tj, pair;
+    int64_t slice;
+    if constexpr (sizeof(T) == 4) {
+        // (the float32 instantiation keeps its job decode to the letter: its hot loop's register allocation moves with it)
+        pair = blockIdx.x % npairs;
+        slice = blockIdx.x / npairs;
+        decode_pair(pair, nt, ti, tj);
+    } else {
+        // edge2 (float64, last tile column with <= 64 live control points): the jobs of a slice are the tile pairs of the
+        // leading (nt - 1) x (nt - 1) triangle, then the nt tiles of the last column TWO per job - rows 2e and 2e + 1, 2 + 2 row
+        // blocks x 4 column blocks per wave: the same 16 MFMAs per k-step as every other job, so the jobs of a slice still run
+        // in step (the half-length edge jobs of the float32 instantiation cost the float64 one 4 %: it lives on that
+        // lock-step), and the dead half of those tiles is not computed (12 of 300 jobs at m = 3000).
+        const int job = blockIdx.x % njobs;
+        slice = blockIdx.x / njobs;
+        if (edge2 && job >= npairs - nt) {
+            const int e = job - (npairs - nt);
+            ti = 2 * e, tj = nt - 1;
+            if (ti + 1 < nt) {
+                const int64_t n0p = (slice0 + slice) * slice_len;
+                const int64_t n1p = min(n_pad, n0p + slice_len);
+                auto slot = [&](int t) { return t * nt - t * (t - 1) / 2 + (tj - t); };
+                double* oa = partial + ((size_t)slice * npairs + slot(ti)) * (size_t)(GT * GT);
+                double* ob = partial + ((size_t)slice * npairs + slot(ti + 1)) * (size_t)(GT * GT);
+                cached_block<T, 4, 4, false, -1, true>(ublk, P, n, n_pad, n0p, n1p, (int64_t)ti * TB + 2 * wave,
+                                                       (int64_t)tj * TB, oa, 32 * wave, 0, (int64_t)(ti + 1) * TB + 2 * wave, ob);
+                return;
+            }
+        } else if (edge2) {
+            decode_pair(job, nt - 1, ti, tj);
+        } else {
+            decode_pair(job, nt, ti, tj);
+        }
+        pair = ti * nt - ti * (ti - 1) / 2 + (tj - ti);
+    }
     const int64_t n0 = (slice0 + slice) * slice_len;  // `slice` indexes the partial tile inside this launch's phase
     const int64_t n1 = min(n_pad, n0 + slice_len);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* out = partial + ((size_t)slice * npairs + pair) * (size_t)(GT * GT);
-    constexpr int TB = GT / UB;  // 8 blocks per tile side
     const int64_t rb = (int64_t)ti * TB, cb = (int64_t)tj * TB;
     // float32: work the reduction never reads is not computed - the edge shape (2 x 4: last tile column with <= 64 live
     // control points) and the balanced diagonal shape (every wave 9 of the 36 blocks on or above the diagonal; rounds
@@ -893,15 +935,15 @@ extern "C" int mvf_gram_cached(int stages, const void* ublk, const void* x4, con
             if (dtype == MVF_F32)
                 hipLaunchKernelGGL(gram_cached_kernel<float>, dim3(njobs), dim3(256), 0, st, (const float*)ublk,
                                    (const float*)P, n, ublk_npad(n), m, p.nt, p.npairs, p.slice_len, s0,
-                                   (double*)workspace);
+                                   (double*)workspace, p.npairs, 0);
             else if (debug_opt(DBG_GRAM_F64_LDS) != 0)  // developer option: column panels shared through LDS (A/B, round 5)
                 hipLaunchKernelGGL(gram_cached_lds_kernel, dim3(njobs), dim3(256), 0, st, (const double*)ublk,
                                    (const double*)P, n, ublk_npad(n), m, p.nt, p.npairs, p.slice_len, s0,
                                    (double*)workspace);
             else
-                hipLaunchKernelGGL(gram_cached_kernel<double>, dim3(njobs), dim3(256), 0, st, (const double*)ublk,
-                                   (const double*)P, n, ublk_npad(n), m, p.nt, p.npairs, p.slice_len, s0,
-                                   (double*)workspace);
+                hipLaunchKernelGGL(gram_cached_kernel<double>, dim3((unsigned)(ns * p.njobs)), dim3(256), 0, st,
+                                   (const double*)ublk, (const double*)P, n, ublk_npad(n), m, p.nt, p.npairs, p.slice_len, s0,
+                                   (double*)workspace, p.njobs, p.edge2);
             if (ph + 1 < p.nphases)
                 hipLaunchKernelGGL(gram_reduce_kernel, dim3(GT * GT / 256, (unsigned)p.npairs), dim3(256), 0, st,
                                    (const double*)workspace, ns, p.nt, p.npairs, m, G, ph > 0 ? 1 : 0);

@@ -175,10 +175,12 @@ def test_gram_vs_oracle(st, dtype, tol, n, m):
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("n,m", [(3000, 300), (700, 130), (5000, 40), (256, 128)])
+@pytest.mark.parametrize("n,m", [(3000, 300), (700, 130), (5000, 40), (256, 128), (2000, 700), (1500, 1080)])
 def test_gram_cached_u_is_bit_identical_to_recompute(st, n, m, dtype):
     """The cached-U Gram kernel streams materialised float32 kernel values; they are the same kernel_value() bits the
-    recompute kernel generates, accumulated in the same order -> identical G and R."""
+    recompute kernel generates, accumulated in the same order -> identical G and R.  (m = 300, 130, 700, 1080: the last tile
+    column has <= 64 live control points - the float64 kernel runs its tiles two per job, with an odd tile left over at
+    m = 300 and 1080.)"""
     rng, X, ctrl = _cloud(n + m, n, m)
     beta = 0.003
     Y = rng.standard_normal((n, 3))
@@ -851,6 +853,32 @@ def test_evaluators_large_vs_oracle(st):
     assert _relmax(J, Jr) < 1e-10
     div = vf.compute_divergence(X)
     assert _relmax(div, np.trace(Jr)) < 1e-10
+
+
+def test_evaluators_matrix_form_far_from_the_centroid_with_cancelling_coefficients(st):
+    """``eval_mfma_kernel`` forms ``sum_m K_m C_mf (p - c_m)_i`` as ``p_i v_f - W_fi`` from ONE matrix product
+    ``[v | W] = K [C | C (x) c]``.  Stress of that difference: queries up to ~40 kernel widths from the control points'
+    centroid and coefficients that cancel to 1e-6 of their size (what a fitted C looks like at lambda_ = 0.02) - the Jacobian,
+    divergence and acceleration still agree with the float64 oracle's pair-by-pair sums to 1e-9 of their own scale."""
+    rng = np.random.default_rng(17)
+    m, n = 600, 5000
+    ctrl = rng.uniform(-1, 1, (m, 3)) * np.array([500.0, 300.0, 200.0]) + np.array([4000.0, -2500.0, 900.0])
+    X = rng.uniform(-1, 1, (n, 3)) * np.array([520.0, 310.0, 210.0]) + np.array([4000.0, -2500.0, 900.0])
+    big = 1e6 * rng.standard_normal((m // 2, 3))
+    C = np.concatenate([big, -big + rng.standard_normal((m // 2, 3))])      # neighbours in the list, not in space
+    near = np.argsort(np.linalg.norm(ctrl[:, None] - ctrl[None], axis=2) + 1e9 * np.eye(m), axis=1)[:, 0]
+    C[near[: m // 2]] = -C[: m // 2] + rng.standard_normal((m // 2, 3))   # and spatial neighbours that nearly cancel
+    vfd = {"X_ctrl": ctrl, "C": C, "beta": 0.004}
+    vf = st.SvcVectorField(dtype="float64", device="cuda:0")
+    vf.vf_dict = vfd
+    J = vf.get_Jacobian()(X)
+    Jr = dgo.Jacobian_rkhs_gaussian(X, vfd, vectorize=True)
+    assert _relmax(J, Jr) < 1e-9
+    assert _relmax(vf.compute_divergence(X), np.trace(Jr)) < 1e-9
+    vf.func = lambda x: st.vector_field_function(x, vfd, dtype="float64")
+    v = svo.con_K(X, ctrl, 0.004) @ C
+    acc, _ = vf.compute_acceleration(X)
+    assert _relmax(acc, np.einsum("fin,ni->nf", Jr, v)) < 1e-9
 
 
 @pytest.mark.parametrize("dtype,tol", [("float64", 1e-10), ("float32", 2e-4)])
