@@ -56,11 +56,13 @@ const char* mvf_last_error(void);
 int mvf_version(void);                 /* ABI version, currently 6 */
 /* Developer options, process-wide: which kernel variant / launch plan is taken in A/B measurements and in the tests that
  * compare the variants bit for bit.  The library NEVER reads the environment (rounds 1 - 3 had getenv knobs in launch
- * paths); nothing but this call changes its behaviour.  value 0 = default.  Names: "conk_form" (1 rows, 2 flat, 3 2d),
- * "conk_rows" (rows per workgroup of the rows form), "slice_len" (cells per Gram slice), "solve_small_off" (1: the blocked
- * multi-launch Cholesky at every m), "jac_gram_wgs" (workgroups per Jacobi Gram launch), "lr_no_deflate" (1: mvf_solve_minnorm_lrd always takes the Jacobi path), "defl_block" (64 / 128 / 256: mvf_solve_minnorm_lrd tries that block size alone), "defl_apps" (1 .. 8: applications of S2^-1 in its block
- * inverse iteration), "lr_no_direct" (1: mvf_solve_minnorm_lrd never takes its direct form), "gram_f64_lds" (1: the float64 cached Gram
- * kernel shares its column panels through LDS), "direct_accept" (v > 0: the direct form accepts at most v - 1 deflated directions), "gram_budget_gb" (partial-tile budget of the Gram plan in GB), "lr_timing" (1: phase times of mvf_solve_minnorm_lr on stderr).  Unknown name: non-zero return.  mvf_debug_option_get returns -1 for an unknown name. */
+ * paths); nothing but this call changes its behaviour.  value 0 = default.  Nine names (round 6 removed four that no test
+ * or measurement used any more): "conk_form" (1 rows, 2 flat, 3 2d), "slice_len" (cells per Gram slice), "solve_small_off"
+ * (1: the blocked multi-launch Cholesky at every m), "lr_no_deflate" (1: mvf_solve_minnorm_lrd always takes the Jacobi path),
+ * "defl_block" (64 / 128 / 256: mvf_solve_minnorm_lrd tries that block size alone), "defl_apps" (1 .. 8: applications of
+ * S2^-1 in its block inverse iteration), "lr_no_direct" (1: mvf_solve_minnorm_lrd never takes its direct form),
+ * "direct_accept" (v > 0: the direct form accepts at most v - 1 deflated directions), "lr_timing" (1: phase times of
+ * mvf_solve_minnorm_lr on stderr).  Unknown name: non-zero return.  mvf_debug_option_get returns -1 for an unknown name. */
 int mvf_debug_option(const char* name, long long value);
 long long mvf_debug_option_get(const char* name);
 int mvf_device_count(int* count);      /* number of visible HIP devices (0 without a GPU) */

@@ -18,7 +18,7 @@ char* err_buf();
 int set_error(const char* fmt, ...);
 // Developer options (process-wide, set only through mvf_debug_option; the library never reads the environment): which
 // kernel variant / plan a launch takes in A/B measurements and in the tests that compare the variants.  0 = default.
-enum DebugOpt { DBG_CONK_FORM = 0, DBG_CONK_ROWS, DBG_SLICE_LEN, DBG_SOLVE_SMALL_OFF, DBG_JAC_GRAM_WGS, DBG_LR_TIMING, DBG_LR_NO_DEFLATE, DBG_DEFL_BLOCK, DBG_DEFL_APPS, DBG_LR_NO_DIRECT, DBG_GRAM_F64_LDS, DBG_DIRECT_ACCEPT, DBG_GRAM_BUDGET_GB, DBG_COUNT };
+enum DebugOpt { DBG_CONK_FORM = 0, DBG_SLICE_LEN, DBG_SOLVE_SMALL_OFF, DBG_LR_TIMING, DBG_LR_NO_DEFLATE, DBG_DEFL_BLOCK, DBG_DEFL_APPS, DBG_LR_NO_DIRECT, DBG_DIRECT_ACCEPT, DBG_COUNT };
 long long debug_opt(DebugOpt which);
 // compute units of the CURRENT HIP device (looked up once per device index; 256 if the query fails)
 int device_cu_count();

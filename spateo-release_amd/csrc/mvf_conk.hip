@@ -222,12 +222,11 @@ static int launch_conk(const T* x, int64_t n, const T* y, int64_t m, int d, doub
     const std::string form = knob ? std::string(knob) : std::string(rows_fit ? "rows" : (sizeof(T) == 4 ? "flat" : "2d"));
     const bool legacy = form != "flat";
     if (form == "rows" && rows_fit) {
-        const long long rk = debug_opt(DBG_CONK_ROWS);  // developer option: rows per workgroup
         // ~128 KB of contiguous output per workgroup, at most 16 rows (measured 8 / 16 / 32 / 64 rows per workgroup: within
         // 3 % of each other, profiles/r03_conk_ab_rowspans.json)
         const int64_t row_bytes = m * (int64_t)sizeof(T);
         const int rows_auto = (int)std::min<int64_t>(16, std::max<int64_t>(rs, (131072 / row_bytes) / rs * rs));
-        const int rows_pb = rk > 0 ? (int)rk : rows_auto;
+        const int rows_pb = rows_auto;
         const int spans_pb = std::max(1, rows_pb / rs);
         const dim3 grid((unsigned)cdiv(cdiv(n, rs), spans_pb));
         // (32 bytes per lane and pass - a 2 x VEC vector store - was measured too: 1.9 - 2.3 TB/s, the compiler does not emit

@@ -65,9 +65,7 @@ static GramPlan make_plan(int64_t n, int64_t m, mvf_dtype dtype) {
     // 20 GB; at least 3 GB) and is reused by several launches when the capped slices need more.
     const int64_t max_chunks = cdiv(n, GCHUNK);
     const double cache_bytes = (double)n * (double)m * (dtype == MVF_F64 ? 8.0 : 4.0);
-    double budget_bytes = std::min(20e9, std::max(3e9, 0.1 * cache_bytes));
-    const long long budget_knob = debug_opt(DBG_GRAM_BUDGET_GB);  // developer option: partial-tile budget in GB (A/B of the phase count)
-    if (budget_knob > 0) budget_bytes = 1e9 * (double)budget_knob;
+    const double budget_bytes = std::min(20e9, std::max(3e9, 0.1 * cache_bytes));  // (1 / 2 / 4 phases A/B-ed in round 5: no difference)
     const int64_t budget_jobs = std::max<int64_t>(p.npairs, (int64_t)(budget_bytes / (GT * GT * sizeof(double))));
     const int64_t fit = std::max<int64_t>(1, budget_jobs / p.npairs);  // slices whose partial tiles fit the buffer
     constexpr int64_t SL_CAP = 8192;
@@ -554,133 +552,6 @@ __global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_kernel(const 
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// float64 cached Gram with the column panels shared through LDS (round 5; developer option
-// "gram_f64_lds").  In gram_cached_kernel<double> every wave of a workgroup loads the same 8 column-block operands from L1
-// (10 global loads per k-step and wave, two k-steps of prefetch in the 40 operand VGPRs the accumulators leave).  Here wave w
-// fetches column blocks 2w and 2w + 1 only (4 global loads per k-step: 2 A, 2 B-share), drops them into a 4-stage LDS ring
-// one k-step ahead, and every wave reads its 8 B operands from LDS (lane l reads the 8 bytes lane l of the loading wave
-// wrote: conflict-free).  The same 40 VGPRs now hold FOUR k-steps of global prefetch.  One workgroup barrier per k-step;
-// the two workgroups of a CU cover each other's barrier and LDS latency.  Same values, same per-slice accumulation order
-// per output element (k-steps in order): bit-identical to the register-operand kernel.  Full 2 x 8 wave tile on every tile
-// pair, as the float64 instantiation of gram_cached_kernel does.
-// ----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, MVF_CACHED_WPS) void gram_cached_lds_kernel(const double* __restrict__ ublk,
-                                                                              const double* __restrict__ P, int64_t n,
-                                                                              int64_t n_pad, int64_t m, int nt, int npairs,
-                                                                              int64_t slice_len, int64_t slice0,
-                                                                              double* __restrict__ partial) {
-    constexpr int NA = 2, NB = 8, D = 4, LST = 4, SUPER = 8;  // SUPER k-steps = 4 KB of one pointer's stream
-    __shared__ double Bs[LST][NB][64];
-    const int pair = blockIdx.x % npairs;
-    const int64_t slice = blockIdx.x / npairs;
-    int ti, tj;
-    decode_pair(pair, nt, ti, tj);
-    const int64_t n0 = (slice0 + slice) * slice_len;
-    const int64_t n1 = min(n_pad, n0 + slice_len);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* out = partial + ((size_t)slice * npairs + pair) * (size_t)(GT * GT);
-    constexpr int TB = GT / UB;
-    const int64_t rb0 = (int64_t)ti * TB + 2 * wave, cb0 = (int64_t)tj * TB;
-    const int orow0 = 32 * wave;
-    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-
-    const double* pa[NA];
-    const double* pbs[2];
-    const double* pbd[NB];  // remainder only: every column block straight from global memory
-#pragma unroll
-    for (int a = 0; a < NA; ++a) pa[a] = ublk + ((rb0 + a) * n_pad + n0 + lk) * UB + li;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) pbs[j] = ublk + ((cb0 + 2 * wave + j) * n_pad + n0 + lk) * UB + li;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) pbd[b] = ublk + ((cb0 + b) * n_pad + n0 + lk) * UB + li;
-    const double* pP = P + n0 + lk;
-
-    f64x4 acc[NA][NB];
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
-
-    const int ngroups = (int)((n1 - n0) / 4);  // k-steps of 4 cells; slices are multiples of 256 cells
-    const int64_t live = max((int64_t)0, min(n1, n) - n0);
-    const int ng_main = (int)(min((int64_t)ngroups, live / 4) / SUPER) * SUPER;  // whole superblocks of existing cells
-    const int pmax = (int)min((int64_t)0x3fffffff, n - 1 - n0 - lk);
-
-    double ra[D][NA], rs[D][2], rp[D];
-    auto gload = [&](int64_t gbase, int s, int slot) {  // k-step gbase + s; `s`, `slot` static after unrolling
-        const int64_t off = (gbase + s) * (4 * UB);
-#pragma unroll
-        for (int a = 0; a < NA; ++a) ra[slot][a] = pa[a][off];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) rs[slot][j] = pbs[j][off];
-        rp[slot] = pP[(gbase + s) * 4];
-    };
-    if (ng_main > 0) {
-        // prologue: k-steps 0 .. D-1 in flight, the share of k-step 0 in stage 0
-#pragma unroll
-        for (int s = 0; s < D; ++s) gload(0, s, s);
-        Bs[0][2 * wave][lane] = rs[0][0];
-        Bs[0][2 * wave + 1][lane] = rs[0][1];
-        __syncthreads();
-        for (int g0 = 0; g0 < ng_main; g0 += SUPER) {
-#pragma unroll
-            for (int s = 0; s < SUPER; ++s) {
-                const int slot = s % D, stg = s % LST, nslot = (s + 1) % D, nstg = (s + 1) % LST;
-                // operands of k-step g0 + s: A x P from the ring, the 8 column blocks from the LDS stage
-                const double pd = rp[slot];
-                double fa[NA], fb[NB];
-#pragma unroll
-                for (int a = 0; a < NA; ++a) fa[a] = ra[slot][a] * pd;
-#pragma unroll
-                for (int b = 0; b < NB; ++b) fb[b] = Bs[stg][b][lane];
-                // the share of the NEXT k-step into its stage (read by everybody after this iteration's barrier)
-                if (g0 + s + 1 < ng_main) {
-                    Bs[nstg][2 * wave][lane] = rs[nslot][0];
-                    Bs[nstg][2 * wave + 1][lane] = rs[nslot][1];
-                }
-                // refill this ring slot with k-step g0 + s + D
-                if (g0 + s + D < ng_main) gload(g0, s + D, slot);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int a = 0; a < NA; ++a)
-#pragma unroll
-                    for (int b = 0; b < NB; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                __syncthreads();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-    // remainder (< SUPER k-steps, plus the padded cells of the last slice): unpipelined, operands straight from global
-    // memory, P index clamped (cached rows of padded cells are zero)
-    for (int g = ng_main; g < ngroups; ++g) {
-        const int64_t off = (int64_t)g * (4 * UB);
-        const double pd = pP[min(g * 4, pmax)];
-        double fa[NA], fb[NB];
-#pragma unroll
-        for (int a = 0; a < NA; ++a) fa[a] = pa[a][off] * pd;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) fb[b] = pbd[b][off];
-#pragma unroll
-        for (int a = 0; a < NA; ++a)
-#pragma unroll
-            for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
-    }
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = orow0 + a * 16 + lk + 4 * r;
-                const int col = b * 16 + li;
-                __builtin_nontemporal_store(acc[a][b][r], &out[row * GT + col]);
-            }
-        }
-}
-
-// ----------------------------------------------------------------------------------------------------------------
 // rhs:  R[j, :] = sum_n K(x_n, c_j) P_n y_n   (VALU kernel; a lane owns RHS_CPT control points, cells broadcast
 // from LDS; float64 accumulation)
 // ----------------------------------------------------------------------------------------------------------------
@@ -936,10 +807,6 @@ extern "C" int mvf_gram_cached(int stages, const void* ublk, const void* x4, con
                 hipLaunchKernelGGL(gram_cached_kernel<float>, dim3(njobs), dim3(256), 0, st, (const float*)ublk,
                                    (const float*)P, n, ublk_npad(n), m, p.nt, p.npairs, p.slice_len, s0,
                                    (double*)workspace, p.npairs, 0);
-            else if (debug_opt(DBG_GRAM_F64_LDS) != 0)  // developer option: column panels shared through LDS (A/B, round 5)
-                hipLaunchKernelGGL(gram_cached_lds_kernel, dim3(njobs), dim3(256), 0, st, (const double*)ublk,
-                                   (const double*)P, n, ublk_npad(n), m, p.nt, p.npairs, p.slice_len, s0,
-                                   (double*)workspace);
             else
                 hipLaunchKernelGGL(gram_cached_kernel<double>, dim3((unsigned)(ns * p.njobs)), dim3(256), 0, st,
                                    (const double*)ublk, (const double*)P, n, ublk_npad(n), m, p.nt, p.npairs, p.slice_len, s0,

@@ -19,8 +19,8 @@ int set_error(const char* fmt, ...) {
 }
 
 static std::atomic<long long> g_debug[DBG_COUNT];
-static const char* const g_debug_names[DBG_COUNT] = {"conk_form", "conk_rows", "slice_len", "solve_small_off", "jac_gram_wgs",
-                                                     "lr_timing", "lr_no_deflate", "defl_block", "defl_apps", "lr_no_direct", "gram_f64_lds", "direct_accept", "gram_budget_gb"};
+static const char* const g_debug_names[DBG_COUNT] = {"conk_form", "slice_len", "solve_small_off", "lr_timing", "lr_no_deflate",
+                                                     "defl_block", "defl_apps", "lr_no_direct", "direct_accept"};
 long long debug_opt(DebugOpt which) { return g_debug[which].load(std::memory_order_relaxed); }
 
 // Looked up per CURRENT device (the host binding makes the launch stream's device current) and remembered per device

@@ -1862,8 +1862,7 @@ static JacPlan jac_plan(int64_t m, int nrhs) {
     p.nb = (int)(p.mp / JB);
     p.npairs = p.nb / 2;
     const int nk = (int)(p.mp / 64);
-    const long long tk = debug_opt(DBG_JAC_GRAM_WGS);  // developer option: workgroups per Gram launch (default 512)
-    const int target = tk > 0 ? (int)std::max<long long>(64, tk) : 512;
+    const int target = 512;  // workgroups per Gram launch
     int want = std::max(1, target / p.npairs);
     p.nsplit = std::min(nk, want);
     p.kchunks = (int)cdiv(nk, p.nsplit);
@@ -2641,8 +2640,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
 
     // 2. one-sided block Jacobi on the r rows of Y
     const int nb = (int)(rp / JB), npairs = nb / 2, nk = (int)(mp / 64);
-    const long long gk = debug_opt(DBG_JAC_GRAM_WGS);  // developer option: workgroups per Gram launch
-    const int gram_wgs = gk > 0 ? (int)std::min<long long>(LR_GRAM_WGS, std::max<long long>(64, gk)) : LR_GRAM_WGS_DEFAULT;
+    const int gram_wgs = LR_GRAM_WGS_DEFAULT;
     int nsplit = std::min(nk, std::max(1, gram_wgs / npairs));
     const int kchunks = (int)cdiv(nk, nsplit);
     nsplit = (int)cdiv(nk, kchunks);

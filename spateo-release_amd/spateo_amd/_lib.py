@@ -14,15 +14,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # calls at load time.  Without the gate the environment changes nothing.
 DEV_KNOBS = os.environ.get("MVF_DEV_KNOBS") == "1"
 LIB_PATH = (DEV_KNOBS and os.environ.get("MVF_LIB_PATH")) or os.path.join(_HERE, "lib", "libmvf.so")
-DEBUG_OPTIONS = ("conk_form", "conk_rows", "slice_len", "solve_small_off", "jac_gram_wgs", "lr_timing", "lr_no_deflate", "defl_block",
-                 "defl_apps", "lr_no_direct", "gram_f64_lds",
-                 "direct_accept", "gram_budget_gb")
+DEBUG_OPTIONS = ("conk_form", "slice_len", "solve_small_off", "lr_timing", "lr_no_deflate", "defl_block", "defl_apps", "lr_no_direct",
+                 "direct_accept")
 _LEGACY_ENV = {  # environment name -> (option, value parser)
     "MVF_CONK": ("conk_form", lambda v: {"rows": 1, "flat": 2, "2d": 3}[v]),
-    "MVF_CONK_ROWS": ("conk_rows", int),
     "MVF_SLICE_LEN": ("slice_len", int),
     "MVF_SOLVE_SMALL": ("solve_small_off", lambda v: 1 if v.startswith("0") else 0),
-    "MVF_JAC_GRAM_WGS": ("jac_gram_wgs", int),
     "MVF_LR_TIMING": ("lr_timing", lambda v: 1),
 }
 
