@@ -362,12 +362,15 @@ def test_c4_generator_at_the_cpu_baseline_size(st, dtype):
 # sparsevfc_oracle.em_step, bit-identical to the `sumorder` form of the in-memory oracle) at BASELINE config 3's stated size,
 # at one rank's share of config 4, and for ONE EM iteration of config 4 itself; every 32nd - 256th cell of V / P is stored,
 # the floors (LAPACK driver swapped; the sums over cells made of another number of pieces) are evaluated on ALL cells.
-_STREAM_CASES = {"c3_full": ("C3", 2_000_000, 2000), "c4_rank": ("C4", 1_000_000, 3000), "c4_step": ("C4", 8_000_000, 3000)}
+_STREAM_CASES = {"c3_full": ("C3", 2_000_000, 2000), "c4_rank": ("C4", 1_000_000, 3000), "c4_step": ("C4", 8_000_000, 3000),
+                 "c4_3step": ("C4", 8_000_000, 3000)}
 
 
 @functools.lru_cache(maxsize=None)
 def _stream_fixture(name):
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"stream_oracle_{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} has not been generated (tests/golden/make_stream_oracle.py {name}: hours of host time)")
     with np.load(path) as z:
         fx = {k: z[k] for k in z.files}
     cfg, n, M = _STREAM_CASES[name]
@@ -376,7 +379,8 @@ def _stream_fixture(name):
                vmax=float(fx["vmax"]))
     # no float32-kernel variant was run at these sizes: the float32 mode is held to the float64-mode floors (stricter)
     table = {q: (float(fx[f"floor_{q}"]), float(fx[f"floor_{q}"])) for q in ("V", "sigma2", "P", "E")}
-    table["_variants"] = {v: {q: float(fx[f"var_{v}_{q}"]) for q in ("V", "sigma2", "P", "E")} for v in ("eigh", "sumorder")}
+    table["_variants"] = {v: {q: float(fx[f"var_{v}_{q}"]) for q in ("V", "sigma2", "P", "E")} for v in ("eigh", "sumorder")
+                          if f"var_{v}_V" in fx}  # (c4_3step: the eigh variant alone)
     return fx, ref, table
 
 
@@ -393,11 +397,13 @@ def _strict_fixture_check(tag, dtype, dev, table, tight=TIGHT):
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
-@pytest.mark.parametrize("case", ["c3_full", "c4_rank"])
+@pytest.mark.parametrize("case", ["c3_full", "c4_rank", "c4_3step"])
 def test_fit_against_the_streamed_oracle_at_benchmark_sizes(st, case, dtype):
     """BASELINE config 3 AT ITS STATED SIZE (2 M cells x 2000 control points) and one rank's share of config 4 (1 M x 3000):
     5 EM iterations at Spateo's lambda_ = 0.02 through the drop-in ``SparseVFC`` against the committed streamed-oracle
-    fixture - field, sigma^2, P and the energy trajectory each within 1.25 x its own reference floor."""
+    fixture - field, sigma^2, P and the energy trajectory each within 1.25 x its own reference floor.  c4_3step (round 6,
+    VERDICT r5 next #7): config 4 ITSELF, 8 M cells x 3000 control points, THREE EM iterations - the rank-deficient regime
+    of the coefficient solve starts at the second - floor = the oracle's own lstsq -> eigh variant over the same three."""
     from spateo_amd._synthetic import make_config
 
     fx, ref, table = _stream_fixture(case)
