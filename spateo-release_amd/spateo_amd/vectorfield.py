@@ -29,7 +29,7 @@ from . import _runtime as _rt
 from ._runtime import (DEFLATED_MIN_M, _check_lstsq_method, _Phases, _shared_kernels, _TLS, _to_host,  # noqa: F401
                        clear_eval_cache, last_fit_profile, set_default_dtype)
 from .engine import SparseVFCEngine, _current_device, _dist_info, _gather_rows_np, shard_bounds  # noqa: F401
-from .preprocess import (bandwidth_selector, sample_by_velocity, sparsevfc_preprocess, unique_rows,  # noqa: F401
+from .preprocess import (bandwidth_selector, finite_rows, sample_by_velocity, sparsevfc_preprocess, unique_rows,  # noqa: F401
                          _sample_by_norms, _sparsevfc_preprocess)
 
 __all__ = [
@@ -275,7 +275,7 @@ def SparseVFC(
         import torch.distributed as dist
 
         root = dist.get_global_rank(group, 0) if group is not None else 0
-        valid_loc = np.where(np.isfinite(Y.sum(1)))[0]
+        valid_loc = finite_rows(Y)
         if sharded_input:
             lens = [None] * world
             with _current_device(device):

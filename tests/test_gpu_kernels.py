@@ -865,8 +865,9 @@ def test_evaluators_matrix_form_far_from_the_centroid_with_cancelling_coefficien
     assert _relmax(vf.compute_divergence(X), np.trace(Jr)) < 1e-9
     vf.func = lambda x: st.vector_field_function(x, vfd, dtype="float64")
     v = svo.con_K(X, ctrl, 0.004) @ C
-    acc, _ = vf.compute_acceleration(X)
-    assert _relmax(acc, np.einsum("fin,ni->nf", Jr, v)) < 1e-9
+    acc_norm, acc = vf.compute_acceleration(X)
+    ref = np.einsum("fin,ni->nf", Jr, v)
+    assert _relmax(acc, ref) < 1e-9 and _relmax(acc_norm, np.linalg.norm(ref, axis=1)) < 1e-9
 
 
 @pytest.mark.parametrize("dtype,tol", [("float64", 1e-10), ("float32", 2e-4)])

@@ -549,6 +549,35 @@ def test_degenerate_inputs_behave_like_the_reference(cpu_kernels):
         st.SparseVFC(X, Y, None, M=1, beta=0.3, **kw)
 
 
+def test_row_norms_and_finite_rows_are_the_reference_expressions_bit_for_bit():
+    """The two host shortcuts of round 6: ``row_norms(V)`` IS ``np.linalg.norm(V, axis=1)`` (the weights of dynamo's
+    velocity-based draw: one differing bit could change the draw) and ``finite_rows(Y)`` IS
+    ``np.where(np.isfinite(Y.sum(1)))[0]`` - including NaN / inf entries, row sums that overflow although every entry is
+    finite, integer and float32 input, 1 - 9 columns, empty and Fortran-ordered arrays."""
+    from spateo_amd.preprocess import finite_rows, row_norms
+
+    rng = np.random.default_rng(23)
+    for d in range(1, 10):
+        V = rng.standard_normal((4001, d)) * rng.uniform(1e-150, 1e150, (4001, 1))
+        for A in (V, np.asfortranarray(V), V[::3], V.astype(np.float32)):
+            assert row_norms(A).tobytes() == np.linalg.norm(A, axis=1).tobytes(), d
+            assert np.array_equal(finite_rows(A), np.where(np.isfinite(A.sum(1)))[0])
+    Y = rng.standard_normal((1000, 3))
+    for bad in (np.nan, np.inf, -np.inf):
+        Z = Y.copy()
+        Z[[3, 500, 999], [0, 2, 1]] = bad
+        assert np.array_equal(finite_rows(Z), np.where(np.isfinite(Z.sum(1)))[0]) and len(finite_rows(Z)) == 997
+    Z = Y.copy()
+    Z[7] = [1.7e308, 1.7e308, 0.0]      # finite entries, the row SUM overflows: the reference drops the row
+    Z[8] = [1.7e308, -1.7e308, 1.0]     # ... and keeps this one
+    with np.errstate(over="ignore"):
+        ref = np.where(np.isfinite(Z.sum(1)))[0]
+        got = finite_rows(Z)
+    assert np.array_equal(got, ref) and 7 not in got and 8 in got
+    assert np.array_equal(finite_rows(np.zeros((0, 3))), np.where(np.isfinite(np.zeros((0, 3)).sum(1)))[0])
+    assert np.array_equal(finite_rows(np.arange(12).reshape(4, 3)), np.arange(4))
+
+
 def test_unique_rows_matches_numpy_unique():
     """The host shortcut for dynamo's ``np.unique(X, axis=0, return_index=True)`` is bit-identical to it (rows, first
     occurrence indices), including ties on the leading coordinate, duplicated rows, signed zeros and 1/2/3 columns."""
