@@ -10,7 +10,7 @@ rows = []
 for line in open(sys.argv[1], errors="replace"):
     line = line.lstrip(".FEsx")
     m = re.match(r"(C2 lambda [\d.]+|C5 organ|M=\d+ lambda=[\d.]+|C4 generator .*?lambda=[\d.]+|c3_full \(.*?\)|c4_rank \(.*?\)|"
-                 r"c4_step \(.*?\)|PIVOT [\w ,]+?) (float\d+): (?:iterations \d+; )?(.*)", line)
+                 r"c4_step \(.*?\)|c4_3step \(.*?\)|PIVOT [\w ,]+?) (float\d+): (?:iterations \d+; )?(.*)", line)
     if not m:
         continue
     case, dtype, rest = m.groups()

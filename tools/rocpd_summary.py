@@ -6,12 +6,13 @@ import sqlite3
 import sys
 
 
-def main(path):
+def main(path, by_grid=False):
+    """by_grid: one row per (kernel, grid size) - tells the launches of the same kernel at different problem sizes apart."""
     con = sqlite3.connect(path)
     rows = con.execute(
         "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(vgpr_count), "
         "max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(grid_x), max(workgroup_x) from kernels "
-        "group by name order by sum(duration) desc"
+        f"group by name{', grid_x' if by_grid else ''} order by sum(duration) desc"
     ).fetchall()
     total = sum(r[2] for r in rows) or 1
     print("| kernel | calls | total ms | avg ms | min ms | max ms | % | vgpr | agpr | sgpr | lds B | grid_x | wg_x |")
@@ -23,4 +24,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], by_grid="--by-grid" in sys.argv[2:])
