@@ -963,7 +963,7 @@ def test_preprocess_uses_the_device_unique_and_matches_the_host(st):
         np.testing.assert_array_equal(u, v)
 
 
-@pytest.mark.parametrize("m,d", [(1024, 3), (1500, 3), (3000, 3), (2000, 2), (8192, 3)])
+@pytest.mark.parametrize("m,d", [(256, 3), (500, 3), (1024, 3), (1500, 3), (3000, 3), (2000, 2), (8192, 3)])
 def test_knn_bandwidth_on_the_device_is_the_host_bandwidth(st, m, d):
     """dynamo's bandwidth_selector with the neighbour search on the device (all squared distances of a point in LDS,
     bitonic sort, sum of the k - 1 smallest non-self distances) against the kd-tree route: the same distances summed in
