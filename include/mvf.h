@@ -288,7 +288,9 @@ int mvf_solve_minnorm_lr(const double* G, const double* K, double lambda_sigma2,
  * reads the workspace state before it launches, the Rayleigh-Ritz counter and the acceptance numbers after (three round
  * trips of ~40 us in a 0.9 ms call, and the host cannot run ahead of the device across any of them).  The caller says what it
  * knows from the previous call's einfo ON THIS WORKSPACE: form_hint = 1: that call returned einfo[6] == m (all m columns
- * kept) through the factor form, 2: through the direct form (its block is continued).  The device verifies the state
+ * kept) through the factor form, 2: through the direct form (its block is continued); + 4 (that is 5 or 6): the matrix
+ * moved since that call (the caller's sigma^2 changed by more than a few per cent): 13 warm power steps for lambda_max
+ * instead of 5, as the synchronous entry adds them after reading the Rayleigh quotient.  The device verifies the state
  * (a stale or foreign workspace, a pending cool-down: not accepted) and takes the acceptance decision itself (every pivot
  * above the tolerance, lambda_max settled after the five warm power steps, the 64 x 64 Rayleigh-Ritz converged inside its one
  * launch, at most 40 directions below the cut): einfo[9] = 0: accepted - C, einfo[0..8] and the workspace exactly as the

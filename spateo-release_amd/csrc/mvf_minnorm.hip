@@ -2197,7 +2197,13 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
     // test before the deflated solve then refines as before.
     double* xkeep = (double*)(ws + p.off_xkeep);
     const int use_hint0 = rank_hint > 0 && rank_hint <= m;
-    const int npow = use_hint0 ? 5 : (deflate ? 12 : 8);  // the deflated solve takes its cut-off from this estimate
+    // (form_hint bit 4, asynchronous entry only: the CALLER knows that the matrix moved since the previous call - sigma^2
+    // changed by more than a few per cent, the first iterations of a fit - and asks for the 13 steps the synchronous entry
+    // adds after reading the quotient; without it a fit's early asynchronous attempts fail the lambda_max test and cost a
+    // repeat plus a four-call cool-down)
+    const bool more_power = (form_hint & 4) != 0;
+    form_hint &= 3;
+    const int npow = use_hint0 ? (more_power ? 13 : 5) : (deflate ? 12 : 8);  // the deflated solve takes its cut-off from this estimate
     hipLaunchKernelGGL(lr_power_kernel, dim3(1), dim3(256), 0, st, xv, xv + mp, m, mp, use_hint0 ? 2 : 1, stt,
                        (const double*)xkeep, rank_hint, (double*)nullptr);
     for (int it = 0; it < npow; ++it) {
@@ -2734,7 +2740,8 @@ extern "C" int mvf_solve_minnorm_lrd(const double* G, const double* K, double la
 extern "C" int mvf_solve_minnorm_lrd_async(const double* G, const double* K, double lambda_sigma2, double tolf, double rcond,
                                            const double* R, int64_t m, int nrhs, double* C, int* info, double* einfo,
                                            int form_hint, void* workspace, size_t workspace_bytes, void* stream) {
-    MVF_REQUIRE(form_hint == 1 || form_hint == 2, "mvf_solve_minnorm_lrd_async: form_hint must be 1 or 2 (got %d)", form_hint);
+    MVF_REQUIRE((form_hint & ~4) == 1 || (form_hint & ~4) == 2,
+                "mvf_solve_minnorm_lrd_async: form_hint must be 1 or 2, optionally + 4 (got %d)", form_hint);
     MVF_REQUIRE(m >= 2 * DEFL_TINY && m <= 640, "mvf_solve_minnorm_lrd_async: the direct form covers 128 <= m <= 640 (got %lld)",
                 (long long)m);
     MVF_REQUIRE(debug_opt(DBG_LR_NO_DEFLATE) == 0 && debug_opt(DBG_LR_NO_DIRECT) == 0,

@@ -593,6 +593,14 @@ def test_direct_form_without_host_synchronisation(st):
     np.testing.assert_array_equal(A1, S1)
     np.testing.assert_array_equal(A2, S2)
     np.testing.assert_array_equal(a2[:8], s2[:8])
+    # form_hint + 4 ("the matrix moved": thirteen warm power steps instead of five) on an unchanged matrix: lambda_max was
+    # settled already, the same decisions, the same field to rounding
+    km = _k("float64")
+    M0, _, m0 = _run_minnorm(km, G, K, ls2, R, method="deflated")
+    M1, j1, m1 = async_call(km, int(m0[8]) | 4)
+    M2, j2, m2 = async_call(km, int(m1[8]) | 4)
+    assert j1 == 0 and j2 == 0 and m1[9] == 0.0 and m2[9] == 0.0 and int(m2[8]) == 2 and int(m2[1]) == int(s2[1])
+    assert np.abs(U @ (M2 - S2)).max() / np.abs(U @ S2).max() < 1e-9 and abs(m2[2] / s2[2] - 1) < 1e-9
     A3, _, a3 = _run_minnorm(ka, G, K, ls2, R, method="deflated", rank_hint=500)   # a synchronous call continues from it
     S3, _, s3 = _run_minnorm(ks, G, K, ls2, R, method="deflated", rank_hint=500)
     np.testing.assert_array_equal(A3, S3)
