@@ -37,6 +37,11 @@ static void run(int64_t n, int64_t m, mvf_dtype dt) {
         float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
         printf("   %-24s %8.2f ms  %6.1f TF(alg)\n", name, ms, flops / ms / 1e9);
     };
+    {
+        hipEventRecord(e0); for (int r = 0; r < 3; ++r) mvf_ublk_build(x, n, c, m, beta, ub, ubb, dt, nullptr); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+        printf("   %-24s %8.2f ms  %6.2f TB/s written\n", "ublk_build", ms, ubb / ms / 1e9);
+    }
     timeit("tiles cached", 1, true);
     timeit("tiles recompute", 1, false);
     timeit("rhs", 2, true);
