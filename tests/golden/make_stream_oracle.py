@@ -40,6 +40,7 @@ CASES = {
     "c4_3step": dict(cfg="C4", n=8_000_000, M=3000, steps=3, stride=256, chunks=(128, None)),
     # seconds-sized twin of the above for the CPU test of this script's plumbing
     "tiny": dict(cfg="C3", n=6_000, M=150, steps=3, stride=4, chunks=(5, 3)),
+    "tiny3": dict(cfg="C3", n=6_000, M=150, steps=3, stride=4, chunks=(5, None)),
 }
 LAMBDA = 0.02
 T0 = time.time()
@@ -88,6 +89,36 @@ def run(name):
         variants["eigh"] = devs(dict(V=V2, P=em.P, sigma2=s2, E_traj=ref["E_traj"]), ref)
         log("eigh", variants["eigh"])
         del em
+    elif c["chunks"][1] is None:
+        # several iterations, eigh variant only: the two runs share the FIRST iteration's assembled system (the variant
+        # differs from the base run in the solver alone, and P of iteration 1 precedes every solve), then go their own ways
+        def trajectory(em, E0, s0):
+            E_t, s_t = [E0], [s0]
+            for _ in range(c["steps"] - 1):
+                E, _ = em.step(lambda_=LAMBDA)
+                E_t.append(E)
+                s_t.append(em.sigma2)
+                log("  iteration", len(E_t), "sigma2", em.sigma2)
+            return dict(V=em.V, P=em.P, sigma2=em.sigma2, E_traj=np.array(E_t), sigma2_traj=np.array(s_t),
+                        iteration=c["steps"] - 1)
+
+        em = so.StreamedEM(setup[1], setup[2], setup[4], setup[5], c["chunks"][0], progress=progress("base"))
+        E1, tecr1 = em.step(lambda_=LAMBDA, keep_system=True)
+        log("iteration 1 done: sigma2", em.sigma2)
+        em2 = so.StreamedEM(setup[1], setup[2], setup[4], setup[5], c["chunks"][0], solver=F.eigh_solver,
+                            progress=progress("eigh"))
+        em2._buf = em._buf
+        C2 = F.eigh_solver(em.lhs, em.rhs)
+        V2 = em.apply(C2)
+        s2 = float(em.P[:, 0].dot(np.sum((em.Y - V2) ** 2, 1)) / (np.sum(em.P) * em.D))
+        em2.P, em2.E, em2.tecr, em2.C, em2.V, em2.sigma2, em2.gamma = em.P, em.E, em.tecr, C2, V2, s2, em.gamma
+        em.lhs = em.rhs = None
+        ref = trajectory(em, E1, em.sigma2)
+        log("base done: sigma2", ref["sigma2_traj"])
+        got = trajectory(em2, E1, s2)
+        variants["eigh"] = devs(got, ref)
+        log("eigh", variants["eigh"])
+        del got, em, em2
     else:
         ref = so.SparseVFC_streamed(X, Y, chunks=c["chunks"][0], progress=progress("base"), **kw)
         log("base done: sigma2", ref["sigma2_traj"])
