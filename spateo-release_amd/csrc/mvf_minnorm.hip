@@ -208,6 +208,12 @@ __device__ __forceinline__ void inner_pair(int r, int l, int& p, int& q) {
 // Blocks partition S, so phase B is in place; two barriers per round.  Within a half-wave the 32 lanes touch 32 distinct
 // columns of one row: conflict-free without padding.
 constexpr int EIG_THREADS = 1024;
+// Stopping criterion of the RAYLEIGH-RITZ problems of the deflated solves (the projected matrix H = (Z Rc)(Z Rc)^T of the block
+// of smallest Ritz values; NOT of the full eigendecompositions, which keep sqrt(m) eps): |h_pq| <= RR_TOL sqrt(h_pp h_qq).
+#ifndef MVF_RR_TOL
+#define MVF_RR_TOL 1.4551915228366852e-11 /* 2^-36 */
+#endif
+constexpr double RR_TOL = MVF_RR_TOL;
 // inner_sweeps > 1 (FULL only; used when the pair IS the whole matrix, the 64 x 64 Rayleigh-Ritz problem of the small
 // deflated solve): the sweep is repeated on the Gram tile in LDS until one applies no rotation (at most inner_sweeps times)
 // and J accumulates all of them - a complete two-sided Jacobi diagonalisation in ONE launch instead of eight rounds of
@@ -2299,7 +2305,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         const int hnb = b / JB;  // 2: one pair
         hipLaunchKernelGGL(jac_init_kernel, dim3(1u, 1u), dim3(256), 0, st, cq.W, (int64_t)b, (int64_t)b, Yh, mod,
                            hnb + hnb * hnb, rot, 64);  // (+ the stamps, the rotation counter and the diagnostics behind it)
-        const double htol = std::sqrt((double)b) * 2.220446049250313e-16;
+        const double htol = RR_TOL;
         int* hclean = mod + hnb;
         int hsweeps = 0;
         unsigned int hrot2 = 1;
@@ -2532,7 +2538,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
                                (int64_t)b, Yh);
             MVF_LAUNCH_CHECK();
             const int hnb = b / JB, hnp = hnb / 2, hnk = b / 64;
-            const double htol = std::sqrt((double)b) * 2.220446049250313e-16;
+            const double htol = RR_TOL;
             int* hclean = mod + hnb;
             MVF_CHECK_HIP(hipMemsetAsync(mod, 0, (size_t)(hnb + (size_t)hnb * hnb) * sizeof(int), st));
             hsweeps = 0;
