@@ -254,18 +254,27 @@ extern "C" int mvf_apply(const void* x4, int64_t n, const void* ctrl4, int64_t m
     MVF_REQUIRE(!(P && y4) || (stats && scratch), "mvf_apply: P given but stats / scratch is null");
     hipStream_t st = (hipStream_t)stream;
     const double s = std::sqrt(beta * LOG2E);
-    constexpr int CPT = 4;
-    const int64_t nblocks = dtype == MVF_F32 ? cdiv(n, 256 * CPT) : cdiv(n, 256 * 2);
-    if (dtype == MVF_F32)
-        hipLaunchKernelGGL((apply_kernel<float, CPT>), dim3((unsigned)nblocks), dim3(256), 0, st, (const float*)x4, n,
-                           (const float*)ctrl4, m, (float)s, C, (float*)V4, (const float*)y4, (const float*)P,
-                           (float*)r, scratch);
-    else if (dtype == MVF_F64)
-        hipLaunchKernelGGL((apply_kernel<double, 2>), dim3((unsigned)nblocks), dim3(256), 0, st, (const double*)x4, n,
-                           (const double*)ctrl4, m, s, C, (double*)V4, (const double*)y4, (const double*)P, (double*)r,
-                           scratch);
-    else
+    // Cells per lane: 4 (float) / 2 (double) when that still gives every compute unit several workgroups, fewer below (50 k
+    // cells at 4 per lane are 49 workgroups on 256 compute units: BASELINE config 2's field update ran on a fifth of the part).
+    // A cell's sum runs over the control points in the same order whatever the choice: the same bits.
+    const int cpt_max = dtype == MVF_F32 ? 4 : 2;
+    int cpt = cpt_max;
+    while (cpt > 1 && cdiv(n, (int64_t)256 * cpt) < 1024) cpt >>= 1;
+    const int64_t nblocks = cdiv(n, (int64_t)256 * cpt);
+#define MVF_APPLY_LAUNCH(T, CPT_)                                                                                              \
+    hipLaunchKernelGGL((apply_kernel<T, CPT_>), dim3((unsigned)nblocks), dim3(256), 0, st, (const T*)x4, n, (const T*)ctrl4, \
+                       m, (T)s, C, (T*)V4, (const T*)y4, (const T*)P, (T*)r, scratch)
+    if (dtype == MVF_F32) {
+        if (cpt == 4) MVF_APPLY_LAUNCH(float, 4);
+        else if (cpt == 2) MVF_APPLY_LAUNCH(float, 2);
+        else MVF_APPLY_LAUNCH(float, 1);
+    } else if (dtype == MVF_F64) {
+        if (cpt == 2) MVF_APPLY_LAUNCH(double, 2);
+        else MVF_APPLY_LAUNCH(double, 1);
+    } else {
         return set_error("mvf_apply: bad dtype %d", (int)dtype);
+    }
+#undef MVF_APPLY_LAUNCH
     MVF_LAUNCH_CHECK();
     if (y4 && P) {
         hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, scratch, nblocks, 1, 1, stats);
@@ -275,7 +284,8 @@ extern "C" int mvf_apply(const void* x4, int64_t n, const void* ctrl4, int64_t m
 }
 
 extern "C" size_t mvf_reduce_scratch_doubles(int64_t n) {
-    // apply: one partial per 512 cells; estep_p: 5 per block (<= 2048 blocks); quadform: one per control point
+    // apply: one partial per workgroup (>= 512 cells each, or fewer than 2048 workgroups); estep_p: 5 per block (<= 2048
+    // blocks); quadform: one per control point
     return (size_t)std::max<int64_t>(cdiv(std::max<int64_t>(n, 1), 512) + 16, 5 * 2048 + 16);
 }
 
