@@ -1,4 +1,6 @@
 #!/bin/bash
+# (record of a measurement: the "new basis" variants' code was not kept - profiles/r06_rr_ab.md; the libraries under tools/ab/ were
+# built from the tree of that moment with -DMVF_RR_OLD_BASIS / -DMVF_RR_TOL=1.7763568394002505e-15)
 # round 6, re-entry: the Rayleigh-Ritz problems of the deflated solves - block continued in the basis of the previous call's Ritz
 # vectors (new basis) or not (old), stopping criterion sqrt(b) eps (tight) or 2^-36 (relaxed): sweeps of the one-launch 64 x 64
 # problem in the EM's steady state, and the EM step of C2 / one C5 organ / M = 300 / 640 / C3-sized M = 2000, same box
