@@ -53,7 +53,7 @@ enum {
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
 const char* mvf_last_error(void);
-int mvf_version(void);                 /* ABI version, currently 6 */
+int mvf_version(void);                 /* ABI version, currently 7 */
 /* Developer options, process-wide: which kernel variant / launch plan is taken in A/B measurements and in the tests that
  * compare the variants bit for bit.  The library NEVER reads the environment (rounds 1 - 3 had getenv knobs in launch
  * paths); nothing but this call changes its behaviour.  value 0 = default.  Nine names (round 6 removed four that no test
@@ -137,6 +137,10 @@ int mvf_estep_min(const void* r, int64_t n, double sigma2, double* mins, mvf_dty
 int mvf_estep_p(const void* r, int64_t n, double sigma2, double gamma, double a, int dy, double minP, double theta,
                 double t1_zero_fill, const double* t1_zero_fill_dev, void* P_out, double* stats, double* scratch,
                 mvf_dtype dtype, void* stream);
+/* mvf_estep (ABI 7): mvf_estep_min followed by mvf_estep_p with the fill taken from mins[0] on the device - the E-step of ONE
+ * process (no MIN all-reduce between the phases) in one call.  `stats` is OVERWRITTEN (no memset by the caller).  n >= 1. */
+int mvf_estep(const void* r, int64_t n, double sigma2, double gamma, double a, int dy, double minP, double theta, double* mins,
+              void* P_out, double* stats, double* scratch, mvf_dtype dtype, void* stream);
 
 /* ---- M-step assembly:  G = U^T diag(P) U (m x m),  R = U^T diag(P) Y (m x 3)  --------------------------------
  * Replaces: `UP = U.T * repmat(P.T, M, 1); lhs = UP.dot(U) ...; rhs = UP.dot(Y)` of SparseVFC (App. A 5c; same

@@ -315,9 +315,29 @@ extern "C" int mvf_estep_min(const void* r, int64_t n, double sigma2, double* mi
     return 0;
 }
 
+static int estep_p_impl(const void* r, int64_t n, double sigma2, double gamma, double a, int dy, double minP, double theta,
+                        double t1_zero_fill, const double* t1_zero_fill_dev, void* P_out, double* stats, double* scratch,
+                        mvf_dtype dtype, void* stream, int overwrite);
+
 extern "C" int mvf_estep_p(const void* r, int64_t n, double sigma2, double gamma, double a, int dy, double minP,
                            double theta, double t1_zero_fill, const double* t1_zero_fill_dev, void* P_out,
                            double* stats, double* scratch, mvf_dtype dtype, void* stream) {
+    return estep_p_impl(r, n, sigma2, gamma, a, dy, minP, theta, t1_zero_fill, t1_zero_fill_dev, P_out, stats, scratch, dtype,
+                        stream, 0);
+}
+
+// Both phases in one call (one process: nothing has to happen between them), stats OVERWRITTEN: the head of an EM iteration
+// is what the device waits for after the iteration's one host read, and every separate call there is exposed host latency.
+extern "C" int mvf_estep(const void* r, int64_t n, double sigma2, double gamma, double a, int dy, double minP, double theta,
+                         double* mins, void* P_out, double* stats, double* scratch, mvf_dtype dtype, void* stream) {
+    MVF_REQUIRE(n >= 1, "mvf_estep: need n >= 1");
+    if (int rc = mvf_estep_min(r, n, sigma2, mins, dtype, stream)) return rc;
+    return estep_p_impl(r, n, sigma2, gamma, a, dy, minP, theta, 0.0, mins, P_out, stats, scratch, dtype, stream, 1);
+}
+
+static int estep_p_impl(const void* r, int64_t n, double sigma2, double gamma, double a, int dy, double minP, double theta,
+                        double t1_zero_fill, const double* t1_zero_fill_dev, void* P_out, double* stats, double* scratch,
+                        mvf_dtype dtype, void* stream, int overwrite) {
     MVF_REQUIRE(n >= 0 && sigma2 > 0.0 && gamma > 0.0 && gamma < 1.0 && a > 0.0 && dy >= 1,
                 "mvf_estep_p: bad parameters (sigma2=%g gamma=%g a=%g dy=%d)", sigma2, gamma, a, dy);
     if (n == 0) return 0;
@@ -335,7 +355,7 @@ extern "C" int mvf_estep_p(const void* r, int64_t n, double sigma2, double gamma
     else
         return set_error("mvf_estep_p: bad dtype %d", (int)dtype);
     MVF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, scratch, (int64_t)nb, 5, 5, stats);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, scratch, (int64_t)nb, 5, 5, stats, overwrite);
     MVF_LAUNCH_CHECK();
     return 0;
 }

@@ -47,7 +47,7 @@ int device_cu_count() {
 
 extern "C" const char* mvf_last_error(void) { return mvf::err_buf(); }
 
-extern "C" int mvf_version(void) { return 6; }
+extern "C" int mvf_version(void) { return 7; }
 
 extern "C" int mvf_debug_option(const char* name, long long value) {
     if (!name) return mvf::set_error("mvf_debug_option: null name");

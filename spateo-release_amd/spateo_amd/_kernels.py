@@ -25,6 +25,8 @@ def _on_device(fn):
 
     @functools.wraps(fn)
     def wrapped(self, *a, **kw):
+        if torch.cuda.current_device() == self._dev_index:  # the usual case: no context switch (microseconds per launch,
+            return fn(self, *a, **kw)                        # exposed at the head of a sub-millisecond EM iteration)
         with torch.cuda.device(self.device):
             return fn(self, *a, **kw)
 
@@ -42,6 +44,8 @@ class HipKernels:
             )
         self.lib = _lib.load()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._gram_need = {}
         if dtype not in _DT:
             raise ValueError(f"dtype must be 'float32' or 'float64', got {dtype!r}")
         self.dtype_name = dtype
@@ -228,6 +232,13 @@ class HipKernels:
                                         _ptr(fill_dev), _ptr(P_out), _ptr(stats),
                                         self._red(r.shape[0]), self.cdtype, self._stream()), "mvf_estep_p")
 
+    @_on_device
+    def estep(self, r, sigma2, gamma, a, dy, minP, theta, P_out, stats):
+        """Both phases of the E-step in one call (one process: no MIN all-reduce between them); `stats` is overwritten."""
+        _lib.check(self.lib.mvf_estep(_ptr(r), r.shape[0], float(sigma2), float(gamma), float(a), int(dy), float(minP),
+                                      float(theta), _ptr(self._mins), _ptr(P_out), _ptr(stats), self._red(r.shape[0]),
+                                      self.cdtype, self._stream()), "mvf_estep")
+
     def ublk_bytes(self, n, m):
         return int(self.lib.mvf_ublk_bytes(n, m, self.cdtype))
 
@@ -290,7 +301,10 @@ class HipKernels:
         and the second half of a multi-rank step; tiles_only: only G (tile stage + its reduction) - the first half of a
         multi-rank step, whose all-reduce of G then overlaps the rhs kernels."""
         n, m = x4.shape[0], ctrl4.shape[0]
-        need = self.lib.mvf_gram_workspace_bytes(n, m, self.cdtype)
+        key = (n, m, _lib.OPTION_EPOCH[0])
+        need = self._gram_need.get(key)
+        if need is None:  # (the call runs the launch plan's search: once per shape, not once per EM iteration)
+            need = self._gram_need[key] = self.lib.mvf_gram_workspace_bytes(n, m, self.cdtype)
         if self._gram_ws is None or self._gram_ws.numel() < need:
             self._gram_ws = None
             self._gram_ws = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)

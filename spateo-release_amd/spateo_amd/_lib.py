@@ -50,6 +50,7 @@ SIGNATURES = {
     "mvf_apply": (_i, [_p, _i64, _p, _i64, _d, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "mvf_estep_min": (_i, [_p, _i64, _d, _p, _i, _p]),
     "mvf_estep_p": (_i, [_p, _i64, _d, _d, _d, _i, _d, _d, _d, _p, _p, _p, _p, _i, _p]),
+    "mvf_estep": (_i, [_p, _i64, _d, _d, _d, _i, _d, _d, _p, _p, _p, _p, _i, _p]),
     "mvf_gram_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "mvf_gram": (_i, [_p, _p, _p, _i64, _p, _i64, _d, _p, _p, _p, _sz, _i, _p]),
     "mvf_gram_stages": (_i, [_i, _p, _p, _p, _i64, _p, _i64, _d, _p, _p, _p, _sz, _i, _p]),
@@ -122,8 +123,12 @@ def load():
     return lib
 
 
+OPTION_EPOCH = [0]  # bumped by every debug_option call: what callers key their cached launch-plan sizes with
+
+
 def debug_option(name, value):
     """Set a developer option of the library (mvf.h: mvf_debug_option); returns the previous value."""
+    OPTION_EPOCH[0] += 1
     lib = load()
     old = int(lib.mvf_debug_option_get(name.encode()))
     check(lib.mvf_debug_option(name.encode(), int(value)), "mvf_debug_option")

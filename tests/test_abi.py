@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libmvf.so does not export {name}"
     assert sorted(_lib.SIGNATURES) == declared, "ctypes table and include/mvf.h disagree"
-    assert lib.mvf_version() == 6
+    assert lib.mvf_version() == 7
 
 
 def test_constants_match_header():
