@@ -1524,39 +1524,6 @@ __global__ __launch_bounds__(256) void defl_sub_kernel(const double* __restrict_
     T[e] -= s;
 }
 
-// T (n x 8) -= Wsel^T (Wsel T) for a 64-row Wsel in ONE single-workgroup launch (the three-launch form - rowstat, back,
-// sub - costs 14 us of launch floor per projection at n = 512; a 64 x 512 Wsel is 256 KB, one compute unit's worth)
-__global__ __launch_bounds__(1024) void defl_project64_kernel(const double* __restrict__ Wsel, int64_t n, double* __restrict__ T) {
-    __shared__ double cb[64][8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // 16 waves
-    for (int i = wave; i < 64; i += 16) {  // cb[i][:] = Wsel[i][:] . T
-        const double* w = Wsel + (int64_t)i * n;
-        double t[8];
-#pragma unroll
-        for (int d = 0; d < 8; ++d) t[d] = 0.0;
-        for (int64_t k = lane; k < n; k += 64) {
-            const double v = w[k];
-#pragma unroll
-            for (int d = 0; d < 8; ++d) t[d] = fma(v, T[k * 8 + d], t[d]);
-        }
-#pragma unroll
-        for (int d = 0; d < 8; ++d) t[d] = wave_sum(t[d]);
-        if (lane == 0) {
-#pragma unroll
-            for (int d = 0; d < 8; ++d) cb[i][d] = t[d];
-        }
-    }
-    __syncthreads();
-    for (int64_t e = tid; e < n * 8; e += 1024) {  // T[k][d] -= sum_i Wsel[i][k] cb[i][d]  (i ascending: fixed order)
-        const int64_t k = e >> 3;
-        const int d = (int)(e & 7);
-        double s = 0.0;
-#pragma unroll 8
-        for (int i = 0; i < 64; ++i) s = fma(Wsel[(int64_t)i * n + k], cb[i][d], s);
-        T[e] -= s;
-    }
-}
-
 // ---- the direct form of the small deflated solve (round 5) ---------------------------------------------------------------
 // When the previous call on the workspace factored ALL m columns (factor rank r = m: what M <= 640 control points give, BASELINE
 // configs 2 and 5) the pivoted Cholesky of the next, nearby matrix is, in that pivot order, an ordinary Cholesky of the permuted
@@ -2109,10 +2076,8 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         double *dummy = (double*)(dw + d.dummy), *dpart = (double*)(dw + d.part), *Wsel = (double*)(dw + d.wsel);
         const double* Minv = S;
         auto project = [&](double* T) {  // T -= Wsel^T (Wsel T)
-            if (b == DEFL_TINY) {
-                hipLaunchKernelGGL(defl_project64_kernel, dim3(1), dim3(1024), 0, st, (const double*)Wsel, rp, T);
-                return;
-            }
+            // (a fused single-workgroup form of this projection for 64-row blocks measured 63 us per call against ~10 for these
+            // three launches - one compute unit pulling 256 KB through dependent loads: profiles/r06_c2_step_timeline_b.md)
             hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, Wsel, (int64_t)b, rp, rp, T, 8,
                                dummy, cb);
             hipLaunchKernelGGL(jac_back_kernel, dim3((unsigned)(rp / 64), 4u), dim3(256), 0, st, Wsel, (int64_t)b, rp, rp, cb,
@@ -2147,10 +2112,6 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         double *Ta = (double*)(dw + d.ta), *Tb = (double*)(dw + d.tb), *cb = (double*)(dw + d.cb);
         double *dummy = (double*)(dw + d.dummy), *dpart = (double*)(dw + d.part), *Wsel = (double*)(dw + d.wsel);
         auto project = [&](double* T) {  // T -= Wsel^T (Wsel T)
-            if (b == DEFL_TINY) {
-                hipLaunchKernelGGL(defl_project64_kernel, dim3(1), dim3(1024), 0, st, (const double*)Wsel, rp, T);
-                return;
-            }
             hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, Wsel, (int64_t)b, rp, rp, T, 8,
                                dummy, cb);
             hipLaunchKernelGGL(jac_back_kernel, dim3((unsigned)(rp / 64), 4u), dim3(256), 0, st, Wsel, (int64_t)b, rp, rp, cb,
