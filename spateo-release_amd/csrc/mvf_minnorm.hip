@@ -33,11 +33,55 @@
 // Every transformation applied to Y is orthogonal to rounding, so Y^T Y == L L^T to rounding whatever the rotation
 // choices were: the result is the truncated solve of a matrix within O(eps ||A||) of A, like gelsd's.
 // mvf_pinv_diag evaluates diag(U pinv(A) U^T) from the Y either of the two Jacobi solvers left behind.
+#include <cstring>
 #include "mvf_common.h"
 #include "mvf_solve.h"
 #include "mvf_chol_dev.h"
 
 namespace mvf {
+
+// ---- small device -> host status reads through pinned staging -------------------------------------------------------------
+// A status read into pageable memory costs a round trip PER COPY (tools/readback_probe.hip on this part: kernel + 2 pageable
+// hipMemcpyAsync + synchronise 40 us, the same through pinned memory 22 us, kernel + synchronise alone 18.5 us); the factor form
+// at M = 3000 makes about ten such reads per solve.  rb_copy stages a copy in a per-thread pinned page, rb_sync synchronises
+// the stream once and hands the bytes to their destinations.  (The page is never freed: 8 KB per OS thread that ever ran a
+// solve; freeing it from a thread-exit destructor would race the runtime's own shutdown.)
+namespace {
+struct Readback {
+    char* pin = nullptr;
+    bool tried = false;
+    size_t off = 0;
+    int np = 0;
+    struct { void* dst; size_t off, n; } pend[16];
+};
+thread_local Readback g_rb;
+
+hipError_t rb_copy(hipStream_t st, void* dst, const void* src, size_t n) {
+    Readback& rb = g_rb;
+    if (!rb.tried) {
+        rb.tried = true;
+        if (hipHostMalloc((void**)&rb.pin, 8192, hipHostMallocPortable) != hipSuccess) {
+            rb.pin = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    if (!rb.pin || rb.np == 16 || rb.off + n > 8192) return hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, st);
+    const hipError_t e = hipMemcpyAsync(rb.pin + rb.off, src, n, hipMemcpyDeviceToHost, st);
+    rb.pend[rb.np].dst = dst, rb.pend[rb.np].off = rb.off, rb.pend[rb.np].n = n;
+    ++rb.np;
+    rb.off += (n + 63) & ~(size_t)63;
+    return e;
+}
+
+hipError_t rb_sync(hipStream_t st) {
+    Readback& rb = g_rb;
+    const hipError_t e = hipStreamSynchronize(st);
+    for (int i = 0; i < rb.np; ++i) memcpy(rb.pend[i].dst, rb.pin + rb.pend[i].off, rb.pend[i].n);
+    rb.np = 0;
+    rb.off = 0;
+    return e;
+}
+}  // namespace
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -1941,8 +1985,8 @@ extern "C" int mvf_solve_minnorm(const double* G, const double* K, double lambda
         return rc;
     }
     int hinfo = 0;
-    MVF_CHECK_HIP(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, st));
-    MVF_CHECK_HIP(hipStreamSynchronize(st));
+    MVF_CHECK_HIP(rb_copy(st, &hinfo, info, sizeof(int)));
+    MVF_CHECK_HIP(rb_sync(st));
     if (hinfo != 0) return 0;  // shift too small for this matrix: info[0] tells the caller, who escalates it
     MVF_REQUIRE(cp.mp == p.mp, "mvf_solve_minnorm: internal padding mismatch");
 
@@ -1972,8 +2016,8 @@ extern "C" int mvf_solve_minnorm(const double* G, const double* K, double lambda
         }
         MVF_LAUNCH_CHECK();
         ++sweeps;
-        MVF_CHECK_HIP(hipMemcpyAsync(&hrot, rot, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-        MVF_CHECK_HIP(hipStreamSynchronize(st));
+        MVF_CHECK_HIP(rb_copy(st, &hrot, rot, sizeof(unsigned int)));
+        MVF_CHECK_HIP(rb_sync(st));
         if (hrot == 0) break;
     }
 
@@ -1997,7 +2041,7 @@ extern "C" int mvf_solve_minnorm(const double* G, const double* K, double lambda
     MVF_LAUNCH_CHECK();
     const double hs[1] = {(double)sweeps + (hrot != 0 ? 0.5 : 0.0)};  // x.5 = sweep cap hit before convergence
     MVF_CHECK_HIP(hipMemcpyAsync(einfo, hs, sizeof(double), hipMemcpyHostToDevice, st));
-    MVF_CHECK_HIP(hipStreamSynchronize(st));
+    MVF_CHECK_HIP(rb_sync(st));
     return 0;
 }
 
@@ -2134,8 +2178,8 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
 
     if (reuse) {
         // the workspace still holds the decomposition of the previous call for this matrix
-        MVF_CHECK_HIP(hipMemcpyAsync(&hs, stt, sizeof(hs), hipMemcpyDeviceToHost, st));
-        MVF_CHECK_HIP(hipStreamSynchronize(st));
+        MVF_CHECK_HIP(rb_copy(st, &hs, stt, sizeof(hs)));
+        MVF_CHECK_HIP(rb_sync(st));
         MVF_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
         if (hs.r <= 0) {
             MVF_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)m * nrhs * sizeof(double), st));
@@ -2197,8 +2241,8 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         bool prev_direct = form_hint == 2 && debug_opt(DBG_DEFL_APPS) == 0;
         if (!nosync) {
             PcholState hprev;
-            MVF_CHECK_HIP(hipMemcpyAsync(&hprev, stt, sizeof(hprev), hipMemcpyDeviceToHost, st));
-            MVF_CHECK_HIP(hipStreamSynchronize(st));
+            MVF_CHECK_HIP(rb_copy(st, &hprev, stt, sizeof(hprev)));
+            MVF_CHECK_HIP(rb_sync(st));
             if (!(hprev.magic == PCHOL_MAGIC && hprev.order_len == (int)m)) {
                 if (timing)
                     for (auto& e : ev) (void)hipEventDestroy(e);
@@ -2208,7 +2252,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             if (hprev.direct_skip > 0 && hprev.direct_skip <= 4) {  // a recent attempt of this form failed: not again just yet
                 const int left[1] = {hprev.direct_skip - 1};
                 MVF_CHECK_HIP(hipMemcpyAsync(&stt->direct_skip, left, sizeof(left), hipMemcpyHostToDevice, st));
-                MVF_CHECK_HIP(hipStreamSynchronize(st));
+                MVF_CHECK_HIP(rb_sync(st));
                 if (timing)
                     for (auto& e : ev) (void)hipEventDestroy(e);
                 return lr_solve(G, K, lambda_sigma2, tolf, rcond, R, m, nrhs, C, info, einfo, max_sweeps, reuse, rank_hint, workspace,
@@ -2282,8 +2326,8 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             MVF_LAUNCH_CHECK();
             ++hsweeps;
             if (nosync) break;  // (its convergence - rot[0] == 0 - is part of the device-side acceptance test)
-            MVF_CHECK_HIP(hipMemcpyAsync(&hrot2, rot, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-            MVF_CHECK_HIP(hipStreamSynchronize(st));
+            MVF_CHECK_HIP(rb_copy(st, &hrot2, rot, sizeof(unsigned int)));
+            MVF_CHECK_HIP(rb_sync(st));
             if (hrot2 == 0) break;
         }
         hipLaunchKernelGGL(jac_rowstat_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, Yh, (int64_t)b, (int64_t)b, (int64_t)b,
@@ -2306,8 +2350,8 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         double* rep = (double*)(ws + p.off_scal) + 16;  // 11 doubles of the 256-byte scalar slot (its first two are the shift's)
         hipLaunchKernelGGL(direct_report_kernel, dim3(1), dim3(64), 0, st, einfo, info, dflag, stt, rep);
         double hrep[11];
-        MVF_CHECK_HIP(hipMemcpyAsync(hrep, rep, sizeof(hrep), hipMemcpyDeviceToHost, st));
-        MVF_CHECK_HIP(hipStreamSynchronize(st));
+        MVF_CHECK_HIP(rb_copy(st, hrep, rep, sizeof(hrep)));
+        MVF_CHECK_HIP(rb_sync(st));
         const double* he = hrep;
         const int hinfo2 = (int)hrep[6], hflag = (int)hrep[7];
         const double q_est = hrep[8], q_prev = hrep[9], q_maxdiag = hrep[10];
@@ -2345,7 +2389,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         {
             const int skip[1] = {4};
             MVF_CHECK_HIP(hipMemcpyAsync(&stt->direct_skip, skip, sizeof(skip), hipMemcpyHostToDevice, st));
-            MVF_CHECK_HIP(hipStreamSynchronize(st));
+            MVF_CHECK_HIP(rb_sync(st));
         }
         return lr_solve(G, K, lambda_sigma2, tolf, rcond, R, m, nrhs, C, info, einfo, max_sweeps, reuse, rank_hint, workspace,
                         workspace_bytes, stream, deflate, false);
@@ -2374,9 +2418,9 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             hipLaunchKernelGGL(pchol_update_kernel, ugrid, dim3(256), 0, st, S, Y, mp, 64 * b, stt, b + 1);
         }
         MVF_LAUNCH_CHECK();
-        MVF_CHECK_HIP(hipMemcpyAsync(&hs, stt, sizeof(hs), hipMemcpyDeviceToHost, st));
-        MVF_CHECK_HIP(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, st));
-        MVF_CHECK_HIP(hipStreamSynchronize(st));
+        MVF_CHECK_HIP(rb_copy(st, &hs, stt, sizeof(hs)));
+        MVF_CHECK_HIP(rb_copy(st, &hinfo, info, sizeof(int)));
+        MVF_CHECK_HIP(rb_sync(st));
         if (hinfo != 0) return 0;
         j = hs.r;  // pivots taken from the hint (the last accepted panel may be partial: its rows behind are zero and
                    // already applied to S, the greedy steps overwrite them)
@@ -2406,9 +2450,9 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
     while (!finished) {
         enqueue(upto);
         MVF_LAUNCH_CHECK();
-        MVF_CHECK_HIP(hipMemcpyAsync(&hs, stt, sizeof(hs), hipMemcpyDeviceToHost, st));
-        MVF_CHECK_HIP(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, st));
-        MVF_CHECK_HIP(hipStreamSynchronize(st));
+        MVF_CHECK_HIP(rb_copy(st, &hs, stt, sizeof(hs)));
+        MVF_CHECK_HIP(rb_copy(st, &hinfo, info, sizeof(int)));
+        MVF_CHECK_HIP(rb_sync(st));
         if (hinfo != 0) return 0;  // non-finite input: info[0] tells the caller
         if (hs.done || j >= msteps) break;
         upto = std::min(msteps, upto + (tail_only ? 16 : 128));
@@ -2425,7 +2469,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         MVF_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)m * nrhs * sizeof(double), st));
         MVF_CHECK_HIP(hipMemsetAsync(einfo, 0, 6 * sizeof(double), st));
         if (deflate) MVF_CHECK_HIP(hipMemsetAsync(einfo + 7, 0, 3 * sizeof(double), st));  // no block ran
-        MVF_CHECK_HIP(hipStreamSynchronize(st));
+        MVF_CHECK_HIP(rb_sync(st));
         return 0;
     }
     const int64_t rp = cdiv(r, 64) * 64;
@@ -2455,13 +2499,13 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
                     hipLaunchKernelGGL(lr_power_kernel, dim3(1), dim3(256), 0, st, xv, xv + mp, r, rp, 0, stt);
                 }
                 MVF_LAUNCH_CHECK();
-                MVF_CHECK_HIP(hipMemcpyAsync(&h2, stt, sizeof(h2), hipMemcpyDeviceToHost, st));
-                MVF_CHECK_HIP(hipStreamSynchronize(st));
+                MVF_CHECK_HIP(rb_copy(st, &h2, stt, sizeof(h2)));
+                MVF_CHECK_HIP(rb_sync(st));
                 if (std::fabs(h2.lmax_est - h2.lmax_prev) <= 1e-7 * h2.lmax_est) break;
             }
             const double best[1] = {std::max(before, h2.lmax_est)};  // both are lower bounds of lambda_max
             MVF_CHECK_HIP(hipMemcpyAsync(&stt->lmax_est, best, sizeof(best), hipMemcpyHostToDevice, st));
-            MVF_CHECK_HIP(hipStreamSynchronize(st));
+            MVF_CHECK_HIP(rb_sync(st));
         }
         CholPlan cs, cq;
         if (int rc = chol_factor_mat_inv(st, S2, rp, r, dw + d.cw, &cs, info, 1)) return rc;
@@ -2528,8 +2572,8 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
                     }
                 MVF_LAUNCH_CHECK();
                 unsigned int hb[16];
-                MVF_CHECK_HIP(hipMemcpyAsync(hb, rot, sizeof(hb), hipMemcpyDeviceToHost, st));
-                MVF_CHECK_HIP(hipStreamSynchronize(st));
+                MVF_CHECK_HIP(rb_copy(st, hb, rot, sizeof(hb)));
+                MVF_CHECK_HIP(rb_sync(st));
                 int done_at = -1;
                 for (int sb = 0; sb < batch && done_at < 0; ++sb)
                     if (hb[sb] == 0) done_at = sb;
@@ -2579,9 +2623,9 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             if (int rc = attempt(napp)) return rc;
             if (timing) MVF_CHECK_HIP(hipEventRecord(ev[2], st));
             if (int rc = defl_apply(rp, b)) return rc;
-            MVF_CHECK_HIP(hipMemcpyAsync(he, einfo, sizeof(he), hipMemcpyDeviceToHost, st));
-            MVF_CHECK_HIP(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, st));
-            MVF_CHECK_HIP(hipStreamSynchronize(st));
+            MVF_CHECK_HIP(rb_copy(st, he, einfo, sizeof(he)));
+            MVF_CHECK_HIP(rb_copy(st, &hinfo, info, sizeof(int)));
+            MVF_CHECK_HIP(rb_sync(st));
             ok = hinfo == 0 && hrot2 == 0 && he[4] <= (double)accept && std::isfinite(he[5]) && he[5] > 0.0;
             if (hinfo != 0) break;  // a factorisation met a non-positive pivot: the larger block would meet it too
         }
@@ -2602,7 +2646,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             MVF_CHECK_HIP(hipMemcpyAsync(einfo, hsw, sizeof(hsw), hipMemcpyHostToDevice, st));
             const double hblk[3] = {(double)b, 1.0, 0.0};  // einfo[7] = the block size used (0: the Jacobi path answered),
             MVF_CHECK_HIP(hipMemcpyAsync(einfo + 7, hblk, sizeof(hblk), hipMemcpyHostToDevice, st));  // [8] = the form, [9] = 0
-            MVF_CHECK_HIP(hipStreamSynchronize(st));
+            MVF_CHECK_HIP(rb_sync(st));
             if (timing)
                 for (auto& e : ev) (void)hipEventDestroy(e);
             return 0;
@@ -2641,8 +2685,8 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             }
         MVF_LAUNCH_CHECK();
         unsigned int hb[8];
-        MVF_CHECK_HIP(hipMemcpyAsync(hb, rot, sizeof(hb), hipMemcpyDeviceToHost, st));
-        MVF_CHECK_HIP(hipStreamSynchronize(st));
+        MVF_CHECK_HIP(rb_copy(st, hb, rot, sizeof(hb)));
+        MVF_CHECK_HIP(rb_sync(st));
         int done_at = -1;
         for (int sb = 0; sb < batch && done_at < 0; ++sb)
             if (hb[sb] == 0) done_at = sb;
@@ -2678,7 +2722,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
     // mvf_solve_minnorm_lrd answered by this path (small factor, launch-grid limit, lr_no_deflate, a failed attempt):
     // einfo[7] = 0, the block size of a deflated solve that did not run (mvf.h)
     if (deflate) MVF_CHECK_HIP(hipMemsetAsync(einfo + 7, 0, 3 * sizeof(double), st));  // block, form, repeat flag
-    MVF_CHECK_HIP(hipStreamSynchronize(st));
+    MVF_CHECK_HIP(rb_sync(st));
     return 0;
 }
 
@@ -2725,13 +2769,13 @@ extern "C" int mvf_lr_pivot_order(const void* workspace, size_t workspace_bytes,
     hipStream_t st = (hipStream_t)stream;
     const char* ws = (const char*)workspace;
     PcholState hs;
-    MVF_CHECK_HIP(hipMemcpyAsync(&hs, ws + p.off_state, sizeof(hs), hipMemcpyDeviceToHost, st));
-    MVF_CHECK_HIP(hipStreamSynchronize(st));
+    MVF_CHECK_HIP(rb_copy(st, &hs, ws + p.off_state, sizeof(hs)));
+    MVF_CHECK_HIP(rb_sync(st));
     MVF_REQUIRE(hs.magic == PCHOL_MAGIC && hs.r >= 0 && hs.r <= m, "mvf_lr_pivot_order: the workspace holds no finished factorisation");
     MVF_CHECK_HIP(hipMemcpyAsync(order_out, ws + p.off_order, (size_t)hs.r * sizeof(int), hipMemcpyDeviceToHost, st));
     if (pivots_out)
         MVF_CHECK_HIP(hipMemcpyAsync(pivots_out, ws + p.off_piv, (size_t)hs.r * sizeof(double), hipMemcpyDeviceToHost, st));
-    MVF_CHECK_HIP(hipStreamSynchronize(st));
+    MVF_CHECK_HIP(rb_sync(st));
     if (tol_out) *tol_out = hs.tol;
     *r_out = hs.r;
     return 0;
@@ -2754,8 +2798,8 @@ extern "C" int mvf_pinv_diag(const void* x4, int64_t n, const void* ctrl4, int64
         const LrPlan p = lr_plan(m);
         MVF_REQUIRE(workspace_bytes >= p.total, "mvf_pinv_diag: not the workspace of mvf_solve_minnorm_lr for this m");
         PcholState hs;
-        MVF_CHECK_HIP(hipMemcpyAsync(&hs, ws + p.off_state, sizeof(hs), hipMemcpyDeviceToHost, st));
-        MVF_CHECK_HIP(hipStreamSynchronize(st));
+        MVF_CHECK_HIP(rb_copy(st, &hs, ws + p.off_state, sizeof(hs)));
+        MVF_CHECK_HIP(rb_sync(st));
         MVF_REQUIRE(hs.magic == PCHOL_MAGIC && hs.r >= 0 && hs.r <= m, "mvf_pinv_diag: the workspace holds no finished decomposition");
         MVF_REQUIRE(!hs.defl, "mvf_pinv_diag: the workspace holds a deflated decomposition (mvf_solve_minnorm_lrd); run mvf_solve_minnorm_lr");
         mp = p.mp;
