@@ -54,6 +54,9 @@ enum {
 /* ---- library ------------------------------------------------------------------------------------------------ */
 const char* mvf_last_error(void);
 int mvf_version(void);                 /* ABI version, currently 7 */
+/* mvf_read_back (ABI 7): blocking device -> host copy of a small status block on `stream` (everything enqueued on the stream
+ * before it is complete when it returns) - the one host read of an EM iteration (statistics, solver status, sum P r). */
+int mvf_read_back(void* dst_host, const void* src_device, size_t nbytes, void* stream);
 /* Developer options, process-wide: which kernel variant / launch plan is taken in A/B measurements and in the tests that
  * compare the variants bit for bit.  The library NEVER reads the environment (rounds 1 - 3 had getenv knobs in launch
  * paths); nothing but this call changes its behaviour.  value 0 = default.  Nine names (round 6 removed four that no test

@@ -11,6 +11,7 @@ import torch
 from . import _lib
 
 _DT = {"float32": (torch.float32, _lib.MVF_F32), "float64": (torch.float64, _lib.MVF_F64)}
+_NP = {torch.float64: np.float64, torch.float32: np.float32, torch.int32: np.int32, torch.int64: np.int64}
 
 
 def _ptr(t):
@@ -231,6 +232,12 @@ class HipKernels:
                                         float(minP), float(theta), 0.0 if fill_dev is not None else float(zero_fill),
                                         _ptr(fill_dev), _ptr(P_out), _ptr(stats),
                                         self._red(r.shape[0]), self.cdtype, self._stream()), "mvf_estep_p")
+
+    def read_host(self, t):
+        """A contiguous device tensor as a host NumPy array, through ONE blocking copy on the current stream."""
+        out = np.empty(t.shape, dtype=_NP[t.dtype])
+        _lib.check(self.lib.mvf_read_back(out.ctypes.data, _ptr(t), out.nbytes, self._stream()), "mvf_read_back")
+        return out
 
     @_on_device
     def estep(self, r, sigma2, gamma, a, dy, minP, theta, P_out, stats):

@@ -37,6 +37,7 @@ _p, _i64, _i, _d, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_size_t
 SIGNATURES = {
     "mvf_last_error": (C.c_char_p, []),
     "mvf_version": (_i, []),
+    "mvf_read_back": (_i, [_p, _p, C.c_size_t, _p]),
     "mvf_debug_option": (_i, [C.c_char_p, C.c_longlong]),
     "mvf_debug_option_get": (C.c_longlong, [C.c_char_p]),
     "mvf_device_count": (_i, [C.POINTER(C.c_int)]),
