@@ -1111,6 +1111,147 @@ __global__ __launch_bounds__(PC_T) void pchol_step_kernel(const double* __restri
     }
 }
 
+// ---- pivot steps of a 32-row sub-block in ONE launch by ONE workgroup (mp <= 512 columns: thread i owns column i) ----------
+// A pivot step launched on its own costs ~8 us whatever its size, so the cold factorisation of a fit's FIRST EM iteration (no pivot
+// order to follow yet) was m dependent launches: 4.3 ms at m = 500, a quarter of a whole BASELINE config 2 call.  Cycle counters in
+// a first single-workgroup version (same loop, one launch per 64 steps: 3.98 ms) showed that it is NOT launch latency: per step
+// 3200 cycles of shuffle-based argmax, 230 cycles per earlier row of dependent global loads (the step re-reads the block's rows it
+// needs: 9300 at row 40), 3900 of IEEE sqrt / divide, the row's store and a barrier that waits for it.  What this kernel does instead:
+//   * the rows of the current 32-row sub-block live in LDS (128 KB) - a step reads them from there, this column's entry and the
+//     pivot column's (a broadcast); the rows go to global memory as well, but nothing waits for those stores: the barriers of a
+//     step order LDS traffic only;
+//   * the other half of a 64-row block (32 older rows): this column's entries once per launch into registers, the pivot column's
+//     through LDS from one load instruction of the first wave - issued together with the pivot's row of S, the one global round
+//     trip of a step;
+//   * argmax by DPP row operations + a ballot (value first, then the lowest lane that holds it) instead of 12 dependent
+//     ds_bpermute per wave.
+// The arithmetic per column is pchol_step_kernel's, statement by statement and in the same order (rows ascending): same pivots,
+// same rows, same bits.
+constexpr int PS_T = 512;    // threads = columns
+constexpr int PS_SUB = 32;   // rows per launch / LDS-resident sub-block
+constexpr size_t PS_LDS = ((size_t)PS_SUB * PS_T + PS_SUB + 16) * sizeof(double) + 16 * sizeof(int);
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)(b & 0xffffffffLL), (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(b >> 32), (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// max over the wave, returned in every lane (through lane 63 and a scalar broadcast)
+__device__ __forceinline__ double wave_max_dpp(double v) {
+    v = fmax(v, dpp_f64<0xB1, 0xf>(v));   // quad_perm [1, 0, 3, 2]
+    v = fmax(v, dpp_f64<0x4E, 0xf>(v));   // quad_perm [2, 3, 0, 1]
+    v = fmax(v, dpp_f64<0x124, 0xf>(v));  // row_ror 4
+    v = fmax(v, dpp_f64<0x128, 0xf>(v));  // row_ror 8: every lane holds its row's maximum
+    v = fmax(v, dpp_f64<0x142, 0xa>(v));  // row_bcast 15 into rows 1 and 3
+    v = fmax(v, dpp_f64<0x143, 0xc>(v));  // row_bcast 31 into rows 2 and 3: lane 63 holds the wave's
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// workgroup barrier that orders LDS traffic only (a __syncthreads() also waits for the row's global stores)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(PS_T) void pchol_steps_kernel(const double* __restrict__ S, double* __restrict__ Y, int64_t mp, int jb,
+                                                            int sb, int j0, int nsteps, double* __restrict__ dg,
+                                                            PcholState* __restrict__ stt, int* __restrict__ order,
+                                                            double* __restrict__ piv) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ps_smem[];
+    if (stt->done) return;
+    double* Yl = reinterpret_cast<double*>(ps_smem);  // [PS_SUB][PS_T]: rows sb .. of the block
+    double* hp = Yl + (size_t)PS_SUB * PS_T;          // [PS_SUB]: the pivot column's entries of the rows jb .. sb - 1
+    double* sv = hp + PS_SUB;                          // [8] wave maxima
+    int* si = reinterpret_cast<int*>(sv + 16);         // [8] their columns
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i = tid;
+    const bool live = i < mp;
+    const int64_t ic = live ? i : 0;
+    double di = live ? dg[i] : -INFINITY;
+    const double tol = stt->tol;
+    const int nold = sb - jb;  // rows of the block that are NOT LDS resident: 0 or PS_SUB
+    double aold[PS_SUB];
+#pragma unroll
+    for (int u = 0; u < PS_SUB; ++u) aold[u] = (u < nold) ? Y[(int64_t)(jb + u) * mp + ic] : 0.0;
+    for (int k = sb; k < j0; ++k) Yl[(k - sb) * PS_T + tid] = Y[(int64_t)k * mp + ic];  // (a launch that continues a sub-block)
+    lds_barrier();
+    int j = j0;
+    for (int s = 0; s < nsteps; ++s) {
+        // ---- p = argmax of the remaining diagonal, ties to the lowest column
+        const double wm = wave_max_dpp(di);
+        const unsigned long long hit = __ballot(di == wm);
+        if (lane == 0) {
+            sv[wave] = wm;
+            si[wave] = wave * 64 + (int)__ffsll((long long)hit) - 1;
+        }
+        lds_barrier();
+        double bv = sv[0];
+        int bi = si[0];
+#pragma unroll
+        for (int w = 1; w < PS_T / 64; ++w)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) {
+                bv = sv[w];
+                bi = si[w];
+            }
+        if (!(bv > tol)) {  // uniform over the workgroup
+            if (tid == 0) stt->done = 1;
+            break;
+        }
+        const int64_t p = bi;
+        // ---- the step's one global round trip: the pivot's row of S and (second half of a block) its column of the old rows
+        if (wave == 0 && lane < nold) hp[lane] = Y[(int64_t)(jb + lane) * mp + p];
+        double acc = S[p * mp + ic], accp = S[p * mp + p];
+        const int cnt = j - sb;  // LDS-resident rows so far
+        if (nold != 0) {
+            lds_barrier();  // hp complete
+#pragma unroll
+            for (int u = 0; u < PS_SUB; ++u) {
+                const double p0 = hp[u];
+                acc = fma(-aold[u], p0, acc);
+                accp = fma(-p0, p0, accp);
+            }
+        }
+        {
+            const double* yc = Yl + tid;
+            const double* yp = Yl + p;
+            int k = 0;
+            for (; k + 4 <= cnt; k += 4) {
+                const double p0 = yp[k * PS_T], p1 = yp[(k + 1) * PS_T], p2 = yp[(k + 2) * PS_T], p3 = yp[(k + 3) * PS_T];
+                const double a0 = yc[k * PS_T], a1 = yc[(k + 1) * PS_T], a2 = yc[(k + 2) * PS_T], a3 = yc[(k + 3) * PS_T];
+                acc = fma(-a0, p0, acc);
+                accp = fma(-p0, p0, accp);
+                acc = fma(-a1, p1, acc);
+                accp = fma(-p1, p1, accp);
+                acc = fma(-a2, p2, acc);
+                accp = fma(-p2, p2, accp);
+                acc = fma(-a3, p3, acc);
+                accp = fma(-p3, p3, accp);
+            }
+            for (; k < cnt; ++k) {
+                const double p0 = yp[k * PS_T], a0 = yc[k * PS_T];
+                acc = fma(-a0, p0, acc);
+                accp = fma(-p0, p0, accp);
+            }
+        }
+        const bool used = !live || di == -INFINITY;
+        const bool badp = !(accp > 0.25 * tol);  // a pivot the fresh evaluation does not confirm: retired with an all-zero row
+        const double inv = badp ? 0.0 : 1.0 / sqrt(accp);
+        const double y = (used || badp) ? 0.0 : acc * inv;
+        Yl[cnt * PS_T + tid] = y;
+        if (live) Y[(int64_t)j * mp + i] = y;
+        di = (used || i == p) ? -INFINITY : di - y * y;
+        if (tid == 0) {
+            order[j] = (int)p;
+            piv[j] = accp;
+        }
+        ++j;
+        lds_barrier();  // row j is in LDS for the next step; sv / si / hp are free
+    }
+    if (live) dg[i] = di;
+    if (tid == 0) stt->r = j;
+}
+
 // trailing update after a block of 64 pivot steps:  S -= Yb^T Yb,  Yb = rows jb .. jb + 63 of Y (64 x 64 tile per
 // workgroup, f64 MFMA, both operand tiles staged k-major in LDS)
 __global__ __launch_bounds__(256) void pchol_update_kernel(double* __restrict__ S, const double* __restrict__ Y,
@@ -2427,13 +2568,27 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         finished = hs.done || j >= msteps;
     }
     int jbase = j;  // first row not yet applied to S by a trailing update
+    // up to 512 columns: the steps of a 32-row sub-block in ONE single-workgroup launch (pchol_steps_kernel), the whole rest of the
+    // factorisation enqueued at once - launches behind the end of the factorisation return at their first instruction.  (A device
+    // that refuses 129 KB of dynamic LDS keeps the one-launch-per-step form.)
+    const bool one_wg = mp <= PS_T && hipFuncSetAttribute(reinterpret_cast<const void*>(pchol_steps_kernel),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)PS_LDS) == hipSuccess;
+    if (!one_wg) (void)hipGetLastError();
     auto enqueue = [&](int upto) {
         while (j < upto) {
-            hipLaunchKernelGGL(pchol_step_kernel, dim3((unsigned)p.nwg), dim3(PC_T), 0, st, S, Y, mp, jbase, j,
-                               dg + (size_t)cur * mp, dg + (size_t)(cur ^ 1) * mp, pm + (size_t)cur * 2 * p.nwg,
-                               pm + (size_t)(cur ^ 1) * 2 * p.nwg, p.nwg, stt, order, piv);
-            cur ^= 1;
-            ++j;
+            if (one_wg) {
+                const int sb = jbase + ((j - jbase) / PS_SUB) * PS_SUB;
+                const int n = std::min(upto - j, sb + PS_SUB - j);
+                hipLaunchKernelGGL(pchol_steps_kernel, dim3(1), dim3(PS_T), PS_LDS, st, S, Y, mp, jbase, sb, j, n,
+                                   dg + (size_t)cur * mp, stt, order, piv);
+                j += n;
+            } else {
+                hipLaunchKernelGGL(pchol_step_kernel, dim3((unsigned)p.nwg), dim3(PC_T), 0, st, S, Y, mp, jbase, j,
+                                   dg + (size_t)cur * mp, dg + (size_t)(cur ^ 1) * mp, pm + (size_t)cur * 2 * p.nwg,
+                                   pm + (size_t)(cur ^ 1) * 2 * p.nwg, p.nwg, stt, order, piv);
+                cur ^= 1;
+                ++j;
+            }
             if (j - jbase == 64 && j < msteps) {
                 hipLaunchKernelGGL(pchol_update_kernel, ugrid, dim3(256), 0, st, S, Y, mp, jbase, stt, -1);
                 jbase = j;
@@ -2446,7 +2601,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
     // (behind the hint panels the previous call's rank says how long the greedy tail will be: every enqueued step costs the
     // host ~8 us whether it still has a pivot to take or not - a fixed batch of 32 was 250 us of launches for ~10 pivots)
     const int tail_first = std::max(8, std::min(32, rank_hint - j + 8));
-    int upto = tail_only ? std::min(msteps, j + tail_first) : std::min(msteps, 256);
+    int upto = one_wg ? msteps : (tail_only ? std::min(msteps, j + tail_first) : std::min(msteps, 256));
     while (!finished) {
         enqueue(upto);
         MVF_LAUNCH_CHECK();
