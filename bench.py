@@ -126,6 +126,41 @@ def measured_traffic(cells, ctrl, dtype, lambda_, timeout_s=150):
                       "the bytes of wide streaming reads are tallied), summed over the tile-stage launches of one EM iteration"}
 
 
+def _cpu_budget():
+    """CPUs this process may actually use: the scheduler affinity capped by the container's CFS quota (cgroup v2 cpu.max, v1
+    cpu.cfs_quota_us).  The GPU boxes of this pool report 256 CPUs and hold a quota of 16: thread pools sized by the CPU count
+    (128 BLAS / torch threads) exhaust it within a scheduler period and the whole process is throttled for the rest of it."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = float(fq.read()), float(fp.read())
+                if q > 0:
+                    quota = q / per
+        except Exception:
+            quota = None
+    return n, quota, max(1, min(n, int(quota)) if quota else n)
+
+
+def _throttle_stats():
+    try:
+        with open("/sys/fs/cgroup/cpu.stat") as fh:
+            d = dict(line.split() for line in fh.read().strip().splitlines())
+        return {"nr_periods": int(d.get("nr_periods", 0)), "nr_throttled": int(d.get("nr_throttled", 0)),
+                "throttled_s": int(d.get("throttled_usec", 0)) / 1e6}
+    except Exception:
+        return None
+
+
 def _eigh_solver(lhs, rhs, method=None):
     """The reference's solve with its LAPACK driver swapped for a mathematically identical one (truncated symmetric
     eigendecomposition, same eps * max|lambda| cut-off as gelsd): oracle-vs-oracle deviation = the reference noise floor."""
@@ -206,6 +241,7 @@ def cpu_baseline(M, lambda_, n_cpu, n_target, steps=3):
         "unit": "cells/s",
         "cores": int(threads),
         "host_cpus": os.cpu_count(),
+        "cfs_quota_cpus": _cpu_budget()[1],
         "kind": "port",
         "sample": f"float64 NumPy oracle (cdist+exp con_K, U.T*repmat(P) temporary, scipy.linalg.lstsq), C4 generator at "
                   f"N_cpu={N} and {Nh} cells, M={Mc}, median of {steps} / {max(steps, PARITY_STEPS)} EM steps "
@@ -313,6 +349,19 @@ def main():
 
     import torch
     import torch.distributed as dist
+
+    # host thread pools sized to what the container grants (see _cpu_budget): BLAS through threadpoolctl, torch's intra-op pool
+    n_aff, cpu_quota, cpu_use = _cpu_budget()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu_use = max(1, cpu_use // max(1, world_env))  # one process per GPU shares the quota
+    try:
+        from threadpoolctl import threadpool_limits
+
+        _blas_limit = threadpool_limits(limits=cpu_use)  # (kept alive for the life of the process)
+    except Exception:
+        _blas_limit = None
+    torch.set_num_threads(cpu_use)
+    throttle0 = _throttle_stats()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -684,6 +733,8 @@ def main():
         # developer knobs of libmvf / the host that change which kernel variant runs: none set = defaults
         "env": {k_: v_ for k_, v_ in sorted(os.environ.items()) if k_.startswith("MVF_")},
         "developer_options": __import__("spateo_amd")._lib.debug_options(),   # mvf_debug_option values != default
+        # what the container grants the host side: thread pools (BLAS, torch) are sized to it, and the CPU baseline runs on it
+        "host": {"cpus_visible": n_aff, "cfs_quota_cpus": cpu_quota, "threads_used": cpu_use, "throttle_at_start": throttle0},
     }
     if "comm" in main_rec and not distributed:
         out["per_rank"], out["comm"] = main_rec["per_rank"], main_rec["comm"]
@@ -981,6 +1032,7 @@ def main():
         dist.barrier()
     sys.stdout.flush()
     if rank == 0:  # the line goes out BEFORE the process group is torn down: a hang in the teardown cannot lose it
+        out["host"]["throttle_at_end"] = _throttle_stats()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     os.close(real_stdout)
     if dist.is_initialized():

@@ -80,6 +80,24 @@ class HipKernels:
     # leave hundreds of MB of the host page-locked for the life of the process
     PINNED_MAX_BYTES = 128 << 20
 
+    def h2d(self, a, tdtype=None):
+        """Host array -> device tensor (optionally cast) THROUGH page-locked staging.  Never `torch.from_numpy(a).to(device)`:
+        a copy from a pageable range the runtime has not seen before costs 18 - 28 ms on this stack whatever its size (a
+        500 x 3 array: 28 ms; measured with the caller keeping its results, i.e. every array of the next call at a fresh
+        address - a second `SparseVFC` call cost 60 ms instead of 26).  Arrays above PINNED_MAX_BYTES keep the pageable path:
+        at their size the fixed cost does not matter."""
+        a = np.ascontiguousarray(a)
+        t = torch.from_numpy(a)
+        dt = tdtype or t.dtype
+        if 0 < t.numel() * t.element_size() <= self.PINNED_MAX_BYTES:
+            host = torch.empty(t.shape, dtype=dt, pin_memory=True)
+            # (NumPy's single-threaded copy / cast, not torch's: a torch CPU op fans out over every core it sees - 128 threads on
+            # the test boxes, whose containers hold a 16-CPU quota - and the spinning pool gets the whole process throttled for
+            # the rest of the scheduler period: 50 - 90 ms stalls every few calls, `nr_throttled` in /sys/fs/cgroup/cpu.stat)
+            np.copyto(host.numpy(), a, casting="unsafe")
+            return host.to(self.device, non_blocking=True)
+        return t.to(self.device) if dt == t.dtype else t.to(self.device).to(dt)
+
     def h2d_padded(self, a, width, tdtype, minus=None):
         """Host (n, d <= width) float64 array -> device (n, width) tensor of `tdtype`, zero padded.  minus (1 x d float64, may
         be None): subtracted in float64 on the way - the difference is rounded to `tdtype` as it is written into the staging
@@ -102,11 +120,21 @@ class HipKernels:
         fill(buf)
         return torch.from_numpy(buf).to(self.device)
 
+    def d2h(self, t):
+        """Device tensor -> ordinary (pageable) host NumPy array, THROUGH page-locked staging: the runtime never sees the
+        destination.  A `.cpu()` into a pageable range it has not seen before stalls for 50 - 100 ms every few calls on this
+        stack (and so does the unmapping of such a range when the caller drops the array): 6 MB of unique rows cost 1.4 ms
+        or 90 (tools/kept_results_probe.py)."""
+        if not t.is_cuda:
+            return t.numpy()
+        return self.to_host([t], own_pinned=False)[0]
+
     @_on_device
-    def to_host(self, tensors):
+    def to_host(self, tensors, own_pinned=True):
         """Device tensors -> host NumPy arrays with ONE stream synchronisation: page-locked destinations while the total
-        stays under PINNED_MAX_BYTES (the arrays returned then own their pinned block until they are garbage collected),
-        otherwise pageable arrays filled through two page-locked 32 MB staging buffers."""
+        stays under PINNED_MAX_BYTES (own_pinned: the arrays returned own their pinned block until they are garbage
+        collected; else they are pageable copies of it and the block goes back to torch's host cache), otherwise pageable
+        arrays filled through two page-locked 32 MB staging buffers."""
         tensors = [t.contiguous() for t in tensors]
         total = sum(t.numel() * t.element_size() for t in tensors)
         stream = torch.cuda.current_stream(self.device)
@@ -115,7 +143,7 @@ class HipKernels:
             for h, t in zip(hosts, tensors):
                 h.copy_(t, non_blocking=True)
             stream.synchronize()
-            return [h.numpy() for h in hosts]
+            return [h.numpy() if own_pinned else h.numpy().copy() for h in hosts]
         outs = []
         chunk = 32 << 20
         stage = [torch.empty(chunk, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
@@ -163,7 +191,7 @@ class HipKernels:
         returns host (unique rows sorted lexicographically, index of the first occurrence of each)."""
         X = np.ascontiguousarray(X, dtype=np.float64)
         n, d = X.shape
-        xd = torch.from_numpy(X).to(self.device)
+        xd = self.h2d(X)
         uid = torch.empty(n, dtype=torch.int64, device=self.device)
         rows = torch.empty(n, d, dtype=torch.float64, device=self.device)
         cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -172,7 +200,7 @@ class HipKernels:
         _lib.check(self.lib.mvf_unique_rows(_ptr(xd), n, d, _ptr(uid), _ptr(rows), _ptr(cnt), _ptr(ws), ws.numel(),
                                             self._stream()), "mvf_unique_rows")
         k = int(cnt.cpu()[0])
-        return rows[:k].cpu().numpy(), uid[:k].cpu().numpy()
+        return self.d2h(rows[:k]), self.d2h(uid[:k])
 
     @_on_device
     def knn_mean_distance(self, X, k):
@@ -180,10 +208,10 @@ class HipKernels:
         neighbour search of dynamo's bandwidth_selector on the device (m <= 8192, d <= 8)."""
         X = np.ascontiguousarray(X, dtype=np.float64)
         m, d = X.shape
-        xd = torch.from_numpy(X).to(self.device)
+        xd = self.h2d(X)
         rows = torch.empty(m, dtype=torch.float64, device=self.device)
         _lib.check(self.lib.mvf_knn_rowsum(_ptr(xd), m, d, int(k), _ptr(rows), self._stream()), "mvf_knn_rowsum")
-        return float(np.sum(rows.cpu().numpy()) / (m * (k - 1)))
+        return float(np.sum(self.d2h(rows)) / (m * (k - 1)))
 
     @_on_device
     def con_k(self, x, y, beta, return_d=False, dtype=None):
@@ -454,12 +482,12 @@ class HipKernels:
     @_on_device
     def hull_mask(self, points, equations, tol):
         """Host (n, 3) points and SciPy ConvexHull.equations (nf, 4) -> host bool (n,): inside the hull."""
-        P = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float64)).to(self.device)
-        E = torch.from_numpy(np.ascontiguousarray(equations, dtype=np.float64)).to(self.device)
+        P = self.h2d(np.ascontiguousarray(points, dtype=np.float64))
+        E = self.h2d(np.ascontiguousarray(equations, dtype=np.float64))
         out = torch.empty(P.shape[0], dtype=torch.uint8, device=self.device)
         _lib.check(self.lib.mvf_hull_mask(_ptr(P), P.shape[0], _ptr(E), E.shape[0], float(tol), _ptr(out),
                                           self._stream()), "mvf_hull_mask")
-        return out.cpu().numpy().astype(bool)
+        return self.d2h(out).astype(bool)
 
     @_on_device
     def quadform(self, K, C, out):

@@ -43,6 +43,11 @@ def _to_host(k, tensors):
     return [t.cpu().numpy().copy() for t in tensors]
 
 
+def _d2h(k, t):
+    """One device tensor -> ordinary host NumPy array (through page-locked staging on the GPU path: `HipKernels.d2h`)."""
+    return k.d2h(t) if hasattr(k, "d2h") else t.cpu().numpy()
+
+
 _LSTSQ_WARNED = set()
 
 # Whole-call profile (bench.py's `whole_fit`, tools/): with PROFILE_FITS = True every SparseVFC call synchronises the device

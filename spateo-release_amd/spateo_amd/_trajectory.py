@@ -119,7 +119,7 @@ def integrate_field(vf_dict, init_states, t_end=None, interpolation_num=250, dir
         raise NotImplementedError("trajectory integration needs a field with Dy == D <= 3")
     C3 = np.zeros((len(ctrl), 3))
     C3[:, : Cc.shape[1]] = Cc
-    Cd = torch.from_numpy(C3).to(k.device)
+    Cd = k.h2d(C3)
     c4 = k.to_x4(ctrl, center)
     beta = float(vf_dict["beta"])
     arc = sampling == "arc_length"
@@ -137,15 +137,15 @@ def integrate_field(vf_dict, init_states, t_end=None, interpolation_num=250, dir
             tr = k.integrate(x4, c4, beta, Cd, sign * dt, max(2, int(substeps) // 2) if arc else substeps, n_fine,
                              affine=affine)
             if not arc:
-                xs.append(tr.cpu().numpy()[:, :, :d] + center[None, None, :d])
+                xs.append(_rt._d2h(k, tr)[:, :, :d] + center[None, None, :d])
                 continue
             # velocities at the dense samples (fused evaluator; same affine as the integrator), then dynamo's resampling
             pts = tr.reshape(-1, 3)
             p4 = torch.zeros(pts.shape[0], 4, dtype=k.tdtype, device=k.device)
             p4[:, :3] = pts.to(k.tdtype)
             vel = k.eval(p4, c4, beta, Cd, _lib.EVAL_V, affine=affine)[_lib.EVAL_V].reshape(tr.shape[0], n_fine, 3)
-            xk = tr.cpu().numpy()[:, :, :d]
-            tq, xq = _arc_length_resample(sign * tf, xk, sign * vel.cpu().numpy()[:, :, :d], n_t,
+            xk = _rt._d2h(k, tr)[:, :, :d]
+            tq, xq = _arc_length_resample(sign * tf, xk, sign * _rt._d2h(k, vel)[:, :, :d], n_t,
                                           stop_tol=1e-5 / float(np.max(vscale)))
             ts.append(tq)
             xs.append(xq + center[None, None, :d])
@@ -190,14 +190,14 @@ def genesis_states(vf_dict, init_states, time_vec, substeps=64, dtype=None, devi
     center = ctrl.mean(0)
     C3 = np.zeros((len(ctrl), 3))
     C3[:, :d] = Cc
-    Cd = torch.from_numpy(C3).to(k.device)
+    Cd = k.h2d(C3)
     c4 = k.to_x4(ctrl, center)
     beta = float(vf_dict["beta"])
     stages = []
     for dt in np.asarray(time_vec, dtype=np.float64):
         if dt != 0.0:
             tr = k.integrate(k.to_x4(pts, center), c4, beta, Cd, float(dt), int(substeps), 2)
-            pts = tr[:, 1, :d].cpu().numpy() + center[None, :d]
+            pts = _rt._d2h(k, tr[:, 1, :d]) + center[None, :d]
         stages.append(pts.copy())
     return stages
 

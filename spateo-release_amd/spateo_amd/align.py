@@ -66,7 +66,7 @@ def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, l
     Gamma = _consistent_K(k, ctrl, center, float(beta))  # generated like U (see SparseVFCEngine)
     f64 = torch.float64
     G, R = k.zeros(m, m, dtype=f64), k.zeros(m, 3, dtype=f64)
-    Pw = torch.from_numpy(w.astype(npdt)).to(k.device)
+    Pw = k.h2d(w.astype(npdt))
     ls2 = float(sigma2) * float(lambdaVF)
     step = 1.0
     if svi is None:
@@ -85,7 +85,7 @@ def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, l
         ones = torch.ones(n, dtype=Pw.dtype, device=k.device)
         k.gram(x4, ones, k.to_x4(B), c4, float(beta), G, R, rhs_only=True)
         # G <- step G + (1 - step) (SigmaInv_prev);  the regulariser enters the solve as (step ls2) Gamma
-        k.lincomb3(G, step, G, 1.0 - step, torch.from_numpy(S_prev).to(k.device))
+        k.lincomb3(G, step, G, 1.0 - step, k.h2d(S_prev))
     x4_I = None
     if guidance is not None:
         X_AI = np.asarray(guidance["X_AI"], dtype=np.float64)
@@ -119,15 +119,15 @@ def update_nonrigid(coordsA, inducing_variables, beta, K_NA, PXB_term, sigma2, l
             if shift > 2.0 ** -12:
                 raise _lib.MVFError("update_nonrigid: SigmaInv is not numerically positive semi-definite")
     V4, _ = k.apply(x4, c4, float(beta), C)
-    SigmaInv = G.cpu().numpy() + step * ls2 * Gamma.cpu().numpy()
+    SigmaInv = _rt._d2h(k, G) + step * ls2 * _rt._d2h(k, Gamma)
     # SigmaDiag = sigma2 diag(U pinv(SigmaInv) U^T) (morpho_class.py:1295-1297) from the decomposition the solve left
     diag = k.pinv_diag(x4, c4, float(beta), rcond=rcond, lowrank=lowrank) if hasattr(k, "pinv_diag") else None
-    out = {"SigmaInv": SigmaInv, "PXB_term": B, "Coff": C.cpu().numpy()[:, :D].copy(),
-           "VnA": V4[:, :D].to(f64).cpu().numpy()}
+    out = {"SigmaInv": SigmaInv, "PXB_term": B, "Coff": _rt._d2h(k, C)[:, :D].copy(),
+           "VnA": _rt._d2h(k, V4[:, :D].to(f64))}
     if diag is not None:
-        out["SigmaDiag"] = float(sigma2) * diag.cpu().numpy()
+        out["SigmaDiag"] = float(sigma2) * _rt._d2h(k, diag)
     if x4_I is not None:
-        out["V_AI"] = k.apply(x4_I, c4, float(beta), C)[0][:, :D].to(f64).cpu().numpy()
+        out["V_AI"] = _rt._d2h(k, k.apply(x4_I, c4, float(beta), C)[0][:, :D].to(f64))
     return out
 
 

@@ -1,6 +1,6 @@
 """Host-side preprocessing of SparseVFC: finite rows, `np.unique` rows, the
 velocity-weighted control-point draw (dynamo's `sample_by_velocity`: in-tree copy spateo/alignment/methods/sampling.py:225-241)
-and the kNN bandwidth rule -> beta.  NumPy on the host, bit-identical to the oracle on purpose; from 200 k rows / 1024 control
+and the kNN bandwidth rule -> beta.  NumPy on the host, bit-identical to the oracle on purpose; from 16 k rows / 1024 control
 points on the unique-rows and neighbour searches run on the device (`mvf_unique_rows`, `mvf_knn_rowsum`)."""
 from __future__ import annotations
 
@@ -81,13 +81,15 @@ def _sample_by_norms(tmp_V: np.ndarray, n: int, seed: int = 19491001) -> np.ndar
     return idx
 
 
-_DEVICE_UNIQUE_MIN_ROWS = 200_000
+# (measured, tools/unique_rows_small_probe.py: device 0.94 / 0.99 / 1.10 / 1.16 / 1.28 ms at 10 / 20 / 50 / 100 / 200 k rows incl. both
+# copies, host 0.66 / 1.44 / 3.89 / 8.28 / 17.5 ms - the round-4 threshold of 200 k rows left 2.8 ms of a 16 ms BASELINE config 2 call on the host)
+_DEVICE_UNIQUE_MIN_ROWS = 16_000
 
 
 def unique_rows(X: np.ndarray, device=None):
     """``np.unique(X, axis=0, return_index=True)`` (lexicographically sorted unique rows + index of the FIRST
     occurrence of each) without NumPy's structured-view sort, which is the slowest host step at millions of cells
-    (12 s at 8 M).  From 200 k rows on, with a GPU: ``mvf_unique_rows`` (stable LSD radix sort over the columns +
+    (12 s at 8 M).  From 16 k rows on, with a GPU: ``mvf_unique_rows`` (stable LSD radix sort over the columns +
     compaction on the device, ~0.1 s at 8 M).  Otherwise on the host: stable argsort on the first coordinate, then a
     stable lexsort only inside runs of equal first coordinates (2-5 s at 8 M).  Both are bit-identical to np.unique for
     finite input; anything else takes the NumPy route."""

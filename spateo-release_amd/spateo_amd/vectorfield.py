@@ -74,16 +74,16 @@ def con_K(x, y, beta: float = 0.1, method: str = "cdist", return_d: bool = False
     npdt = np.float32 if dtype == "float32" else np.float64
     # translation invariance: centre before a possible cast to float32
     c = y.mean(0) if len(y) else np.zeros(x.shape[1])
-    xd = torch.from_numpy(np.ascontiguousarray((x - c).astype(npdt))).to(k.device)
-    yd = torch.from_numpy(np.ascontiguousarray((y - c).astype(npdt))).to(k.device)
+    xd = k.h2d((x - c).astype(npdt))
+    yd = k.h2d((y - c).astype(npdt))
     if return_d or method != "cdist":
         K, D = k.con_k(xd, yd, beta, return_d=True)
-        K = K.to(torch.float64).cpu().numpy()
+        K = _rt._d2h(k, K.to(torch.float64))
         K = np.squeeze(K)
         if return_d:
-            return K, D.to(torch.float64).cpu().numpy()
+            return K, _rt._d2h(k, D.to(torch.float64))
         return K
-    K = k.con_k(xd, yd, beta).to(torch.float64).cpu().numpy()
+    K = _rt._d2h(k, k.con_k(xd, yd, beta).to(torch.float64))
     if len(K) == 1:
         K = K.flatten()
     return K
@@ -177,7 +177,7 @@ def _field_on_device(x, vf_dict, flags, dtype=None, device=None, rows3=False):
         c4 = k.to_x4(Xc, center)
         C3 = np.zeros((len(Xc), 3))
         C3[:, : Cc.shape[1]] = Cc
-        Cd = torch.from_numpy(C3).to(k.device)
+        Cd = k.h2d(C3)
         return k.eval(x4, c4, beta, Cd, fl)
 
     return _fused_eval(x, ("svc", Xc, Cc, beta), flags, k, launch, rows3)
@@ -544,7 +544,7 @@ def _gp_eval(X, vf_dict, flags, nonrigid_only=False, dtype=None, device=None, ro
         x4, c4 = k.to_x4(xn, center), k.to_x4(ind, center)
         C3 = np.zeros((len(ind), 3))
         C3[:, : Coff.shape[1]] = Coff
-        Cd = torch.from_numpy(C3).to(k.device)
+        Cd = k.h2d(C3)
         return k.eval(x4, c4, beta, Cd, fl, affine=(alpha3, float(ratio[0]), A3, b3))
 
     return _fused_eval(X, ("gp", ind, Coff, beta, sf, stt, A3, b3, mean_t), flags, k, launch, rows3)

@@ -72,6 +72,10 @@ class CpuKernels:
         buf[:, : a.shape[1]] = a
         return torch.from_numpy(buf)
 
+    def h2d(self, a, tdtype=None):
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(tdtype) if tdtype is not None and tdtype != t.dtype else t
+
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.tdtype)
 
