@@ -11,8 +11,43 @@ for p in (ROOT, os.path.join(ROOT, "spateo-release_amd")):
         sys.path.insert(0, p)
 
 
+def _cpu_budget():
+    """CPUs the container really grants (affinity capped by the CFS quota of cgroup v2): the GPU boxes show 256 CPUs and hold a
+    quota of 16 - BLAS / torch pools sized by the CPU count get the whole test process throttled."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return n
+
+
+_POOL_LIMIT = None
+
+
 def pytest_configure(config):
+    global _POOL_LIMIT
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
+    n = _cpu_budget()
+    if n < (os.cpu_count() or 1):  # only where a quota / affinity is in force: the oracle's BLAS and torch's CPU pool follow it
+        try:
+            from threadpoolctl import threadpool_limits
+
+            _POOL_LIMIT = threadpool_limits(limits=n)
+        except Exception:
+            pass
+        try:
+            import torch
+
+            torch.set_num_threads(n)
+        except Exception:
+            pass
 
 
 @pytest.fixture(scope="session")
