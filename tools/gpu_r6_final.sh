@@ -18,6 +18,11 @@ print("headline", d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofli
 print("config", json.dumps(d['config']))
 print("cpu", d['cpu_baseline']['value'], d['cpu_baseline']['sample_value'], d.get('speedup_vs_cpu_baseline'))
 PY
+# the multi-rank code path of bench.py on this ONE GPU (2 and 4 ranks on cuda:0, gloo collectives: RCCL refuses two ranks per device)
+for N in 2 4; do
+  MVF_BENCH_ONE_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2951$N bench.py --gpus $N --steps 2 --warmup 1 --cells 2000000 > $OUT/bench_${N}ranks_one_device.json 2> $OUT/bench_${N}ranks_one_device.err; echo "ranks $N rc $?"
+  python -c "import json;d=json.load(open('$OUT/bench_${N}ranks_one_device.json'));print(d['n_gpus'],d['value'],d['ms_per_step'],d['config'].get('collectives_per_step'))" 2>&1 | tail -1
+done
 cd /tmp
 timeout 1200 rocprofv3 --kernel-trace --stats -d $OUT/prof -o p -- python $R/bench.py --no-conk --cpu-cells 0 --no-measure-traffic --no-whole-fit --no-rccl-world1 > $OUT/bench_under_rocprof.json 2> $OUT/prof.log; echo "rocprof bench rc=$?"
 DB=$(find $OUT/prof -name "*.db" | head -1)
