@@ -125,8 +125,14 @@ def test_estep_vs_oracle(st, dtype):
     assert mins[1] > 0  # the outliers underflow: the min-non-zero rule is exercised
     np.testing.assert_allclose(mins[0], t1[t1 != 0].min(), rtol=1e-12)
     Pd = torch.empty(n, dtype=rd.dtype, device="cuda:0")
-    stats = torch.zeros(4, dtype=torch.float64, device="cuda:0")
+    stats = torch.zeros(5, dtype=torch.float64, device="cuda:0")
     k.estep_p(rd, sigma2, gamma, a, 3, minP, theta, float(mins[0]), Pd, stats)
+    # mvf_estep (ABI 7): both phases in one call, the fill taken from the device, the statistics OVERWRITTEN - the same bits
+    P2 = torch.empty(n, dtype=rd.dtype, device="cuda:0")
+    stats2 = torch.full((5,), 123.0, dtype=torch.float64, device="cuda:0")
+    k.estep(rd, sigma2, gamma, a, 3, minP, theta, P2, stats2)
+    assert torch.equal(P2, Pd) and torch.equal(stats2, stats)
+    assert float(stats[4]) == mins[1]  # the cells that took the fill
     # oracle on the SAME (possibly float32-rounded) residuals: V' chosen so that ||Y - V'||^2 == r_dev
     Vp = Y.copy()
     Vp[:, 0] -= np.sqrt(r_dev.astype(np.float64))
