@@ -699,6 +699,62 @@ def test_pinv_diag_is_the_leverage_of_the_kernel_matrix(st, m, lowrank):
     assert abs(d.sum() - int(e[1])) < 1e-3 * int(e[1])
 
 
+def _greedy_pivoted_cholesky(A, tol):
+    """Diagonally pivoted Cholesky, largest remaining diagonal first (ties: lowest index), stopped when it is <= tol: the order
+    and the pivot values mvf_solve_minnorm_lr's cold factorisation must take (NumPy float64, right-looking)."""
+    A = A.copy()
+    m = len(A)
+    d = np.diag(A).copy()
+    order, piv, rows = [], [], []
+    alive = np.ones(m, dtype=bool)
+    for _ in range(m):
+        dm = np.where(alive, d, -np.inf)
+        p = int(np.argmax(dm))
+        if not dm[p] > tol:
+            break
+        row = A[p].copy()
+        for y in rows:
+            row -= y * y[p]
+        y = np.where(alive, row / np.sqrt(row[p]), 0.0)
+        order.append(p)
+        piv.append(row[p])
+        rows.append(y)
+        d = d - y * y
+        alive[p] = False
+    return np.asarray(order), np.asarray(piv)
+
+
+@pytest.mark.parametrize("n,m", [(4000, 300), (6000, 500), (5000, 512)])
+def test_cold_pivoted_factorisation_up_to_512_columns_takes_the_greedy_pivots(st, n, m):
+    """Up to 512 columns the cold factorisation (no pivot order to follow: a fit's first EM iteration) runs its pivot steps 32
+    per launch in ONE workgroup with the sub-block's rows in LDS (pchol_steps_kernel, round 6).  Its pivots must be the greedy
+    ones: the same order as a NumPy diagonally pivoted Cholesky wherever the choice is not a rounding-level near-tie, the same
+    pivot values, the same rank; and the solve on top of it the reference's solution."""
+    import scipy.linalg
+
+    k = _k("float64")
+    U, G, K, R, ls2 = _kernel_system(n, m)
+    A = G + ls2 * K
+    C, info, e = _run_minnorm(k, G, K, ls2, R, method="lowrank")
+    assert info == 0
+    order, vals, tol = k.lr_pivot_order(m, with_values=True)
+    ref_order, ref_vals = _greedy_pivoted_cholesky(A, tol)
+    r = len(order)
+    assert abs(r - len(ref_order)) <= 2, (r, len(ref_order))
+    q = min(r, len(ref_order))
+    same = order[:q] == ref_order[:q]
+    first_diff = int(np.argmin(same)) if not same.all() else q
+    # the early pivots are separated by far more than rounding: identical; later ones may swap between near-equal diagonals
+    assert first_diff >= min(q, 64), (first_diff, order[:8], ref_order[:8])
+    assert len(set(order.tolist())) == r  # every column at most once
+    # (pivot values: relative to the largest one - the last pivots are differences of numbers 1e10 times their size)
+    np.testing.assert_allclose(vals[:first_diff], ref_vals[:first_diff], rtol=1e-6, atol=1e-12 * vals[0])
+    F_ref = U @ scipy.linalg.lstsq(A, R)[0]
+    dev = np.abs(U @ C - F_ref).max() / np.abs(F_ref).max()
+    print(f"m={m}: rank {r} (numpy greedy {len(ref_order)}), identical pivots up to step {first_diff}, field vs lstsq {dev:.2e}")
+    assert dev < 0.1  # (sanity only: where the system is rank deficient the solve's parity is the floor tests' business)
+
+
 def test_solve_minnorm_lr_follows_the_previous_pivot_order(st):
     """rank_hint > 0: the factorisation follows the pivot order the previous call left in the workspace, 64 columns per
     three launches, accepting each pivot only while it is not small against the remaining diagonal.  Same matrix: same
