@@ -97,7 +97,25 @@ class HipKernels:
             # the rest of the scheduler period: 50 - 90 ms stalls every few calls, `nr_throttled` in /sys/fs/cgroup/cpu.stat)
             np.copyto(host.numpy(), a, casting="unsafe")
             return host.to(self.device, non_blocking=True)
-        return t.to(self.device) if dt == t.dtype else t.to(self.device).to(dt)
+        if t.numel() == 0:
+            return t.to(self.device).to(dt)
+        # larger arrays: the same, streamed through two page-locked 32 MB staging buffers (the cast, if any, on the device)
+        flat = a.reshape(-1)
+        out = torch.empty(flat.shape, dtype=t.dtype, device=self.device)
+        per = max(1, (32 << 20) // a.itemsize)
+        stage = [torch.empty(per, dtype=t.dtype, pin_memory=True) for _ in range(2)]
+        free = [None, None]
+        stream = torch.cuda.current_stream(self.device)
+        for i, lo in enumerate(range(0, flat.shape[0], per)):
+            hi, b = min(lo + per, flat.shape[0]), i & 1
+            if free[b] is not None:
+                free[b].synchronize()
+            np.copyto(stage[b].numpy()[: hi - lo], flat[lo:hi])
+            out[lo:hi].copy_(stage[b][: hi - lo], non_blocking=True)
+            free[b] = torch.cuda.Event()
+            free[b].record(stream)
+        out = out.reshape(t.shape)
+        return out if dt == t.dtype else out.to(dt)
 
     def h2d_padded(self, a, width, tdtype, minus=None):
         """Host (n, d <= width) float64 array -> device (n, width) tensor of `tdtype`, zero padded.  minus (1 x d float64, may
