@@ -486,7 +486,8 @@ class HipKernels:
             if reuse:
                 raise RuntimeError("solve_minnorm_lr(reuse=True) without a previous decomposition")
             self._lr_ws = None
-            self._lr_ws = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
+            # (zeroed: the 64-byte state record in it must not be read as a finished factorisation - ADVICE r5; once per allocation)
+            self._lr_ws = torch.zeros(max(need, 1), dtype=torch.uint8, device=self.device)
         rc = float(np.finfo(np.float64).eps) if rcond is None else float(rcond)
         _lib.check(fn(_ptr(G), _ptr(K), float(lambda_sigma2), float(tolf), rc, _ptr(R), m, nrhs, _ptr(C_out), _ptr(info),
                       _ptr(einfo), int(max_sweeps), 1 if reuse else 0, int(rank_hint), _ptr(self._lr_ws),
