@@ -2234,6 +2234,19 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
     PcholState hs;
     const bool timing = debug_opt(DBG_LR_TIMING) != 0;  // developer option: phase times on stderr
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // the timing events (developer option) are destroyed on EVERY path out of this function, early error returns included
+    // (they leaked there); an explicit drop_events() before a tail call keeps them from outliving their use
+    auto drop_events = [&ev]() {
+        for (auto& e : ev)
+            if (e) {
+                (void)hipEventDestroy(e);
+                e = nullptr;
+            }
+    };
+    struct EventGuard {
+        decltype(drop_events)& drop;
+        ~EventGuard() { drop(); }
+    } event_guard{drop_events};
     if (timing && !reuse) {
         for (auto& e : ev) MVF_CHECK_HIP(hipEventCreate(&e));
         MVF_CHECK_HIP(hipEventRecord(ev[0], st));
@@ -2386,7 +2399,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             MVF_CHECK_HIP(rb_sync(st));
             if (!(hprev.magic == PCHOL_MAGIC && hprev.order_len == (int)m)) {
                 if (timing)
-                    for (auto& e : ev) (void)hipEventDestroy(e);
+                    drop_events();
                 return lr_solve(G, K, lambda_sigma2, tolf, rcond, R, m, nrhs, C, info, einfo, max_sweeps, reuse, rank_hint, workspace,
                                 workspace_bytes, stream, deflate, false);
             }
@@ -2395,7 +2408,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
                 MVF_CHECK_HIP(hipMemcpyAsync(&stt->direct_skip, left, sizeof(left), hipMemcpyHostToDevice, st));
                 MVF_CHECK_HIP(rb_sync(st));
                 if (timing)
-                    for (auto& e : ev) (void)hipEventDestroy(e);
+                    drop_events();
                 return lr_solve(G, K, lambda_sigma2, tolf, rcond, R, m, nrhs, C, info, einfo, max_sweeps, reuse, rank_hint, workspace,
                                 workspace_bytes, stream, deflate, false);
             }
@@ -2483,7 +2496,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
                                dacc0 > 0 ? (double)(dacc0 - 1) : (double)DEFL_TINY_ACCEPT);
             MVF_LAUNCH_CHECK();
             if (timing)
-                for (auto& e : ev) (void)hipEventDestroy(e);
+                drop_events();
             return 0;
         }
         // ONE device -> host copy decides (einfo[0..5], info, the state flag, the power iteration's last two quotients), and
@@ -2516,7 +2529,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             fprintf(stderr, "    Rayleigh-Ritz sweeps (active rounds / rotations):");
             for (int q = 0; q < 12; ++q) fprintf(stderr, " %u/%u", hsw[2 * q], hsw[2 * q + 1]);
             fprintf(stderr, "\n");
-            for (auto& e : ev) (void)hipEventDestroy(e);
+            drop_events();
         }
         if (ok) {
             // the workspace now holds: the same pivot order (all m columns), their pivots, E = Rc^-T and its transpose, the block
@@ -2803,7 +2816,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
             MVF_CHECK_HIP(hipMemcpyAsync(einfo + 7, hblk, sizeof(hblk), hipMemcpyHostToDevice, st));  // [8] = the form, [9] = 0
             MVF_CHECK_HIP(rb_sync(st));
             if (timing)
-                for (auto& e : ev) (void)hipEventDestroy(e);
+                drop_events();
             return 0;
         }
         MVF_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int), st));  // the Jacobi path below starts clean (Y is untouched)
@@ -2870,7 +2883,7 @@ static int lr_solve(const double* G, const double* K, double lambda_sigma2, doub
         (void)hipMemcpy(hc, rot, sizeof(hc), hipMemcpyDeviceToHost);
         fprintf(stderr, "    eig kernel sections (100 MHz ticks): load %u, rounds %u, store %u\n", hc[4], hc[5], hc[6]);
 #endif
-        for (auto& e : ev) (void)hipEventDestroy(e);
+        drop_events();
     }
     const double hsw[1] = {(double)sweeps + (hrot != 0 ? 0.5 : 0.0)};  // x.5 = sweep cap hit before convergence
     MVF_CHECK_HIP(hipMemcpyAsync(einfo, hsw, sizeof(double), hipMemcpyHostToDevice, st));
