@@ -154,9 +154,11 @@ def test_sparsevfc_non_finite_rows_and_duplicates(st):
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
-@pytest.mark.parametrize("dy", [1, 5])
+@pytest.mark.parametrize("dy", [1, 5, 16, 31])
 def test_sparsevfc_wide_and_narrow_outputs(st, dtype, dy):
-    """Dy != D (kernel_interpolation's call shape): 3-column groups sharing one Gram matrix per EM step."""
+    """Dy != D (kernel_interpolation's call shape): 3-column groups sharing one Gram matrix per EM step.  Dy = 16 and 31: the
+    column counts at which 3 x the number of groups overshoots the 16-column padding of the wide path's buffers (a fit with 16
+    genes raised a shape error until the re-entry of round 6: found by tools/api_stall_probe.py, no test had that width)."""
     rng = np.random.default_rng(dy)
     X, _ = _c2(5000)
     Y = np.column_stack([np.sin(X[:, 0] / 80 + j) + 0.3 * np.cos(X[:, 1] / 60 * (j + 1)) for j in range(dy)])
